@@ -1,0 +1,187 @@
+/*
+ * vo_hip.h -- C ABI of libvo_hip.so: the MI355X (gfx950) implementation of the
+ * projective-ICP hot path of lucanunz/Visual-odometry.
+ *
+ * Every entry point replaces one interface of the reference (cited as
+ * <file>:<line> under the reference tree).  The reference has no FFI: its
+ * "plugin API" for this path is two C++ classes (Camera, PICPSolver) and a few
+ * free functions; include/vo/ *.hpp re-create those on top of this ABI.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++ / torch types.
+ *  - matrices are COLUMN-major, exactly the memory of the Eigen objects the
+ *    reference passes around (defs.h:7-29): K = Eigen::Matrix3f (9 floats),
+ *    T/X = Eigen::Isometry3f (4x4, 16 floats).
+ *  - point arrays are the contiguous storage of the reference's std::vectors:
+ *    Vector3fVector -> float[3n], Vector2fVector -> float[2n],
+ *    Vector10fVector -> float[10n], IntPairVector -> int32_t[2n] (first,second).
+ *  - functions return 0 (VO_OK) or a negative vo_status; vo_last_error() gives
+ *    the message of the last failure on the calling thread.
+ *  - unless the name ends in _dev, array arguments are HOST pointers: inputs
+ *    are copied to the GPU, outputs copied back, and the call returns when the
+ *    outputs are valid.  *_dev variants take DEVICE pointers (memory from
+ *    vo_dev_alloc or any hipMalloc), enqueue on the context's stream and do not
+ *    synchronise; counts are then produced in device memory.
+ *  - a vo_ctx and the handles created from it must be used by one host thread
+ *    at a time (the reference objects are not thread-safe either).
+ *  - there is NO CPU fallback: every entry point fails with VO_ERR_NO_DEVICE if
+ *    no gfx950 device can be used.
+ */
+#ifndef VO_HIP_H
+#define VO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_HIP_ABI_VERSION 1
+
+typedef enum vo_status {
+  VO_OK = 0,
+  VO_ERR_INVALID_ARG = -1,
+  VO_ERR_NO_DEVICE = -2,
+  VO_ERR_HIP = -3,
+  VO_ERR_OUT_OF_MEMORY = -4,
+  VO_ERR_BAD_INDEX = -5,   /* a correspondence index is outside its array */
+  VO_ERR_NOT_READY = -6    /* e.g. one_round before set_points */
+} vo_status;
+
+typedef struct vo_ctx vo_ctx;     /* one per (device, stream) */
+typedef struct vo_picp vo_picp;   /* device twin of a PICPSolver */
+
+int vo_abi_version(void);
+const char *vo_last_error(void);
+
+/* ---- context ----------------------------------------------------------- */
+/* stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL
+ * to let the context create its own non-blocking stream. */
+int vo_ctx_create(int device, void *stream, vo_ctx **out);
+int vo_ctx_destroy(vo_ctx *ctx);
+int vo_ctx_synchronize(vo_ctx *ctx);
+void *vo_ctx_stream(vo_ctx *ctx);
+int vo_ctx_device(vo_ctx *ctx);
+/* name of the device ("gfx950...") and number of compute units */
+int vo_ctx_device_info(vo_ctx *ctx, char *name, int name_len, int *n_cu);
+
+/* device memory helpers for callers without a HIP runtime of their own */
+int vo_dev_alloc(vo_ctx *ctx, size_t bytes, void **dptr);
+int vo_dev_free(vo_ctx *ctx, void *dptr);
+int vo_memcpy_h2d(vo_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes); /* synchronous */
+int vo_memcpy_d2h(vo_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* synchronous */
+
+/* ---- Camera::projectPoints (camera.cpp:16-37; projectPoint camera.h:25-37) */
+/* out_uv has room for n points.  keep_indices!=0: *n_out = n and invalid
+ * points are (-1,-1); keep_indices==0: valid points only, input order kept.
+ * *n_inside = the reference's return value (number of points inside). */
+int vo_project_points(vo_ctx *ctx, int rows, int cols, int z_near, int z_far, const float K[9],
+                      const float T[16], const float *world_xyz, int n, int keep_indices,
+                      float *out_uv, int *n_out, int *n_inside);
+/* device form: d_counts[0] = n_out, d_counts[1] = n_inside */
+int vo_project_points_dev(vo_ctx *ctx, int rows, int cols, int z_near, int z_far, const float K[9],
+                          const float T[16], const float *d_world_xyz, int n, int keep_indices,
+                          float *d_out_uv, int *d_counts);
+
+/* ---- PICPSolver (picp_solver.h:18-79, picp_solver.cpp) ----------------- */
+/* ctor: threshold 1000, damping 1, min inliers 0 (picp_solver.cpp:6-14) */
+int vo_picp_create(vo_ctx *ctx, vo_picp **out);
+int vo_picp_destroy(vo_picp *s);
+/* init(camera, world, image) (picp_solver.cpp:16-23).  The reference stores
+ * raw pointers to the caller's vectors; this copies them to the GPU. */
+int vo_picp_set_camera(vo_picp *s, int rows, int cols, int z_near, int z_far, const float K[9],
+                       const float T[16]);
+int vo_picp_set_points(vo_picp *s, const float *world_xyz, int n_world, const float *meas_uv,
+                       int n_meas);
+/* borrowed device arrays; must stay valid until the next set_points* call */
+int vo_picp_set_points_dev(vo_picp *s, const float *d_world_xyz, int n_world,
+                           const float *d_meas_uv, int n_meas);
+int vo_picp_set_pose(vo_picp *s, const float T[16]);            /* camera.h:50 */
+int vo_picp_set_kernel_threshold(vo_picp *s, float thr);        /* picp_solver.h:35 */
+int vo_picp_get_kernel_threshold(vo_picp *s, float *thr);       /* picp_solver.h:33 */
+/* oneRound(correspondences, keep_outliers) (picp_solver.cpp:98-112):
+ * pairs = (measurement index, world index).  Enqueues one Gauss-Newton
+ * iteration and returns without waiting; the pose/statistics getters are the
+ * synchronisation points.  The pairs are uploaded when (pointer, count,
+ * sampled content) differ from the previous call.  As in the reference it
+ * cannot fail on "too few inliers" (min_num_inliers is 0 with no setter). */
+int vo_picp_one_round(vo_picp *s, const int32_t *pairs, int n_pairs, int keep_outliers);
+/* n_iters x oneRound with no host round trip in between */
+int vo_picp_solve(vo_picp *s, const int32_t *pairs, int n_pairs, int keep_outliers, int n_iters);
+/* device pairs; d_n_pairs (may be NULL) points at a device int that overrides
+ * n_pairs (<= n_pairs), so the output of the join kernel can be consumed
+ * without a host round trip. */
+int vo_picp_solve_dev(vo_picp *s, const int32_t *d_pairs, int n_pairs, const int *d_n_pairs,
+                      int keep_outliers, int n_iters);
+int vo_picp_get_pose(vo_picp *s, float T[16]);                  /* camera(), picp_solver.h:41 */
+int vo_picp_get_pose_dev(vo_picp *s, float *d_T16);             /* async copy on the stream */
+int vo_picp_get_stats(vo_picp *s, float *chi_inliers, float *chi_outliers, int *num_inliers); /* :44-50 */
+/* H (6x6 col-major, damping included, as _H after oneRound) and b of the last round */
+int vo_picp_get_system(vo_picp *s, float H[36], float b[6]);
+
+/* Batched solver: n_problems independent (camera, points, pairs) problems,
+ * every one iterated n_iters times inside one launch.  Arrays are DEVICE
+ * pointers; problem p uses world[p*world_stride..], meas[p*meas_stride..],
+ * pairs[p*pairs_stride..] (strides in elements of the respective type:
+ * points, points, pairs) and n_pairs[p] pairs.  All share rows/cols/z/K/thr.
+ * d_T0: n_problems initial poses (16 floats each) or NULL for identity;
+ * d_T_out: n_problems final poses; d_stats_out (may be NULL): per problem
+ * {chi_inliers, chi_outliers, (float)num_inliers, 0}. */
+int vo_picp_solve_batch_dev(vo_ctx *ctx, int n_problems, int rows, int cols, int z_near, int z_far,
+                            const float K[9], float kernel_threshold, int keep_outliers,
+                            const float *d_world_xyz, size_t world_stride, const float *d_meas_uv,
+                            size_t meas_stride, const int32_t *d_pairs, size_t pairs_stride,
+                            const int *d_n_pairs, const float *d_T0, int n_iters, float *d_T_out,
+                            float *d_stats_out);
+
+/* ---- compute_correspondences_images (vo_complete.cpp:12-49) ------------ */
+/* Exact nearest neighbour within `radius` in the 10-D appearance space,
+ * replacing TreeNode_::bestMatchFull (eigen_kdtree.h:90-115): the larger set
+ * is searched (ties: a1), the smaller set queries in ascending index, a hit
+ * needs squared distance < radius*radius (strict), pairs are emitted as
+ * (index in a1, index in a2).  Exact-distance ties go to the lowest index.
+ * out_pairs has room for min(n1,n2) pairs. */
+int vo_match_appearances(vo_ctx *ctx, const float *a1, int n1, const float *a2, int n2,
+                         float radius, int32_t *out_pairs, int *n_out);
+int vo_match_appearances_dev(vo_ctx *ctx, const float *d_a1, int n1, const float *d_a2, int n2,
+                             float radius, int32_t *d_out_pairs, int *d_n_out);
+
+/* ---- extract_correspondences_world (vo_complete.cpp:52-66) ------------- */
+/* For each image pair (ref,cur) in order, the FIRST world pair (ref',w) with
+ * ref'==ref gives (cur,w); image pairs without partner are dropped.
+ * out_pairs has room for n_img pairs. */
+int vo_join_correspondences(vo_ctx *ctx, const int32_t *img_pairs, int n_img,
+                            const int32_t *world_pairs, int n_world, int32_t *out_pairs,
+                            int *n_out);
+/* device form; the counts may come from device memory (NULL -> use n_img / n_world);
+ * n_ref = size of the reference index space (all .first values < n_ref). */
+int vo_join_correspondences_dev(vo_ctx *ctx, const int32_t *d_img_pairs, int n_img,
+                                const int *d_n_img, const int32_t *d_world_pairs, int n_world,
+                                const int *d_n_world, int n_ref, int32_t *d_out_pairs,
+                                int *d_n_out);
+
+/* ---- Isometry3f * point set (PointCloud.h:77-82, vo_daKnown.cpp:144) --- */
+int vo_transform_points(vo_ctx *ctx, const float T[16], const float *in_xyz, int n,
+                        float *out_xyz);
+int vo_transform_points_dev(vo_ctx *ctx, const float T[16], const float *d_in_xyz, int n,
+                            const int *d_n, float *d_out_xyz);
+
+/* ---- triangulate_points (utils.cpp:51-134; triangulate_point :36-49) --- */
+/* pairs = (index in p1, index in p2); X = pose of the first camera in the
+ * frame of the second.  Survivors are written densely in input order:
+ * out_xyz[k], out_pairs[k] = (index in p2, k) (may be NULL: overload v1),
+ * out_app[k] = app2[index in p2] when app2/out_app are non-NULL (overload
+ * v3).  Output arrays have room for n pairs.  Returns the count in *n_out. */
+int vo_triangulate(vo_ctx *ctx, const float K[9], const float X[16], const int32_t *pairs, int n,
+                   const float *p1_uv, int n1, const float *p2_uv, int n2, const float *app2,
+                   float *out_xyz, int32_t *out_pairs, float *out_app, int *n_out);
+int vo_triangulate_dev(vo_ctx *ctx, const float K[9], const float X[16], const float *d_X16,
+                       const int32_t *d_pairs, int n, const int *d_n, const float *d_p1_uv, int n1,
+                       const float *d_p2_uv, int n2, const float *d_app2, float *d_out_xyz,
+                       int32_t *d_out_pairs, float *d_out_app, int *d_n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_HIP_H */

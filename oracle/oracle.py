@@ -1,0 +1,212 @@
+"""ctypes front-end of the CPU oracle (oracle/libvo_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py; never by the product package.
+
+PARITY UNPINNED at kernel level (see vo_oracle_impl.h): the reference has no
+golden vectors for this path and needs Eigen3, which the image lacks.
+
+All matrices cross this interface as numpy arrays in the usual mathematical
+(row, col) indexing; they are flattened column-major (Eigen's default layout)
+before they reach C.  `bits` selects ref32 (float, the reference's arithmetic)
+or ref64 (double, the arbiter).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libvo_oracle.so")
+    src = [os.path.join(_HERE, f) for f in ("vo_oracle.c", "vo_oracle_impl.h")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+    return _LIB
+
+
+@dataclass
+class Camera:
+    """Mirror of the reference Camera's state (camera.h:55-61)."""
+    rows: int = 100
+    cols: int = 100
+    z_near: int = 0
+    z_far: int = 10
+    K: np.ndarray = field(default_factory=lambda: np.eye(3))
+    T: np.ndarray = field(default_factory=lambda: np.eye(4))
+
+
+def _cam_struct(real):
+    class S(C.Structure):
+        _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("z_near", C.c_int), ("z_far", C.c_int),
+                    ("K", real * 9), ("T", real * 16)]
+    return S
+
+
+def _picp_struct(real, cam_t):
+    class S(C.Structure):
+        _fields_ = [("cam", cam_t), ("kernel_threshold", real), ("damping", real),
+                    ("min_num_inliers", C.c_int), ("world", C.c_void_p), ("meas", C.c_void_p),
+                    ("H", real * 36), ("b", real * 6), ("chi_inliers", real),
+                    ("chi_outliers", real), ("num_inliers", C.c_int)]
+    return S
+
+
+class Oracle:
+    def __init__(self, bits: int = 32):
+        assert bits in (32, 64)
+        self.bits = bits
+        self.dt = np.float32 if bits == 32 else np.float64
+        self.real = C.c_float if bits == 32 else C.c_double
+        self.pfx = "vo32_" if bits == 32 else "vo64_"
+        self.cam_t = _cam_struct(self.real)
+        self.picp_t = _picp_struct(self.real, self.cam_t)
+        self.L = lib()
+
+    # -- helpers ---------------------------------------------------------
+    def _f(self, name):
+        return getattr(self.L, self.pfx + name)
+
+    def _arr(self, a, shape=None):
+        a = np.ascontiguousarray(np.asarray(a, dtype=self.dt))
+        if shape is not None:
+            a = a.reshape(shape)
+        return a
+
+    def _p(self, a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def _cam(self, cam: Camera):
+        s = self.cam_t()
+        s.rows, s.cols, s.z_near, s.z_far = int(cam.rows), int(cam.cols), int(cam.z_near), int(cam.z_far)
+        K = np.asarray(cam.K, dtype=self.dt).reshape(3, 3)
+        T = np.asarray(cam.T, dtype=self.dt).reshape(4, 4)
+        s.K[:] = K.ravel(order="F").tolist()
+        s.T[:] = T.ravel(order="F").tolist()
+        return s
+
+    @staticmethod
+    def _pairs(p):
+        return np.ascontiguousarray(np.asarray(p, dtype=np.int32).reshape(-1, 2))
+
+    # -- Camera ----------------------------------------------------------
+    def project_points(self, cam: Camera, world, keep_indices: bool = False):
+        w = self._arr(world, (-1, 3))
+        out = np.empty((len(w), 2), dtype=self.dt)
+        n_out = C.c_int(0)
+        s = self._cam(cam)
+        f = self._f("project_points")
+        f.restype = C.c_int
+        n_in = f(C.byref(s), self._p(w), C.c_int(len(w)), C.c_int(int(keep_indices)), self._p(out),
+                 C.byref(n_out))
+        return out[: n_out.value].copy(), int(n_in)
+
+    # -- PICPSolver ------------------------------------------------------
+    def picp_solve(self, cam: Camera, world, meas, corr, n_iters: int, kernel_threshold=1000.0,
+                   keep_outliers: bool = False, trace: bool = True):
+        """n_iters x oneRound from cam.T; returns the final pose and, when
+        trace, per-iteration H (pre-damping), b, (chi_in, chi_out, n_in), T."""
+        w = self._arr(world, (-1, 3))
+        z = self._arr(meas, (-1, 2))
+        cp = self._pairs(corr)
+        s = self.picp_t()
+        self._f("picp_ctor")(C.byref(s))
+        cs = self._cam(cam)
+        self._f("picp_init")(C.byref(s), C.byref(cs), self._p(w), self._p(z))
+        s.kernel_threshold = kernel_threshold
+        tH = np.zeros((n_iters, 36), dtype=self.dt) if trace else None
+        tb = np.zeros((n_iters, 6), dtype=self.dt) if trace else None
+        ts = np.zeros((n_iters, 3), dtype=self.dt) if trace else None
+        tT = np.zeros((n_iters, 16), dtype=self.dt) if trace else None
+        nul = C.c_void_p(0)
+        self._f("picp_solve")(C.byref(s), self._p(cp), C.c_int(len(cp)), C.c_int(int(keep_outliers)),
+                              C.c_int(n_iters),
+                              self._p(tH) if trace else nul, self._p(tb) if trace else nul,
+                              self._p(ts) if trace else nul, self._p(tT) if trace else nul)
+        res = {
+            "T": np.array(s.cam.T[:], dtype=self.dt).reshape(4, 4, order="F"),
+            "chi_inliers": float(s.chi_inliers), "chi_outliers": float(s.chi_outliers),
+            "num_inliers": int(s.num_inliers),
+        }
+        if trace:
+            res["H"] = tH.reshape(n_iters, 6, 6).transpose(0, 2, 1).copy()  # col-major -> (r,c)
+            res["b"] = tb
+            res["stats"] = ts
+            res["T_trace"] = tT.reshape(n_iters, 4, 4).transpose(0, 2, 1).copy()
+        return res
+
+    def ldlt_solve(self, A, rhs):
+        A = np.asarray(A, dtype=self.dt)
+        n = A.shape[0]
+        Af = np.ascontiguousarray(A.ravel(order="F"))
+        r = self._arr(rhs)
+        x = np.zeros(n, dtype=self.dt)
+        self._f("ldlt_solve")(C.c_int(n), self._p(Af), self._p(r), self._p(x))
+        return x
+
+    def v2t_euler(self, v):
+        v = self._arr(v)
+        T = np.zeros(16, dtype=self.dt)
+        self._f("v2t_euler")(self._p(v), self._p(T))
+        return T.reshape(4, 4, order="F")
+
+    # -- triangulation ---------------------------------------------------
+    def triangulate(self, K, X, corr, p1, p2, app2=None, want_pairs=True):
+        Kf = np.ascontiguousarray(np.asarray(K, dtype=self.dt).reshape(3, 3).ravel(order="F"))
+        Xf = np.ascontiguousarray(np.asarray(X, dtype=self.dt).reshape(4, 4).ravel(order="F"))
+        cp = self._pairs(corr)
+        a = self._arr(p1, (-1, 2))
+        b = self._arr(p2, (-1, 2))
+        n = len(cp)
+        xyz = np.zeros((n, 3), dtype=self.dt)
+        pairs = np.zeros((n, 2), dtype=np.int32)
+        app = self._arr(app2, (-1, 10)) if app2 is not None else None
+        oapp = np.zeros((n, 10), dtype=self.dt) if app is not None else None
+        f = self._f("triangulate_points")
+        f.restype = C.c_int
+        nul = C.c_void_p(0)
+        m = f(self._p(Kf), self._p(Xf), self._p(cp), C.c_int(n), self._p(a), self._p(b),
+              self._p(app) if app is not None else nul, self._p(xyz),
+              self._p(pairs) if want_pairs else nul, self._p(oapp) if oapp is not None else nul)
+        return xyz[:m].copy(), pairs[:m].copy(), (oapp[:m].copy() if oapp is not None else None)
+
+    # -- matcher / join / transform ---------------------------------------
+    def match(self, a1, a2, radius=0.1):
+        x = self._arr(a1, (-1, 10))
+        y = self._arr(a2, (-1, 10))
+        out = np.zeros((min(len(x), len(y)), 2), dtype=np.int32)
+        f = self._f("match")
+        f.restype = C.c_int
+        n = f(self._p(x), C.c_int(len(x)), self._p(y), C.c_int(len(y)), self.real(radius), self._p(out))
+        return out[:n].copy()
+
+    def join(self, img_pairs, world_pairs, linear=False):
+        a = self._pairs(img_pairs)
+        b = self._pairs(world_pairs)
+        out = np.zeros((len(a), 2), dtype=np.int32)
+        f = self.L.vo_join_linear if linear else self.L.vo_join
+        f.restype = C.c_int
+        n = f(self._p(a), C.c_int(len(a)), self._p(b), C.c_int(len(b)), self._p(out))
+        return out[:n].copy()
+
+    def transform_points(self, T, pts):
+        Tf = np.ascontiguousarray(np.asarray(T, dtype=self.dt).reshape(4, 4).ravel(order="F"))
+        p = self._arr(pts, (-1, 3))
+        out = np.zeros_like(p)
+        self._f("transform_points")(self._p(Tf), self._p(p), C.c_int(len(p)), self._p(out))
+        return out

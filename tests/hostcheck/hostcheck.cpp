@@ -1,0 +1,60 @@
+// hostcheck.cpp -- compiles the __host__ __device__ functors of
+// visual-odometry_amd/csrc/vo_math.h with g++ so that the per-element logic the
+// kernels run (projection gates, PICP term, pivoted LDLT, pose update,
+// triangulate_point) can be compared with the oracle in the GPU-less
+// container.  TEST INFRASTRUCTURE: not part of libvo_hip.so, never shipped.
+#include "../../visual-odometry_amd/csrc/vo_math.h"
+
+using namespace vo;
+
+static CamK mk(int rows, int cols, int zn, int zf, const float* K) {
+  CamK c; for (int i = 0; i < 9; ++i) c.K[i] = K[i];
+  c.rows = rows; c.cols = cols; c.z_near = zn; c.z_far = zf; return c;
+}
+
+extern "C" {
+
+int hc_project_point(int rows, int cols, int zn, int zf, const float* K, const float* T16,
+                     const float* p, float* uv) {
+  float pc[3], ph[3], inv;
+  return project_point(mk(rows, cols, zn, zf, K), pose_from_T16(T16), p[0], p[1], p[2], uv[0], uv[1], pc, ph, inv) ? 1 : 0;
+}
+
+// accumulates n correspondences sequentially into acc[30] (zeroed here)
+void hc_picp_accumulate(int rows, int cols, int zn, int zf, const float* K, const float* T16, float thr,
+                        int keep, const float* world, const float* meas, const int* corr, int n, float* acc) {
+  const CamK cam = mk(rows, cols, zn, zf, K);
+  const Pose T = pose_from_T16(T16);
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float* w = world + 3 * corr[2 * i + 1];
+    const float* z = meas + 2 * corr[2 * i];
+    picp_accumulate(cam, T, thr, keep != 0, w[0], w[1], w[2], z[0], z[1], acc);
+  }
+}
+
+void hc_picp_update(const float* acc, float damping, const float* T16, float* T16_out, float* H, float* b) {
+  const Pose Tn = picp_update(acc, damping, pose_from_T16(T16), H, b);
+  pose_to_T16(Tn, T16_out);
+}
+
+void hc_ldlt6(const float* A_colmajor, const float* rhs, float* x) {
+  float a[6][6];
+  for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) a[r][c] = A_colmajor[r + 6 * c];
+  ldlt6_solve(a, rhs, x);
+}
+
+void hc_ldlt2(const float* m, const float* rhs, float* x) { ldlt2_solve(m[0], m[1], m[3], rhs[0], rhs[1], x[0], x[1]); }
+
+int hc_triangulate_point(const float* d1, const float* d2, const float* p2, float* p) {
+  return triangulate_point(d1, d2, p2, p) ? 1 : 0;
+}
+
+void hc_tri_constants(const float* K, const float* X16, float* iK, float* iRiK, float* t) {
+  const TriConst c = tri_constants(K, pose_from_T16(X16));
+  for (int i = 0; i < 9; ++i) { iK[i] = c.iK[i]; iRiK[i] = c.iRiK[i]; }
+  for (int i = 0; i < 3; ++i) t[i] = c.t[i];
+}
+
+void hc_v2t(const float* v, float* T16) { pose_to_T16(v2t_euler(v), T16); }
+}

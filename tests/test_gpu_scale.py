@@ -1,0 +1,100 @@
+"""Full-size (BASELINE config 2: 50 000 points) checks through size-independent
+properties plus a direct oracle comparison where the oracle finishes in seconds."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle.oracle import Camera as OCam
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(vo):
+    return vo.synth.frame_pair(50000, seed=2000)
+
+
+def test_matcher_50k_is_the_permutation(vo, ctx, big):
+    m = vo.compute_correspondences_images(big["ref_app"], big["cur_app"], ctx=ctx)
+    gt = big["gt_matches"]
+    gt = gt[np.argsort(gt[:, 1], kind="stable")]
+    assert np.array_equal(m, gt)                    # every landmark found, exact indices, query order
+    # symmetric call: roles swap, pairs stay (a1 idx, a2 idx)
+    m2 = vo.compute_correspondences_images(big["cur_app"], big["ref_app"], ctx=ctx)
+    assert np.array_equal(m2[np.argsort(m2[:, 1], kind="stable")][:, ::-1], gt[np.argsort(gt[:, 0], kind="stable")])
+
+
+def test_frame_50k_against_oracle(vo, ctx, o32, o64, big):
+    m = vo.compute_correspondences_images(big["ref_app"], big["cur_app"], ctx=ctx)
+    j = vo.extract_correspondences_world(m, big["model_pairs"], ctx=ctx)
+    assert np.array_equal(j, o32.join(m, big["model_pairs"], linear=True)) and len(j) == 50000
+    cam = vo.Camera(480, 640, 0, 10, big["K"], np.eye(4), ctx=ctx)
+    s = vo.PICPSolver(ctx)
+    s.setKernelThreshold(10000.0)
+    s.init(cam, big["model"], big["cur_pts"])
+    s.oneRound(j, False)
+    H, b = s.system()
+    ocam = OCam(480, 640, 0, 10, big["K"], np.eye(4))
+    r64 = o64.picp_solve(ocam, big["model"], big["cur_pts"], j, 50, 10000.0, False)
+    r32 = o32.picp_solve(ocam, big["model"], big["cur_pts"], j, 50, 10000.0, False)
+    assert rel_err(H - np.eye(6, dtype=np.float32), r64["H"][0]) < 1e-5
+    assert rel_err(b, r64["b"][0]) < 1e-5
+    # the GPU's tree reduction must be at least as close to ref64 as the reference's own sequential sum
+    assert rel_err(H - np.eye(6, dtype=np.float32), r64["H"][0]) <= rel_err(r32["H"][0], r64["H"][0]) * 2 + 1e-6
+    s.solve(j, False, 49)
+    T = s.camera().worldInCameraPose()
+    assert s.numInliers() == 50000 == r32["num_inliers"]
+    assert np.abs(T - r32["T"]).max() < 1e-4 and np.abs(T - r64["T"]).max() < 1e-4
+    assert np.abs(T - big["X_gt"]).max() < 1e-3                        # and it is the right answer
+    assert abs(s.chiInliers() - r64["chi_inliers"]) < 1e-4 * r64["chi_inliers"]
+    # triangulate with the estimated pose: survivors exact, points within tolerance, pairs (cur idx, slot)
+    xyz, pairs, app = vo.triangulate_points(big["K"], T, m, big["ref_pts"], big["cur_pts"], big["cur_app"], ctx=ctx)
+    xo, po, ao = o32.triangulate(big["K"], T, m, big["ref_pts"], big["cur_pts"], big["cur_app"])
+    assert np.array_equal(pairs, po) and np.array_equal(app, ao)
+    assert np.all(np.abs(xyz - xo) <= 1e-4 * np.maximum(1, np.abs(xo)))
+    assert np.array_equal(pairs[:, 1], np.arange(len(pairs)))
+    # transform round trip (linearity / invertibility property)
+    Xi = np.linalg.inv(T.astype(np.float64)).astype(np.float32)
+    back = vo.transform_points(Xi, vo.transform_points(T, big["model"], ctx=ctx), ctx=ctx)
+    assert np.abs(back - big["model"]).max() < 1e-4
+    s.close()
+
+
+def test_batched_solver_matches_single(vo, ctx):
+    """vo_picp_solve_batch_dev on P problems == P independent PICPSolver runs."""
+    import ctypes as C
+    P, n, iters = 5, 3000, 15
+    fps = [vo.synth.frame_pair(n, seed=4000 + p) for p in range(P)]
+    lib = ctx.lib
+    world = np.stack([f["model"] for f in fps]); meas = np.stack([f["cur_pts"] for f in fps])
+    pairs = []
+    for f in fps:
+        mp = dict(f["model_pairs"].tolist())
+        pairs.append(np.array([(c, mp[r]) for r, c in f["gt_matches"].tolist()], np.int32))
+    npairs = np.array([len(p) for p in pairs], np.int32)
+    stride = max(npairs)
+    pbuf = np.zeros((P, stride, 2), np.int32)
+    for i, p in enumerate(pairs):
+        pbuf[i, : len(p)] = p
+    d_world, d_meas, d_pairs, d_n = (ctx.to_device(a) for a in (world, meas, pbuf, npairs))
+    d_T = ctx.alloc(P * 16 * 4); d_stats = ctx.alloc(P * 4 * 4)
+    K = np.ascontiguousarray(fps[0]["K"].T).ravel()
+    rc = lib.vo_picp_solve_batch_dev(ctx.h, P, 480, 640, 0, 10, K.ctypes.data_as(C.c_void_p), C.c_float(10000.0), 0,
+                                     C.c_void_p(d_world), C.c_size_t(n), C.c_void_p(d_meas), C.c_size_t(n),
+                                     C.c_void_p(d_pairs), C.c_size_t(stride), C.c_void_p(d_n), None, iters,
+                                     C.c_void_p(d_T), C.c_void_p(d_stats))
+    assert rc == 0, lib.vo_last_error()
+    T = np.zeros((P, 16), np.float32); st = np.zeros((P, 4), np.float32)
+    ctx.d2h(T, d_T); ctx.d2h(st, d_stats)
+    for p in range(P):
+        cam = vo.Camera(480, 640, 0, 10, fps[p]["K"], np.eye(4), ctx=ctx)
+        s = vo.PICPSolver(ctx); s.setKernelThreshold(10000.0)
+        s.init(cam, fps[p]["model"], fps[p]["cur_pts"])
+        s.solve(pairs[p], False, iters)
+        Ts = s.camera().worldInCameraPose()
+        assert np.abs(T[p].reshape(4, 4).T - Ts).max() < 2e-5          # different reduction tree only
+        assert int(st[p, 2]) == s.numInliers() == n
+        assert np.abs(T[p].reshape(4, 4).T - fps[p]["X_gt"]).max() < 1e-3
+        s.close()
+    for d in (d_world, d_meas, d_pairs, d_n, d_T, d_stats):
+        ctx.free(d)

@@ -1,0 +1,128 @@
+"""The per-element functors the kernels run (vo_math.h), compiled for the host
+with g++, against the oracle.  Decision-making values must agree bit for bit;
+accumulators (which use FMA) to rounding."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle.oracle import Camera
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hc():
+    so = os.path.join(HERE, "hostcheck", "libvo_hostcheck.so")
+    src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
+    hdr = os.path.join(HERE, "..", "visual-odometry_amd", "csrc", "vo_math.h")
+    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-Wno-unknown-pragmas", "-o", so, src])
+    return C.CDLL(so)
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def cm(M, n):
+    return np.ascontiguousarray(np.asarray(M, np.float32).reshape(n, n).T).ravel()
+
+
+def test_projection_is_bit_exact(hc, o32, vo):
+    rng = np.random.default_rng(1)
+    T = vo.synth.random_isometry(rng, 0.3, 0.5)
+    cam = Camera(480, 640, 0, 10, vo.synth.K_REF, T)
+    pts = vo.synth.random_points3d(rng, 4000) * np.float32([0.3, 0.3, 4.0])
+    uv_o, _ = o32.project_points(cam, pts, keep_indices=True)
+    uv = np.zeros(2, np.float32)
+    n_ok = 0
+    for i in range(len(pts)):
+        ok = hc.hc_project_point(480, 640, 0, 10, p(cm(cam.K, 3)), p(cm(T, 4)), p(pts[i]), p(uv))
+        if ok:
+            n_ok += 1
+            assert uv.tobytes() == uv_o[i].tobytes()
+        else:
+            assert uv_o[i, 0] == -1
+    assert 100 < n_ok < len(pts)
+
+
+def test_picp_term_and_update(hc, o32, o64, vo):
+    fp = vo.synth.frame_pair(1500, seed=41, drop=0.05, distractors=5, model_drop=0.05)
+    j = o32.join(o32.match(fp["ref_app"], fp["cur_app"]), fp["model_pairs"])
+    cam = Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4))
+    for thr, keep in ((10000.0, 0), (50.0, 0), (50.0, 1)):
+        r32 = o32.picp_solve(cam, fp["model"], fp["cur_pts"], j, 1, thr, bool(keep))
+        r64 = o64.picp_solve(cam, fp["model"], fp["cur_pts"], j, 1, thr, bool(keep))
+        acc = np.zeros(30, np.float32)
+        hc.hc_picp_accumulate(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], p(cm(fp["K"], 3)),
+                              p(cm(np.eye(4), 4)), C.c_float(thr), keep, p(fp["model"]), p(fp["cur_pts"]),
+                              p(j), len(j), p(acc))
+        H = np.zeros((6, 6), np.float32)
+        H[np.triu_indices(6)] = acc[:21]
+        H = H + np.triu(H, 1).T
+        # same sequential order as the oracle; only FMA rounding differs
+        assert rel_err(H, r32["H"][0]) < 2e-6 and rel_err(acc[21:27], r32["b"][0]) < 2e-5
+        assert rel_err(H, r64["H"][0]) < 3e-5
+        assert acc[29] == r32["stats"][0, 2]                                   # inlier count: exact
+        assert abs(acc[27] - r32["stats"][0, 0]) <= 1e-6 * max(1, r32["stats"][0, 0])
+        assert abs(acc[28] - r32["stats"][0, 1]) <= 1e-6 * max(1, r32["stats"][0, 1])
+        T1 = np.zeros(16, np.float32); Hd = np.zeros(36, np.float32); b = np.zeros(6, np.float32)
+        hc.hc_picp_update(p(acc), C.c_float(1.0), p(cm(np.eye(4), 4)), p(T1), p(Hd), p(b))
+        assert np.abs(T1.reshape(4, 4).T - r32["T_trace"][0]).max() < 2e-5
+        assert np.array_equal(Hd.reshape(6, 6).T, H + np.eye(6, dtype=np.float32))
+
+
+def test_ldlt6_bit_exact_with_oracle(hc, o32):
+    rng = np.random.default_rng(2)
+    for k in range(50):
+        A = rng.normal(size=(9, 6)).astype(np.float32)
+        S = (A.T @ A).astype(np.float32)
+        if k % 3 == 0:
+            S = S * np.float32(10.0) ** rng.integers(-3, 6, 6)[None, :] * np.float32(10.0) ** rng.integers(-3, 6, 6)[:, None]
+            S = ((S + S.T) / 2).astype(np.float32)
+        S += np.eye(6, dtype=np.float32)
+        b = rng.normal(size=6).astype(np.float32)
+        x = np.zeros(6, np.float32)
+        hc.hc_ldlt6(p(np.ascontiguousarray(S.T).ravel()), p(b), p(x))
+        assert x.tobytes() == o32.ldlt_solve(S, b).tobytes()
+    z = np.zeros(6, np.float32)
+    hc.hc_ldlt6(p(np.zeros(36, np.float32)), p(np.ones(6, np.float32)), p(z))
+    assert np.all(z == 0)
+
+
+def test_ldlt2_and_triangulate_point_bit_exact(hc, o32):
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        d1 = rng.normal(size=3).astype(np.float32); d2 = rng.normal(size=3).astype(np.float32)
+        t = rng.normal(size=3).astype(np.float32)
+        out = np.zeros(3, np.float32); ref = np.zeros(3, np.float32)
+        ok = hc.hc_triangulate_point(p(d1), p(d2), p(t), p(out))
+        f = o32._f("triangulate_point"); f.restype = C.c_int
+        ok_ref = f(p(d1), p(d2), p(t), p(ref))
+        assert ok == ok_ref
+        if ok:
+            assert out.tobytes() == ref.tobytes()
+    m = np.array([4.0, 1.0, 1.0, 9.0], np.float32); rhs = np.array([1.0, 2.0], np.float32); x = np.zeros(2, np.float32)
+    hc.hc_ldlt2(p(m), p(rhs), p(x))
+    assert x.tobytes() == o32.ldlt_solve(m.reshape(2, 2), rhs).tobytes()
+
+
+def test_tri_constants_and_v2t(hc, o32, vo):
+    rng = np.random.default_rng(4)
+    X = vo.synth.random_isometry(rng)
+    iK = np.zeros(9, np.float32); iRiK = np.zeros(9, np.float32); t = np.zeros(3, np.float32)
+    hc.hc_tri_constants(p(cm(vo.synth.K_REF, 3)), p(cm(X, 4)), p(iK), p(iRiK), p(t))
+    ref = np.zeros(9, np.float32)
+    o32._f("mat3_inverse")(p(cm(vo.synth.K_REF, 3)), p(ref))
+    assert iK.tobytes() == ref.tobytes()
+    assert np.allclose(iK.reshape(3, 3).T, np.linalg.inv(vo.synth.K_REF), atol=1e-6)
+    assert np.allclose(t, np.linalg.inv(X.astype(np.float64))[:3, 3], atol=1e-6)
+    v = rng.uniform(-0.5, 0.5, 6).astype(np.float32)
+    T = np.zeros(16, np.float32)
+    hc.hc_v2t(p(v), p(T))
+    assert T.reshape(4, 4).T.tobytes() == o32.v2t_euler(v).tobytes()

@@ -1,0 +1,727 @@
+// capi.hip -- the extern "C" boundary of libvo_hip.so (see include/vo_hip.h).
+// Host-side plumbing only: argument checks, device buffers, uploads, launches.
+// There is no CPU implementation of any operator behind these entry points.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "../../include/vo_hip.h"
+#include "vo_internal.h"
+
+using namespace vo;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define VO_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess)                                                               \
+      return fail(_e == hipErrorOutOfMemory ? VO_ERR_OUT_OF_MEMORY : VO_ERR_HIP,        \
+                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+#define VO_REQUIRE(cond, msg) \
+  do { if (!(cond)) return fail(VO_ERR_INVALID_ARG, "%s: %s", __func__, msg); } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  // grow-only; contents are NOT preserved
+  hipError_t ensure(size_t bytes, hipStream_t st) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipStreamSynchronize(st);
+      if (e != hipSuccess) return e;
+      (void)hipFree(p);
+      p = nullptr; cap = 0;
+    }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    cap = want;
+    return hipSuccess;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct vo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int n_cu = 0;
+  char name[128] = "";
+  DevBuf scratch;     // compaction counts
+  DevBuf best;        // matcher keys
+  DevBuf table;       // join table
+  DevBuf in[6];       // staging for host-pointer entry points
+  DevBuf out[3];
+  DevBuf counts;      // small device ints
+  DevBuf batch_pack;  // packed correspondences of the batched solver
+};
+
+struct vo_picp {
+  vo_ctx* ctx = nullptr;
+  PicpParams hp;               // host mirror of the device parameters
+  PicpParams* d_params = nullptr;
+  PicpState* d_state = nullptr;
+  bool params_dirty = true;
+  DevBuf world_own, meas_own, pairs_own, packed, partials;
+  const float* d_world = nullptr;
+  const float* d_meas = nullptr;
+  int n_world = 0, n_meas = 0;
+  bool have_points = false;
+  // cache key of the correspondences already packed
+  const void* key_ptr = nullptr;
+  int key_n = -1;
+  uint64_t key_hash = 0;
+  bool key_dev = false;
+  bool packed_valid = false;
+  int grid = 1;
+  int use_graph = 1;
+  std::map<std::tuple<int, int, const void*, size_t, const void*>, hipGraphExec_t> graphs;
+};
+
+static int set_device(vo_ctx* ctx) {
+  VO_HIP_CHECK(hipSetDevice(ctx->device));
+  return VO_OK;
+}
+
+extern "C" {
+
+int vo_abi_version(void) { return VO_HIP_ABI_VERSION; }
+const char* vo_last_error(void) { return g_err; }
+
+int vo_ctx_create(int device, void* stream, vo_ctx** out) {
+  VO_REQUIRE(out != nullptr, "out is null");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(VO_ERR_NO_DEVICE, "no HIP device available (%s); libvo_hip has no CPU fallback",
+                e == hipSuccess ? "count=0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(VO_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, n);
+  VO_HIP_CHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  VO_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(VO_ERR_NO_DEVICE, "device %d is %s; libvo_hip is built for gfx950 only", device,
+                prop.gcnArchName);
+  vo_ctx* c = new vo_ctx();
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount;
+  snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+  if (stream) {
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+  } else {
+    hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (es != hipSuccess) { delete c; return fail(VO_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(es)); }
+    c->own_stream = true;
+  }
+  *out = c;
+  return VO_OK;
+}
+
+int vo_ctx_destroy(vo_ctx* c) {
+  if (!c) return VO_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  c->scratch.release(); c->best.release(); c->table.release(); c->counts.release();
+  c->batch_pack.release();
+  for (auto& b : c->in) b.release();
+  for (auto& b : c->out) b.release();
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return VO_OK;
+}
+
+int vo_ctx_synchronize(vo_ctx* c) {
+  VO_REQUIRE(c, "ctx is null");
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+void* vo_ctx_stream(vo_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
+int vo_ctx_device(vo_ctx* c) { return c ? c->device : -1; }
+
+int vo_ctx_device_info(vo_ctx* c, char* name, int name_len, int* n_cu) {
+  VO_REQUIRE(c, "ctx is null");
+  if (name && name_len > 0) { strncpy(name, c->name, (size_t)name_len - 1); name[name_len - 1] = 0; }
+  if (n_cu) *n_cu = c->n_cu;
+  return VO_OK;
+}
+
+int vo_dev_alloc(vo_ctx* c, size_t bytes, void** dptr) {
+  VO_REQUIRE(c && dptr, "null argument");
+  if (int r = set_device(c)) return r;
+  VO_HIP_CHECK(hipMalloc(dptr, bytes ? bytes : 16));
+  return VO_OK;
+}
+
+int vo_dev_free(vo_ctx* c, void* dptr) {
+  VO_REQUIRE(c, "ctx is null");
+  if (!dptr) return VO_OK;
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  VO_HIP_CHECK(hipFree(dptr));
+  return VO_OK;
+}
+
+int vo_memcpy_h2d(vo_ctx* c, void* dst, const void* src, size_t bytes) {
+  VO_REQUIRE(c && (bytes == 0 || (dst && src)), "null argument");
+  if (bytes == 0) return VO_OK;
+  VO_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+int vo_memcpy_d2h(vo_ctx* c, void* dst, const void* src, size_t bytes) {
+  VO_REQUIRE(c && (bytes == 0 || (dst && src)), "null argument");
+  if (bytes == 0) return VO_OK;
+  VO_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+}  // extern "C"
+
+// ---- helpers for the host-pointer entry points ------------------------------------
+static int upload(vo_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+  VO_HIP_CHECK(b.ensure(bytes ? bytes : 16, c->stream));
+  if (bytes) VO_HIP_CHECK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  return VO_OK;
+}
+
+static int ensure_counts(vo_ctx* c) {
+  VO_HIP_CHECK(c->counts.ensure(64 * sizeof(int), c->stream));
+  return VO_OK;
+}
+
+static int ensure_scratch(vo_ctx* c, int n) {
+  VO_HIP_CHECK(c->scratch.ensure(compaction_scratch_ints(n) * sizeof(int), c->stream));
+  return VO_OK;
+}
+
+static CamK make_cam(int rows, int cols, int z_near, int z_far, const float K[9]) {
+  CamK cam;
+  for (int i = 0; i < 9; ++i) cam.K[i] = K[i];
+  cam.rows = rows; cam.cols = cols; cam.z_near = z_near; cam.z_far = z_far;
+  return cam;
+}
+
+extern "C" {
+
+// ---- projectPoints ------------------------------------------------------------------
+int vo_project_points_dev(vo_ctx* c, int rows, int cols, int z_near, int z_far, const float K[9],
+                          const float T[16], const float* d_world, int n, int keep_indices,
+                          float* d_out_uv, int* d_counts) {
+  VO_REQUIRE(c && K && T && d_counts, "null argument");
+  VO_REQUIRE(n >= 0 && (n == 0 || (d_world && d_out_uv)), "bad point arrays");
+  if (int r = set_device(c)) return r;
+  if (int r = ensure_scratch(c, n)) return r;
+  VO_HIP_CHECK(launch_project_points(c->stream, make_cam(rows, cols, z_near, z_far, K),
+                                     pose_from_T16(T), d_world, n, keep_indices, d_out_uv, d_counts,
+                                     c->scratch.as<int>()));
+  return VO_OK;
+}
+
+int vo_project_points(vo_ctx* c, int rows, int cols, int z_near, int z_far, const float K[9],
+                      const float T[16], const float* world, int n, int keep_indices, float* out_uv,
+                      int* n_out, int* n_inside) {
+  VO_REQUIRE(c && K && T, "null argument");
+  VO_REQUIRE(n >= 0 && (n == 0 || (world && out_uv)), "bad point arrays");
+  if (int r = set_device(c)) return r;
+  if (int r = upload(c, c->in[0], world, sizeof(float) * 3 * (size_t)n)) return r;
+  VO_HIP_CHECK(c->out[0].ensure(sizeof(float) * 2 * (size_t)(n ? n : 1), c->stream));
+  if (int r = ensure_counts(c)) return r;
+  if (int r = vo_project_points_dev(c, rows, cols, z_near, z_far, K, T, c->in[0].as<float>(), n,
+                                    keep_indices, c->out[0].as<float>(), c->counts.as<int>()))
+    return r;
+  int h[2] = {0, 0};
+  VO_HIP_CHECK(hipMemcpyAsync(h, c->counts.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (h[0] > 0)
+    VO_HIP_CHECK(hipMemcpy(out_uv, c->out[0].p, sizeof(float) * 2 * (size_t)h[0], hipMemcpyDeviceToHost));
+  if (n_out) *n_out = h[0];
+  if (n_inside) *n_inside = h[1];
+  return VO_OK;
+}
+
+// ---- PICPSolver -----------------------------------------------------------------------
+int vo_picp_create(vo_ctx* c, vo_picp** out) {
+  VO_REQUIRE(c && out, "null argument");
+  *out = nullptr;
+  if (int r = set_device(c)) return r;
+  vo_picp* s = new vo_picp();
+  s->ctx = c;
+  memset(&s->hp, 0, sizeof(s->hp));
+  const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  s->hp.cam = make_cam(100, 100, 0, 10, I3);     // Camera defaults, camera.h:16-21
+  s->hp.thr = 1000.f;                            // picp_solver.cpp:13
+  s->hp.damping = 1.f;                           // picp_solver.cpp:10
+  s->hp.keep_outliers = 0;
+  s->hp.n_corr = 0;
+  const char* g = getenv("VO_PICP_GRAPH");
+  if (g) s->use_graph = atoi(g);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_params), sizeof(PicpParams));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_state), sizeof(PicpState));
+  if (e == hipSuccess) e = hipMemsetAsync(s->d_state, 0, sizeof(PicpState), c->stream);
+  if (e != hipSuccess) {
+    if (s->d_params) (void)hipFree(s->d_params);
+    if (s->d_state) (void)hipFree(s->d_state);
+    delete s;
+    return fail(VO_ERR_HIP, "vo_picp_create: %s", hipGetErrorString(e));
+  }
+  // identity pose
+  float pose[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+  VO_HIP_CHECK(hipMemcpyAsync(s->d_state->pose[0], pose, sizeof(pose), hipMemcpyHostToDevice, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  *out = s;
+  return VO_OK;
+}
+
+int vo_picp_destroy(vo_picp* s) {
+  if (!s) return VO_OK;
+  (void)hipSetDevice(s->ctx->device);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+  s->world_own.release(); s->meas_own.release(); s->pairs_own.release();
+  s->packed.release(); s->partials.release();
+  if (s->d_params) (void)hipFree(s->d_params);
+  if (s->d_state) (void)hipFree(s->d_state);
+  delete s;
+  return VO_OK;
+}
+
+int vo_picp_set_pose(vo_picp* s, const float T[16]) {
+  VO_REQUIRE(s && T, "null argument");
+  if (int r = set_device(s->ctx)) return r;
+  const Pose P = pose_from_T16(T);
+  float pose[12];
+  for (int i = 0; i < 9; ++i) pose[i] = P.R[i];
+  for (int i = 0; i < 3; ++i) pose[9 + i] = P.t[i];
+  VO_HIP_CHECK(hipMemcpyAsync(s->d_state->pose[0], pose, sizeof(pose), hipMemcpyHostToDevice,
+                              s->ctx->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));   // `pose` is a stack buffer
+  return VO_OK;
+}
+
+int vo_picp_set_camera(vo_picp* s, int rows, int cols, int z_near, int z_far, const float K[9],
+                       const float T[16]) {
+  VO_REQUIRE(s && K && T, "null argument");
+  s->hp.cam = make_cam(rows, cols, z_near, z_far, K);
+  s->params_dirty = true;
+  return vo_picp_set_pose(s, T);
+}
+
+int vo_picp_set_kernel_threshold(vo_picp* s, float thr) {
+  VO_REQUIRE(s, "null argument");
+  s->hp.thr = thr;
+  s->params_dirty = true;
+  return VO_OK;
+}
+
+int vo_picp_get_kernel_threshold(vo_picp* s, float* thr) {
+  VO_REQUIRE(s && thr, "null argument");
+  *thr = s->hp.thr;
+  return VO_OK;
+}
+
+int vo_picp_set_points_dev(vo_picp* s, const float* d_world, int n_world, const float* d_meas, int n_meas) {
+  VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(n_world >= 0 && n_meas >= 0, "negative count");
+  VO_REQUIRE((n_world == 0 || d_world) && (n_meas == 0 || d_meas), "null point array");
+  s->d_world = d_world; s->n_world = n_world;
+  s->d_meas = d_meas; s->n_meas = n_meas;
+  s->have_points = true;
+  s->packed_valid = false;
+  return VO_OK;
+}
+
+int vo_picp_set_points(vo_picp* s, const float* world, int n_world, const float* meas, int n_meas) {
+  VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(n_world >= 0 && n_meas >= 0, "negative count");
+  VO_REQUIRE((n_world == 0 || world) && (n_meas == 0 || meas), "null point array");
+  if (int r = set_device(s->ctx)) return r;
+  if (int r = upload(s->ctx, s->world_own, world, sizeof(float) * 3 * (size_t)n_world)) return r;
+  if (int r = upload(s->ctx, s->meas_own, meas, sizeof(float) * 2 * (size_t)n_meas)) return r;
+  VO_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));
+  return vo_picp_set_points_dev(s, s->world_own.as<float>(), n_world, s->meas_own.as<float>(), n_meas);
+}
+
+}  // extern "C"
+
+static uint64_t sample_hash(const int32_t* pairs, int n) {
+  // cheap content fingerprint: <= 64 pairs spread over the array
+  uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
+  const int step = n > 64 ? n / 64 : 1;
+  for (int i = 0; i < n; i += step) {
+    h = (h ^ (uint32_t)pairs[2 * i]) * 1099511628211ull;
+    h = (h ^ (uint32_t)pairs[2 * i + 1]) * 1099511628211ull;
+  }
+  if (n > 0) {
+    h = (h ^ (uint32_t)pairs[2 * (n - 1)]) * 1099511628211ull;
+    h = (h ^ (uint32_t)pairs[2 * (n - 1) + 1]) * 1099511628211ull;
+  }
+  return h;
+}
+
+static int picp_prepare(vo_picp* s, const int32_t* d_pairs, int n_pairs, const int* d_n, int keep_outliers) {
+  vo_ctx* c = s->ctx;
+  if (!s->have_points) return fail(VO_ERR_NOT_READY, "vo_picp: set_points has not been called");
+  if (s->hp.keep_outliers != (keep_outliers ? 1 : 0)) { s->hp.keep_outliers = keep_outliers ? 1 : 0; s->params_dirty = true; }
+  if (s->params_dirty) {
+    // n_corr is owned by the pack kernel: keep the device value
+    VO_HIP_CHECK(hipMemcpyAsync(s->d_params, &s->hp, offsetof(PicpParams, n_corr), hipMemcpyHostToDevice,
+                                c->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    s->params_dirty = false;
+  }
+  if (!s->packed_valid) {
+    const size_t cap = ((size_t)(n_pairs > 0 ? n_pairs : 1) + 3) & ~(size_t)3;
+    VO_HIP_CHECK(s->packed.ensure(sizeof(float) * 5 * cap, c->stream));
+    s->grid = picp_grid_for(n_pairs, c->n_cu);
+    VO_HIP_CHECK(s->partials.ensure(sizeof(float) * 2 * (size_t)s->grid * PICP_PSTRIDE, c->stream));
+    PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
+    VO_HIP_CHECK(launch_picp_pack(c->stream, d_pairs, d_n, n_pairs, s->d_world, s->n_world, s->d_meas,
+                                  s->n_meas, pk, s->d_params, s->d_state));
+    s->packed_valid = true;
+  }
+  return VO_OK;
+}
+
+static int picp_enqueue(vo_picp* s, int n_iters) {
+  vo_ctx* c = s->ctx;
+  PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
+  float* partials = s->partials.as<float>();
+  if (s->use_graph && n_iters >= 2) {
+    auto key = std::make_tuple(n_iters, s->grid, (const void*)pk.base, pk.cap, (const void*)partials);
+    auto it = s->graphs.find(key);
+    if (it == s->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        hipError_t el = launch_picp_rounds(c->stream, s->d_params, s->d_state, pk, partials, s->grid, n_iters);
+        e = hipStreamEndCapture(c->stream, &graph);
+        if (e == hipSuccess && el != hipSuccess) e = el;
+      }
+      if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        s->use_graph = 0;   // fall back to plain launches for the rest of this handle's life
+      } else {
+        if (s->graphs.size() > 32) {
+          for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+          s->graphs.clear();
+        }
+        it = s->graphs.emplace(key, exec).first;
+      }
+    }
+    if (s->use_graph && it != s->graphs.end()) {
+      VO_HIP_CHECK(hipGraphLaunch(it->second, c->stream));
+      return VO_OK;
+    }
+  }
+  VO_HIP_CHECK(launch_picp_rounds(c->stream, s->d_params, s->d_state, pk, partials, s->grid, n_iters));
+  return VO_OK;
+}
+
+extern "C" {
+
+int vo_picp_solve_dev(vo_picp* s, const int32_t* d_pairs, int n_pairs, const int* d_n_pairs,
+                      int keep_outliers, int n_iters) {
+  VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || d_pairs), "bad pairs");
+  VO_REQUIRE(n_iters >= 0, "negative n_iters");
+  if (int r = set_device(s->ctx)) return r;
+  // device pairs may have been rewritten in place by the producer: always re-pack
+  s->packed_valid = false;
+  s->key_ptr = nullptr; s->key_n = -1;
+  if (int r = picp_prepare(s, d_pairs, n_pairs, d_n_pairs, keep_outliers)) return r;
+  return picp_enqueue(s, n_iters);
+}
+
+int vo_picp_solve(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_outliers, int n_iters) {
+  VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || pairs), "bad pairs");
+  VO_REQUIRE(n_iters >= 0, "negative n_iters");
+  vo_ctx* c = s->ctx;
+  if (int r = set_device(c)) return r;
+  const uint64_t h = sample_hash(pairs, n_pairs);
+  const bool same = s->packed_valid && !s->key_dev && s->key_ptr == pairs && s->key_n == n_pairs && s->key_hash == h;
+  if (!same) {
+    if (int r = upload(c, s->pairs_own, pairs, sizeof(int32_t) * 2 * (size_t)n_pairs)) return r;
+    VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    s->packed_valid = false;
+    s->key_ptr = pairs; s->key_n = n_pairs; s->key_hash = h; s->key_dev = false;
+  }
+  if (int r = picp_prepare(s, s->pairs_own.as<int32_t>(), n_pairs, nullptr, keep_outliers)) return r;
+  return picp_enqueue(s, n_iters);
+}
+
+int vo_picp_one_round(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_outliers) {
+  return vo_picp_solve(s, pairs, n_pairs, keep_outliers, 1);
+}
+
+static int picp_read_state(vo_picp* s, PicpState* h) {
+  VO_HIP_CHECK(hipMemcpyAsync(h, s->d_state, sizeof(PicpState), hipMemcpyDeviceToHost, s->ctx->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));
+  if (h->n_bad > 0)
+    return fail(VO_ERR_BAD_INDEX, "vo_picp: %d correspondence(s) index outside the point arrays", h->n_bad);
+  return VO_OK;
+}
+
+int vo_picp_get_pose(vo_picp* s, float T[16]) {
+  VO_REQUIRE(s && T, "null argument");
+  if (int r = set_device(s->ctx)) return r;
+  PicpState h;
+  const int r = picp_read_state(s, &h);
+  Pose P;
+  for (int i = 0; i < 9; ++i) P.R[i] = h.pose[0][i];
+  for (int i = 0; i < 3; ++i) P.t[i] = h.pose[0][9 + i];
+  pose_to_T16(P, T);
+  return r;
+}
+
+__global__ void pose12_to_T16_kernel(const float* p, float* T) {
+  const int k = threadIdx.x;
+  if (k < 16) {
+    const int r = k & 3, c = k >> 2;
+    float v;
+    if (r == 3) v = (c == 3) ? 1.f : 0.f;
+    else if (c == 3) v = p[9 + r];
+    else v = p[r + 3 * c];
+    T[k] = v;
+  }
+}
+
+int vo_picp_get_pose_dev(vo_picp* s, float* d_T16) {
+  VO_REQUIRE(s && d_T16, "null argument");
+  if (int r = set_device(s->ctx)) return r;
+  hipLaunchKernelGGL(pose12_to_T16_kernel, dim3(1), dim3(64), 0, s->ctx->stream, s->d_state->pose[0], d_T16);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
+int vo_picp_get_stats(vo_picp* s, float* chi_in, float* chi_out, int* n_in) {
+  VO_REQUIRE(s, "null argument");
+  if (int r = set_device(s->ctx)) return r;
+  PicpState h;
+  const int r = picp_read_state(s, &h);
+  if (chi_in) *chi_in = h.chi_in;
+  if (chi_out) *chi_out = h.chi_out;
+  if (n_in) *n_in = h.n_in;
+  return r;
+}
+
+int vo_picp_get_system(vo_picp* s, float H[36], float b[6]) {
+  VO_REQUIRE(s, "null argument");
+  if (int r = set_device(s->ctx)) return r;
+  PicpState h;
+  const int r = picp_read_state(s, &h);
+  if (H) memcpy(H, h.H, sizeof(h.H));
+  if (b) memcpy(b, h.b, sizeof(h.b));
+  return r;
+}
+
+int vo_picp_solve_batch_dev(vo_ctx* c, int n_problems, int rows, int cols, int z_near, int z_far,
+                            const float K[9], float thr, int keep_outliers, const float* d_world,
+                            size_t world_stride, const float* d_meas, size_t meas_stride,
+                            const int32_t* d_pairs, size_t pairs_stride, const int* d_n_pairs,
+                            const float* d_T0, int n_iters, float* d_T_out, float* d_stats_out) {
+  VO_REQUIRE(c && K, "null argument");
+  VO_REQUIRE(n_problems >= 0 && n_iters >= 0, "negative count");
+  if (n_problems == 0) return VO_OK;
+  VO_REQUIRE(d_world && d_meas && d_pairs && d_n_pairs && d_T_out, "null device array");
+  VO_REQUIRE(world_stride > 0 && meas_stride > 0 && pairs_stride > 0, "zero stride");
+  VO_REQUIRE(world_stride < 0x7fffffff && meas_stride < 0x7fffffff && pairs_stride < 0x7fffffff, "stride too large");
+  if (int r = set_device(c)) return r;
+  BatchArgs a;
+  a.cam = make_cam(rows, cols, z_near, z_far, K);
+  a.thr = thr; a.damping = 1.f; a.keep_outliers = keep_outliers ? 1 : 0;
+  a.n_iters = n_iters; a.n_problems = n_problems;
+  a.world = d_world; a.world_stride = world_stride;
+  a.meas = d_meas; a.meas_stride = meas_stride;
+  a.pairs = d_pairs; a.pairs_stride = pairs_stride;
+  a.n_pairs = d_n_pairs; a.T0 = d_T0; a.T_out = d_T_out; a.stats_out = d_stats_out;
+  a.cap = (pairs_stride + 3) & ~(size_t)3;
+  a.n_world = (int)world_stride; a.n_meas = (int)meas_stride;
+  VO_HIP_CHECK(c->batch_pack.ensure(sizeof(float) * 5 * a.cap * (size_t)n_problems, c->stream));
+  a.packed = c->batch_pack.as<float>();
+  VO_HIP_CHECK(launch_picp_batch(c->stream, a));
+  return VO_OK;
+}
+
+// ---- matcher ------------------------------------------------------------------------------
+int vo_match_appearances_dev(vo_ctx* c, const float* d_a1, int n1, const float* d_a2, int n2,
+                             float radius, int32_t* d_out_pairs, int* d_n_out) {
+  VO_REQUIRE(c && d_n_out, "null argument");
+  VO_REQUIRE(n1 >= 0 && n2 >= 0, "negative count");
+  VO_REQUIRE((n1 == 0 || d_a1) && (n2 == 0 || d_a2), "null appearance array");
+  const int nq = n1 < n2 ? n1 : n2;
+  VO_REQUIRE(nq == 0 || d_out_pairs, "null output");
+  if (int r = set_device(c)) return r;
+  if (int r = ensure_scratch(c, nq)) return r;
+  VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)(nq ? nq : 1), c->stream));
+  VO_HIP_CHECK(launch_match(c->stream, d_a1, n1, d_a2, n2, radius, d_out_pairs, d_n_out,
+                            c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu));
+  return VO_OK;
+}
+
+int vo_match_appearances(vo_ctx* c, const float* a1, int n1, const float* a2, int n2, float radius,
+                         int32_t* out_pairs, int* n_out) {
+  VO_REQUIRE(c && n_out, "null argument");
+  VO_REQUIRE(n1 >= 0 && n2 >= 0, "negative count");
+  VO_REQUIRE((n1 == 0 || a1) && (n2 == 0 || a2), "null appearance array");
+  if (int r = set_device(c)) return r;
+  const int nq = n1 < n2 ? n1 : n2;
+  if (int r = upload(c, c->in[0], a1, sizeof(float) * 10 * (size_t)n1)) return r;
+  if (int r = upload(c, c->in[1], a2, sizeof(float) * 10 * (size_t)n2)) return r;
+  VO_HIP_CHECK(c->out[0].ensure(sizeof(int32_t) * 2 * (size_t)(nq ? nq : 1), c->stream));
+  if (int r = ensure_counts(c)) return r;
+  if (int r = vo_match_appearances_dev(c, c->in[0].as<float>(), n1, c->in[1].as<float>(), n2, radius,
+                                       c->out[0].as<int32_t>(), c->counts.as<int>()))
+    return r;
+  int h = 0;
+  VO_HIP_CHECK(hipMemcpyAsync(&h, c->counts.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (h > 0) VO_HIP_CHECK(hipMemcpy(out_pairs, c->out[0].p, sizeof(int32_t) * 2 * (size_t)h, hipMemcpyDeviceToHost));
+  *n_out = h;
+  return VO_OK;
+}
+
+// ---- join ---------------------------------------------------------------------------------
+int vo_join_correspondences_dev(vo_ctx* c, const int32_t* d_img, int n_img, const int* d_n_img,
+                                const int32_t* d_world, int n_world, const int* d_n_world, int n_ref,
+                                int32_t* d_out, int* d_n_out) {
+  VO_REQUIRE(c && d_n_out, "null argument");
+  VO_REQUIRE(n_img >= 0 && n_world >= 0 && n_ref >= 0, "negative count");
+  VO_REQUIRE((n_img == 0 || (d_img && d_out)) && (n_world == 0 || d_world), "null pair array");
+  if (int r = set_device(c)) return r;
+  if (int r = ensure_scratch(c, n_img)) return r;
+  VO_HIP_CHECK(c->table.ensure(sizeof(int) * (size_t)(n_ref ? n_ref : 1), c->stream));
+  VO_HIP_CHECK(launch_join(c->stream, d_img, n_img, d_n_img, d_world, n_world, d_n_world, n_ref, d_out,
+                           d_n_out, c->table.as<int>(), c->scratch.as<int>()));
+  return VO_OK;
+}
+
+int vo_join_correspondences(vo_ctx* c, const int32_t* img, int n_img, const int32_t* world, int n_world,
+                            int32_t* out, int* n_out) {
+  VO_REQUIRE(c && n_out, "null argument");
+  VO_REQUIRE(n_img >= 0 && n_world >= 0, "negative count");
+  VO_REQUIRE((n_img == 0 || (img && out)) && (n_world == 0 || world), "null pair array");
+  if (int r = set_device(c)) return r;
+  // the reference compares arbitrary ints; negative reference indices never match
+  // anything meaningful, they are treated as "no partner".
+  int n_ref = 0;
+  for (int j = 0; j < n_world; ++j) if (world[2 * j] >= n_ref) n_ref = world[2 * j] + 1;
+  if (int r = upload(c, c->in[0], img, sizeof(int32_t) * 2 * (size_t)n_img)) return r;
+  if (int r = upload(c, c->in[1], world, sizeof(int32_t) * 2 * (size_t)n_world)) return r;
+  VO_HIP_CHECK(c->out[0].ensure(sizeof(int32_t) * 2 * (size_t)(n_img ? n_img : 1), c->stream));
+  if (int r = ensure_counts(c)) return r;
+  if (int r = vo_join_correspondences_dev(c, c->in[0].as<int32_t>(), n_img, nullptr, c->in[1].as<int32_t>(),
+                                          n_world, nullptr, n_ref, c->out[0].as<int32_t>(), c->counts.as<int>()))
+    return r;
+  int h = 0;
+  VO_HIP_CHECK(hipMemcpyAsync(&h, c->counts.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (h > 0) VO_HIP_CHECK(hipMemcpy(out, c->out[0].p, sizeof(int32_t) * 2 * (size_t)h, hipMemcpyDeviceToHost));
+  *n_out = h;
+  return VO_OK;
+}
+
+// ---- transform ------------------------------------------------------------------------------
+int vo_transform_points_dev(vo_ctx* c, const float T[16], const float* d_in, int n, const int* d_n,
+                            float* d_out) {
+  VO_REQUIRE(c && T, "null argument");
+  VO_REQUIRE(n >= 0 && (n == 0 || (d_in && d_out)), "bad point arrays");
+  if (int r = set_device(c)) return r;
+  VO_HIP_CHECK(launch_transform_points(c->stream, pose_from_T16(T), d_in, n, d_n, d_out));
+  return VO_OK;
+}
+
+int vo_transform_points(vo_ctx* c, const float T[16], const float* in, int n, float* out) {
+  VO_REQUIRE(c && T, "null argument");
+  VO_REQUIRE(n >= 0 && (n == 0 || (in && out)), "bad point arrays");
+  if (n == 0) return VO_OK;
+  if (int r = set_device(c)) return r;
+  if (int r = upload(c, c->in[0], in, sizeof(float) * 3 * (size_t)n)) return r;
+  VO_HIP_CHECK(c->out[0].ensure(sizeof(float) * 3 * (size_t)n, c->stream));
+  if (int r = vo_transform_points_dev(c, T, c->in[0].as<float>(), n, nullptr, c->out[0].as<float>())) return r;
+  VO_HIP_CHECK(hipMemcpyAsync(out, c->out[0].p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return VO_OK;
+}
+
+// ---- triangulation ----------------------------------------------------------------------------
+int vo_triangulate_dev(vo_ctx* c, const float K[9], const float X[16], const float* d_X16,
+                       const int32_t* d_pairs, int n, const int* d_n, const float* d_p1, int n1,
+                       const float* d_p2, int n2, const float* d_app2, float* d_out_xyz,
+                       int32_t* d_out_pairs, float* d_out_app, int* d_n_out) {
+  VO_REQUIRE(c && K && d_n_out, "null argument");
+  VO_REQUIRE(X || d_X16, "no pose given");
+  VO_REQUIRE(n >= 0 && n1 >= 0 && n2 >= 0, "negative count");
+  VO_REQUIRE(n == 0 || (d_pairs && d_p1 && d_p2 && d_out_xyz), "null device array");
+  if (int r = set_device(c)) return r;
+  if (int r = ensure_scratch(c, n)) return r;
+  Pose Xp;
+  if (X) Xp = pose_from_T16(X);
+  VO_HIP_CHECK(launch_triangulate(c->stream, K, X ? &Xp : nullptr, d_X16, d_pairs, n, d_n, d_p1, n1, d_p2,
+                                  n2, d_app2, d_out_xyz, d_out_pairs, d_out_app, d_n_out,
+                                  c->scratch.as<int>()));
+  return VO_OK;
+}
+
+int vo_triangulate(vo_ctx* c, const float K[9], const float X[16], const int32_t* pairs, int n,
+                   const float* p1, int n1, const float* p2, int n2, const float* app2, float* out_xyz,
+                   int32_t* out_pairs, float* out_app, int* n_out) {
+  VO_REQUIRE(c && K && X && n_out, "null argument");
+  VO_REQUIRE(n >= 0 && n1 >= 0 && n2 >= 0, "negative count");
+  VO_REQUIRE(n == 0 || (pairs && p1 && p2 && out_xyz), "null array");
+  if (int r = set_device(c)) return r;
+  const bool want_app = app2 && out_app;
+  if (int r = upload(c, c->in[0], pairs, sizeof(int32_t) * 2 * (size_t)n)) return r;
+  if (int r = upload(c, c->in[1], p1, sizeof(float) * 2 * (size_t)n1)) return r;
+  if (int r = upload(c, c->in[2], p2, sizeof(float) * 2 * (size_t)n2)) return r;
+  if (want_app) if (int r = upload(c, c->in[3], app2, sizeof(float) * 10 * (size_t)n2)) return r;
+  const size_t nn = (size_t)(n ? n : 1);
+  VO_HIP_CHECK(c->out[0].ensure(sizeof(float) * 3 * nn, c->stream));
+  VO_HIP_CHECK(c->out[1].ensure(sizeof(int32_t) * 2 * nn, c->stream));
+  if (want_app) VO_HIP_CHECK(c->out[2].ensure(sizeof(float) * 10 * nn, c->stream));
+  if (int r = ensure_counts(c)) return r;
+  if (int r = vo_triangulate_dev(c, K, X, nullptr, c->in[0].as<int32_t>(), n, nullptr, c->in[1].as<float>(),
+                                 n1, c->in[2].as<float>(), n2, want_app ? c->in[3].as<float>() : nullptr,
+                                 c->out[0].as<float>(), out_pairs ? c->out[1].as<int32_t>() : nullptr,
+                                 want_app ? c->out[2].as<float>() : nullptr, c->counts.as<int>()))
+    return r;
+  int h = 0;
+  VO_HIP_CHECK(hipMemcpyAsync(&h, c->counts.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (h > 0) {
+    VO_HIP_CHECK(hipMemcpy(out_xyz, c->out[0].p, sizeof(float) * 3 * (size_t)h, hipMemcpyDeviceToHost));
+    if (out_pairs) VO_HIP_CHECK(hipMemcpy(out_pairs, c->out[1].p, sizeof(int32_t) * 2 * (size_t)h, hipMemcpyDeviceToHost));
+    if (want_app) VO_HIP_CHECK(hipMemcpy(out_app, c->out[2].p, sizeof(float) * 10 * (size_t)h, hipMemcpyDeviceToHost));
+  }
+  *n_out = h;
+  return VO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,417 @@
+// geom.hip -- single-pass, HBM-bound kernels around the solver:
+//   Camera::projectPoints           (camera.cpp:16-37)
+//   Isometry3f * point set          (PointCloud.h:77-82)
+//   triangulate_points v1/v2/v3     (utils.cpp:51-134)
+//   extract_correspondences_world   (vo_complete.cpp:52-66)
+//
+// Variable-length outputs keep the reference's order (stable compaction):
+//   count kernel   : every 256-item workgroup counts its survivors
+//   scan kernel    : one workgroup turns the counts into exclusive offsets and
+//                    the total (left in device memory: no host round trip)
+//   scatter kernel : re-evaluates the (cheap, deterministic) predicate, ranks
+//                    survivors inside the workgroup by ballot/popcount and
+//                    writes them at offset + rank.
+// Nothing is staged in a temporary array: re-evaluating ~60 flops is cheaper
+// than writing and re-reading 12-44 B per item.
+#include <limits.h>
+
+#include "vo_internal.h"
+
+namespace vo {
+
+constexpr int CB = 256;  // items per compaction workgroup
+
+size_t compaction_scratch_ints(int n) { return (size_t)((n + CB - 1) / CB) + 16; }
+
+// exclusive rank of `flag` inside a 256-thread workgroup; total = survivors
+__device__ __forceinline__ int block_rank(bool flag, int* s_wave, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(flag);
+  const int before = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wave[wave] = __popcll(m);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < CB / 64; ++w) {
+    const int c = s_wave[w];
+    if (w < wave) off += c;
+    tot += c;
+  }
+  total = tot;
+  return off + before;
+}
+
+__device__ __forceinline__ int clamp_count(const int* d_n, int n_max) {
+  int n = n_max;
+  if (d_n) { const int m = *d_n; n = m < n_max ? (m < 0 ? 0 : m) : n_max; }
+  return n;
+}
+
+// One workgroup: offsets[b] = sum(counts[0..b-1]) in place, *total = sum.
+__global__ __launch_bounds__(1024) void scan_counts_kernel(int* counts, int nb, int* total,
+                                                           int* total2) {
+  __shared__ int s_w[16];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + tid;
+    const int v = i < nb ? counts[i] : 0;
+    int incl = v;   // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int c = s_w[w];
+      if (w < wave) woff += c;
+      tot += c;
+    }
+    const int carry = s_carry;
+    if (i < nb) counts[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (tid == 0) s_carry = carry + tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *total = s_carry;
+    if (total2) *total2 = s_carry;
+  }
+}
+
+static hipError_t launch_scan(hipStream_t st, int* counts, int nb, int* total, int* total2 = nullptr) {
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, counts, nb, total, total2);
+  return hipGetLastError();
+}
+
+// ---- projectPoints ------------------------------------------------------------
+struct ProjArgs {
+  CamK cam;
+  Pose T;
+  const float* world;
+  int n;
+  int keep_indices;
+  float* out_uv;
+  int* counts;   // per workgroup
+};
+
+__device__ __forceinline__ bool proj_eval(const ProjArgs& a, int i, float& u, float& v) {
+  float pc[3], ph[3], inv;
+  const float* p = a.world + 3 * (size_t)i;
+  return project_point(a.cam, a.T, p[0], p[1], p[2], u, v, pc, ph, inv);
+}
+
+// keep_indices: writes (u,v) or (-1,-1) in place and counts; else counts only
+__global__ __launch_bounds__(CB) void project_count_kernel(ProjArgs a) {
+  __shared__ int s_wave[CB / 64];
+  const int i = blockIdx.x * CB + threadIdx.x;
+  bool ok = false;
+  float u = -1.f, v = -1.f;
+  if (i < a.n) {
+    ok = proj_eval(a, i, u, v);
+    if (a.keep_indices) {
+      float2 o = ok ? make_float2(u, v) : make_float2(-1.f, -1.f);   // camera.cpp:30
+      *reinterpret_cast<float2*>(a.out_uv + 2 * (size_t)i) = o;
+    }
+  }
+  int total;
+  block_rank(ok, s_wave, total);
+  if (threadIdx.x == 0) a.counts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(CB) void project_scatter_kernel(ProjArgs a) {
+  __shared__ int s_wave[CB / 64];
+  const int i = blockIdx.x * CB + threadIdx.x;
+  bool ok = false;
+  float u = 0.f, v = 0.f;
+  if (i < a.n) ok = proj_eval(a, i, u, v);
+  int total;
+  const int r = block_rank(ok, s_wave, total);
+  if (ok) {
+    const size_t dst = (size_t)a.counts[blockIdx.x] + r;
+    *reinterpret_cast<float2*>(a.out_uv + 2 * dst) = make_float2(u, v);
+  }
+}
+
+__global__ void project_finish_kernel(int* d_counts, int n, int keep_indices) {
+  // d_counts[1] = n_inside (written by the scan); d_counts[0] = n_out
+  d_counts[0] = keep_indices ? n : d_counts[1];
+}
+
+hipError_t launch_project_points(hipStream_t st, const CamK& cam, const Pose& T, const float* d_world,
+                                 int n, int keep_indices, float* d_out_uv, int* d_counts,
+                                 int* d_scratch) {
+  const int nb = (n + CB - 1) / CB;
+  ProjArgs a{cam, T, d_world, n, keep_indices, d_out_uv, d_scratch};
+  if (nb > 0) hipLaunchKernelGGL(project_count_kernel, dim3(nb), dim3(CB), 0, st, a);
+  hipError_t e = launch_scan(st, d_scratch, nb, d_counts + 1);
+  if (e != hipSuccess) return e;
+  if (!keep_indices && nb > 0) hipLaunchKernelGGL(project_scatter_kernel, dim3(nb), dim3(CB), 0, st, a);
+  hipLaunchKernelGGL(project_finish_kernel, dim3(1), dim3(1), 0, st, d_counts, n, keep_indices);
+  return hipGetLastError();
+}
+
+// ---- rigid transform ------------------------------------------------------------
+__global__ __launch_bounds__(256) void transform_kernel(Pose T, const float* __restrict__ in, int n_max,
+                                                        const int* __restrict__ d_n,
+                                                        float* __restrict__ out) {
+  const int n = clamp_count(d_n, n_max);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float* p = in + 3 * (size_t)i;
+    float ox, oy, oz;
+    pose_apply(T, p[0], p[1], p[2], ox, oy, oz);
+    float* o = out + 3 * (size_t)i;
+    o[0] = ox; o[1] = oy; o[2] = oz;
+  }
+}
+
+hipError_t launch_transform_points(hipStream_t st, const Pose& T, const float* d_in, int n,
+                                   const int* d_n, float* d_out) {
+  if (n <= 0) return hipSuccess;
+  int grid = (n + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(transform_kernel, dim3(grid), dim3(256), 0, st, T, d_in, n, d_n, d_out);
+  return hipGetLastError();
+}
+
+// ---- triangulation ----------------------------------------------------------------
+struct TriArgs {
+  float K[9];
+  Pose X;               // used when d_X16 == nullptr
+  const float* d_X16;   // pose in device memory (e.g. the solver's result)
+  const int32_t* pairs;
+  int n_max;
+  const int* d_n;
+  const float* p1; int n1;
+  const float* p2; int n2;
+  const float* app2;
+  float* out_xyz;
+  int32_t* out_pairs;
+  float* out_app;
+  int* counts;
+};
+
+__device__ __forceinline__ void tri_setup(const TriArgs& a, TriConst* s_c) {
+  if (threadIdx.x == 0) {
+    Pose X = a.X;
+    if (a.d_X16) {
+      float T16[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) T16[k] = a.d_X16[k];
+      X = pose_from_T16(T16);
+    }
+    *s_c = tri_constants(a.K, X);      // utils.cpp:79-82
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ bool tri_eval(const TriArgs& a, const TriConst& c, int k, int& i2,
+                                         float p[3]) {
+  const int i1 = a.pairs[2 * (size_t)k];
+  i2 = a.pairs[2 * (size_t)k + 1];
+  if (i1 < 0 || i1 >= a.n1 || i2 < 0 || i2 >= a.n2) return false;   // out of range: dropped
+  const float2 q1 = *reinterpret_cast<const float2*>(a.p1 + 2 * (size_t)i1);
+  const float2 q2 = *reinterpret_cast<const float2*>(a.p2 + 2 * (size_t)i2);
+  const float h1[3] = {q1.x, q1.y, 1.f}, h2[3] = {q2.x, q2.y, 1.f};
+  float d1[3], d2[3];
+  mat3_vec(c.iK, 3, h1, d1);     // utils.cpp:89-91
+  mat3_vec(c.iRiK, 3, h2, d2);   // utils.cpp:92-94
+  return triangulate_point(d1, d2, c.t, p);
+}
+
+__global__ __launch_bounds__(CB) void tri_count_kernel(TriArgs a) {
+  __shared__ TriConst s_c;
+  __shared__ int s_wave[CB / 64];
+  tri_setup(a, &s_c);
+  const int n = clamp_count(a.d_n, a.n_max);
+  const int k = blockIdx.x * CB + threadIdx.x;
+  bool ok = false;
+  if (k < n) { int i2; float p[3]; ok = tri_eval(a, s_c, k, i2, p); }
+  int total;
+  block_rank(ok, s_wave, total);
+  if (threadIdx.x == 0) a.counts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a) {
+  __shared__ TriConst s_c;
+  __shared__ int s_wave[CB / 64];
+  tri_setup(a, &s_c);
+  const int n = clamp_count(a.d_n, a.n_max);
+  const int k = blockIdx.x * CB + threadIdx.x;
+  bool ok = false;
+  int i2 = 0;
+  float p[3] = {0.f, 0.f, 0.f};
+  if (k < n) ok = tri_eval(a, s_c, k, i2, p);
+  int total;
+  const int r = block_rank(ok, s_wave, total);
+  if (ok) {
+    const size_t dst = (size_t)a.counts[blockIdx.x] + r;
+    a.out_xyz[3 * dst] = p[0]; a.out_xyz[3 * dst + 1] = p[1]; a.out_xyz[3 * dst + 2] = p[2];
+    if (a.out_pairs) { a.out_pairs[2 * dst] = i2; a.out_pairs[2 * dst + 1] = (int)dst; }   // utils.cpp:97
+    if (a.out_app && a.app2) {                                                               // utils.cpp:127
+      const float2* src = reinterpret_cast<const float2*>(a.app2 + 10 * (size_t)i2);
+      float2* o = reinterpret_cast<float2*>(a.out_app + 10 * dst);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) o[j] = src[j];
+    }
+  }
+}
+
+hipError_t launch_triangulate(hipStream_t st, const float K[9], const Pose* X_host,
+                              const float* d_X16, const int32_t* d_pairs, int n, const int* d_n,
+                              const float* d_p1, int n1, const float* d_p2, int n2,
+                              const float* d_app2, float* d_out_xyz, int32_t* d_out_pairs,
+                              float* d_out_app, int* d_n_out, int* d_scratch) {
+  TriArgs a;
+  for (int k = 0; k < 9; ++k) a.K[k] = K[k];
+  if (X_host) a.X = *X_host;
+  else { for (int k = 0; k < 9; ++k) a.X.R[k] = (k % 4 == 0) ? 1.f : 0.f; a.X.t[0] = a.X.t[1] = a.X.t[2] = 0.f; }
+  a.d_X16 = d_X16;
+  a.pairs = d_pairs; a.n_max = n; a.d_n = d_n;
+  a.p1 = d_p1; a.n1 = n1; a.p2 = d_p2; a.n2 = n2; a.app2 = d_app2;
+  a.out_xyz = d_out_xyz; a.out_pairs = d_out_pairs; a.out_app = d_out_app;
+  a.counts = d_scratch;
+  const int nb = (n + CB - 1) / CB;
+  if (nb > 0) hipLaunchKernelGGL(tri_count_kernel, dim3(nb), dim3(CB), 0, st, a);
+  hipError_t e = launch_scan(st, d_scratch, nb, d_n_out);
+  if (e != hipSuccess) return e;
+  if (nb > 0) hipLaunchKernelGGL(tri_scatter_kernel, dim3(nb), dim3(CB), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---- join ---------------------------------------------------------------------------
+// table[ref] = position of the FIRST world pair whose .first == ref
+// (vo_complete.cpp:57-62 scans from the start and breaks on the first hit).
+constexpr int JOIN_EMPTY = 0x7f7f7f7f;   // byte pattern of the memset
+
+__global__ __launch_bounds__(256) void join_build_kernel(const int32_t* __restrict__ world, int n_max,
+                                                         const int* __restrict__ d_n, int n_ref,
+                                                         int* table) {
+  const int n = clamp_count(d_n, n_max);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int ref = world[2 * (size_t)j];
+    if (ref >= 0 && ref < n_ref) atomicMin(&table[ref], j);
+  }
+}
+
+struct JoinArgs {
+  const int32_t* img; int n_max; const int* d_n;
+  const int32_t* world;
+  int n_ref;
+  const int* table;
+  int32_t* out;
+  int* counts;
+};
+
+__device__ __forceinline__ bool join_eval(const JoinArgs& a, int i, int& cur, int& w) {
+  const int ref = a.img[2 * (size_t)i];
+  cur = a.img[2 * (size_t)i + 1];
+  if (ref < 0 || ref >= a.n_ref) return false;
+  const int j = a.table[ref];
+  if (j == JOIN_EMPTY) return false;
+  w = a.world[2 * (size_t)j + 1];
+  return true;
+}
+
+__global__ __launch_bounds__(CB) void join_count_kernel(JoinArgs a) {
+  __shared__ int s_wave[CB / 64];
+  const int n = clamp_count(a.d_n, a.n_max);
+  const int i = blockIdx.x * CB + threadIdx.x;
+  bool ok = false;
+  if (i < n) { int c, w; ok = join_eval(a, i, c, w); }
+  int total;
+  block_rank(ok, s_wave, total);
+  if (threadIdx.x == 0) a.counts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(CB) void join_scatter_kernel(JoinArgs a) {
+  __shared__ int s_wave[CB / 64];
+  const int n = clamp_count(a.d_n, a.n_max);
+  const int i = blockIdx.x * CB + threadIdx.x;
+  bool ok = false;
+  int c = 0, w = 0;
+  if (i < n) ok = join_eval(a, i, c, w);
+  int total;
+  const int r = block_rank(ok, s_wave, total);
+  if (ok) {
+    const size_t dst = (size_t)a.counts[blockIdx.x] + r;
+    a.out[2 * dst] = c;        // vo_complete.cpp:59
+    a.out[2 * dst + 1] = w;
+  }
+}
+
+hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const int* d_n_img,
+                       const int32_t* d_world, int n_world, const int* d_n_world, int n_ref,
+                       int32_t* d_out, int* d_n_out, int* d_table, int* d_scratch) {
+  hipError_t e = hipSuccess;
+  if (n_ref > 0) {
+    e = hipMemsetAsync(d_table, 0x7f, sizeof(int) * (size_t)n_ref, st);
+    if (e != hipSuccess) return e;
+  }
+  if (n_world > 0 && n_ref > 0) {
+    int grid = (n_world + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(join_build_kernel, dim3(grid), dim3(256), 0, st, d_world, n_world, d_n_world,
+                       n_ref, d_table);
+  }
+  JoinArgs a{d_img, n_img, d_n_img, d_world, n_ref, d_table, d_out, d_scratch};
+  const int nb = (n_img + CB - 1) / CB;
+  if (nb > 0) hipLaunchKernelGGL(join_count_kernel, dim3(nb), dim3(CB), 0, st, a);
+  e = launch_scan(st, d_scratch, nb, d_n_out);
+  if (e != hipSuccess) return e;
+  if (nb > 0) hipLaunchKernelGGL(join_scatter_kernel, dim3(nb), dim3(CB), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---- matcher output compaction (used by match.hip) -------------------------------
+// best[q] = (bits(d2) << 32) | tree index, or idx 0xffffffff when no hit.
+struct MatchOutArgs {
+  const unsigned long long* best;
+  int nq;
+  int tree_is_1;    // pairs are (a1 index, a2 index): vo_complete.cpp:40-43
+  int32_t* out;
+  int* counts;
+};
+
+__global__ __launch_bounds__(CB) void match_count_kernel(MatchOutArgs a) {
+  __shared__ int s_wave[CB / 64];
+  const int q = blockIdx.x * CB + threadIdx.x;
+  const bool ok = q < a.nq && (unsigned)(a.best[q] & 0xffffffffull) != 0xffffffffu;
+  int total;
+  block_rank(ok, s_wave, total);
+  if (threadIdx.x == 0) a.counts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(CB) void match_scatter_kernel(MatchOutArgs a) {
+  __shared__ int s_wave[CB / 64];
+  const int q = blockIdx.x * CB + threadIdx.x;
+  unsigned idx = 0xffffffffu;
+  if (q < a.nq) idx = (unsigned)(a.best[q] & 0xffffffffull);
+  const bool ok = idx != 0xffffffffu;
+  int total;
+  const int r = block_rank(ok, s_wave, total);
+  if (ok) {
+    const size_t dst = (size_t)a.counts[blockIdx.x] + r;
+    a.out[2 * dst] = a.tree_is_1 ? (int)idx : q;
+    a.out[2 * dst + 1] = a.tree_is_1 ? q : (int)idx;
+  }
+}
+
+hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best, int nq, int tree_is_1,
+                                int32_t* d_out, int* d_n_out, int* d_scratch) {
+  MatchOutArgs a{d_best, nq, tree_is_1, d_out, d_scratch};
+  const int nb = (nq + CB - 1) / CB;
+  if (nb > 0) hipLaunchKernelGGL(match_count_kernel, dim3(nb), dim3(CB), 0, st, a);
+  hipError_t e = launch_scan(st, d_scratch, nb, d_n_out);
+  if (e != hipSuccess) return e;
+  if (nb > 0) hipLaunchKernelGGL(match_scatter_kernel, dim3(nb), dim3(CB), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace vo

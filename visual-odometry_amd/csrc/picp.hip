@@ -1,0 +1,363 @@
+// picp.hip -- projective-ICP Gauss-Newton kernels for gfx950 (MI355X).
+//
+// Replaces the scalar host loop PICPSolver::linearize / oneRound
+// (picp_solver.cpp:55-112) and errorAndJacobian (:25-53):
+//
+//   picp_pack_kernel   once per solve: gathers world[pair.second] and
+//                      meas[pair.first] into five SoA arrays (20 B per
+//                      correspondence) so that every iteration streams
+//                      coalesced data and never touches the index pairs again.
+//   picp_round_kernel  one launch per Gauss-Newton iteration.  Every workgroup
+//                      first re-derives the pose of this iteration from the
+//                      previous launch's workgroup partials (fixed-order
+//                      reduction + 6x6 pivoted LDLT + pose update, redundantly
+//                      and identically in every workgroup), then linearises its
+//                      slice and writes one 30-float partial.  One kernel
+//                      boundary per iteration, no atomics, no in-launch
+//                      inter-workgroup hand-off, bitwise reproducible.
+//   picp_batch_*       many independent problems, one 1024-thread workgroup
+//                      each, all iterations inside a single launch.
+//
+// Reduction: per-thread registers -> DPP row reduction (16 lanes) -> LDS across
+// rows and waves -> workgroup partial.  No MFMA: the normal equations are a
+// tall-skinny accumulate (21+6+3 sums per correspondence), not a contraction.
+#include "vo_internal.h"
+
+namespace vo {
+
+// ---- wave-level helpers -----------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+// sum over the 16 lanes of a DPP row; every lane of the row gets the result
+__device__ __forceinline__ float row16_allsum(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
+  return v;
+}
+
+// Reduce the NACC per-thread accumulators over a workgroup of NWAVES waves.
+// On return threads 0..31 hold in `out` the workgroup sum of slot threadIdx.x
+// (slots >= NACC are 0).  s_red: NWAVES*4*32 floats.  Fixed summation order.
+template <int NWAVES>
+__device__ __forceinline__ float block_reduce_acc(float acc[NACC], float* s_red) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = row16_allsum(acc[k]);
+  if ((lane & 15) == 15) {
+    float* dst = s_red + (wave * 4 + (lane >> 4)) * 32;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) dst[k] = acc[k];
+  }
+  __syncthreads();
+  float out = 0.f;
+  if (tid < NACC) {
+#pragma unroll 8
+    for (int j = 0; j < NWAVES * 4; ++j) out += s_red[j * 32 + tid];
+  }
+  return out;
+}
+
+__device__ __forceinline__ Pose load_pose12(const float* p) {
+  Pose P;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) P.R[i] = p[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) P.t[i] = p[9 + i];
+  return P;
+}
+
+// The pose is the same in every lane: move it to scalar registers.
+__device__ __forceinline__ Pose uniform_pose(const Pose& P) {
+  Pose U;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) U.R[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(P.R[i])));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) U.t[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(P.t[i])));
+  return U;
+}
+
+__device__ __forceinline__ void store_pose12(float* p, const Pose& P) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) p[i] = P.R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p[9 + i] = P.t[i];
+}
+
+// ---- pack -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void picp_pack_kernel(const int32_t* __restrict__ pairs,
+                                                        const int* __restrict__ d_n, int n_max,
+                                                        const float* __restrict__ world, int n_world,
+                                                        const float* __restrict__ meas, int n_meas,
+                                                        PackedCorr pk, PicpParams* P, PicpState* S) {
+  int n = n_max;
+  if (d_n) { const int m = *d_n; n = m < n_max ? (m < 0 ? 0 : m) : n_max; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) P->n_corr = n;
+  const float qnan = __int_as_float(0x7fc00000);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int m = pairs[2 * i];       // .first  -> measurement (picp_solver.cpp:66)
+    const int w = pairs[2 * i + 1];   // .second -> world point (picp_solver.cpp:67)
+    float x = qnan, y = 0.f, z = 0.f, u = 0.f, v = 0.f;
+    if (m >= 0 && m < n_meas && w >= 0 && w < n_world) {
+      x = world[3 * (size_t)w]; y = world[3 * (size_t)w + 1]; z = world[3 * (size_t)w + 2];
+      u = meas[2 * (size_t)m]; v = meas[2 * (size_t)m + 1];
+    } else {
+      atomicAdd(&S->n_bad, 1);
+    }
+    pk.arr(0)[i] = x; pk.arr(1)[i] = y; pk.arr(2)[i] = z; pk.arr(3)[i] = u; pk.arr(4)[i] = v;
+  }
+}
+
+// ---- one Gauss-Newton round ---------------------------------------------------
+// PRE:    first derive this round's pose from the partials of launch it-1.
+// FINISH: only derive the pose (single workgroup), publish the statistics.
+template <bool PRE, bool FINISH>
+__global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams* __restrict__ P,
+                                                                PicpState* S, PackedCorr pk,
+                                                                float* partials, int it, int nb) {
+  __shared__ float s_red[16 * 32];
+  __shared__ float s_tot[32];
+  __shared__ float s_pose[12];
+  const int tid = threadIdx.x;
+  const int n = P->n_corr;
+
+  // issue the first correspondence's loads before the (latency-bound) solve
+  int i = blockIdx.x * PICP_BLOCK + tid;
+  bool have = !FINISH && i < n;
+  float x = 0.f, y = 0.f, z = 0.f, u = 0.f, v = 0.f;
+  if (have) { x = pk.arr(0)[i]; y = pk.arr(1)[i]; z = pk.arr(2)[i]; u = pk.arr(3)[i]; v = pk.arr(4)[i]; }
+
+  Pose T;
+  if (PRE) {
+    const float* prev = partials + (size_t)((it - 1) & 1) * nb * PICP_PSTRIDE;
+    const int slot = tid & 31, grp = tid >> 5;   // 8 groups of 32 slots
+    float sf = 0.f;
+    int si = 0;
+    for (int b = grp; b < nb; b += PICP_BLOCK / 32) {
+      const float f = prev[b * PICP_PSTRIDE + slot];
+      sf += f;
+      si += __float_as_int(f);
+    }
+    s_red[grp * 32 + slot] = (slot == 29) ? __int_as_float(si) : sf;
+    __syncthreads();
+    if (tid < 32) {
+      float tf = 0.f;
+      int ti = 0;
+#pragma unroll
+      for (int g = 0; g < PICP_BLOCK / 32; ++g) {
+        const float f = s_red[g * 32 + tid];
+        tf += f;
+        ti += __float_as_int(f);
+      }
+      s_tot[tid] = (tid == 29) ? __int_as_float(ti) : tf;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float acc[NACC];
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) acc[k] = s_tot[k];
+      const Pose Told = load_pose12(S->pose[(it - 1) & 1]);
+      float H[36], b[6];
+      const Pose Tn = picp_update(acc, P->damping, Told, FINISH ? H : nullptr, FINISH ? b : nullptr);
+      store_pose12(s_pose, Tn);
+      if (blockIdx.x == 0) {
+        store_pose12(S->pose[FINISH ? 0 : (it & 1)], Tn);
+        if (FINISH) {
+#pragma unroll
+          for (int k = 0; k < 36; ++k) S->H[k] = H[k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) S->b[k] = b[k];
+          S->chi_in = acc[27];
+          S->chi_out = acc[28];
+          S->n_in = __float_as_int(s_tot[29]);
+        }
+      }
+    }
+    if (FINISH) return;
+    __syncthreads();
+    T = uniform_pose(load_pose12(s_pose));
+  } else {
+    T = uniform_pose(load_pose12(S->pose[0]));
+  }
+
+  const CamK cam = P->cam;
+  const float thr = P->thr;
+  const bool keep = P->keep_outliers != 0;
+  float acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+  const int stride = gridDim.x * PICP_BLOCK;
+  while (have) {
+    const float cx = x, cy = y, cz = z, cu = u, cv = v;
+    i += stride;
+    have = i < n;
+    if (have) { x = pk.arr(0)[i]; y = pk.arr(1)[i]; z = pk.arr(2)[i]; u = pk.arr(3)[i]; v = pk.arr(4)[i]; }
+    picp_accumulate(cam, T, thr, keep, cx, cy, cz, cu, cv, acc);
+  }
+  const float tot = block_reduce_acc<PICP_BLOCK / 64>(acc, s_red);
+  if (tid < PICP_PSTRIDE) {
+    float o = tot;
+    if (tid == 29) o = __int_as_float((int)(tot + 0.5f));
+    if (tid >= NACC) o = 0.f;
+    partials[((size_t)(it & 1) * nb + blockIdx.x) * PICP_PSTRIDE + tid] = o;
+  }
+}
+
+int picp_grid_for(int n_corr, int n_cu) {
+  int g = (n_corr + PICP_BLOCK - 1) / PICP_BLOCK;
+  if (g < 1) g = 1;
+  // beyond one workgroup per CU let each thread take several correspondences
+  // before adding workgroups: the per-iteration partial reduction reads
+  // grid*128 B in every workgroup.
+  const int cap = n_cu > 0 ? 4 * n_cu : 1024;
+  if (g > cap) g = cap;
+  if (g > PICP_MAX_BLOCKS) g = PICP_MAX_BLOCKS;
+  return g;
+}
+
+hipError_t launch_picp_pack(hipStream_t st, const int32_t* d_pairs, const int* d_n, int n_max,
+                            const float* d_world, int n_world, const float* d_meas, int n_meas,
+                            PackedCorr pk, PicpParams* d_params, PicpState* d_state) {
+  hipError_t e = hipMemsetAsync(&d_state->n_bad, 0, sizeof(int), st);
+  if (e != hipSuccess) return e;
+  int grid = (n_max + 255) / 256;
+  if (grid < 1) grid = 1;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(picp_pack_kernel, dim3(grid), dim3(256), 0, st, d_pairs, d_n, n_max, d_world,
+                     n_world, d_meas, n_meas, pk, d_params, d_state);
+  return hipGetLastError();
+}
+
+hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpState* d_state,
+                              PackedCorr pk, float* d_partials, int grid, int n_iters) {
+  if (n_iters <= 0) return hipSuccess;
+  hipLaunchKernelGGL((picp_round_kernel<false, false>), dim3(grid), dim3(PICP_BLOCK), 0, st,
+                     d_params, d_state, pk, d_partials, 0, grid);
+  for (int it = 1; it < n_iters; ++it)
+    hipLaunchKernelGGL((picp_round_kernel<true, false>), dim3(grid), dim3(PICP_BLOCK), 0, st,
+                       d_params, d_state, pk, d_partials, it, grid);
+  hipLaunchKernelGGL((picp_round_kernel<true, true>), dim3(1), dim3(PICP_BLOCK), 0, st, d_params,
+                     d_state, pk, d_partials, n_iters, grid);
+  return hipGetLastError();
+}
+
+// ---- batched solver -----------------------------------------------------------
+// The 6x6 solve runs on one lane once per iteration; keeping it out of line
+// stops its ~90 live registers from setting the whole kernel's VGPR budget.
+__device__ __attribute__((noinline)) void picp_update_outofline(const float* acc_lds, float damping,
+                                                                 const float* pose_in, float* pose_out) {
+  float r[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) r[k] = acc_lds[k];
+  const Pose T = load_pose12(pose_in);
+  const Pose Tn = picp_update(r, damping, T, nullptr, nullptr);
+  store_pose12(pose_out, Tn);
+}
+
+__global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
+  const int p = blockIdx.y;
+  int n = a.n_pairs[p];
+  if (n < 0) n = 0;
+  if ((size_t)n > a.cap) n = (int)a.cap;
+  const int32_t* pairs = a.pairs + 2 * (size_t)p * a.pairs_stride;
+  const float* world = a.world + 3 * (size_t)p * a.world_stride;
+  const float* meas = a.meas + 2 * (size_t)p * a.meas_stride;
+  float* dst = a.packed + (size_t)p * 5 * a.cap;
+  const float qnan = __int_as_float(0x7fc00000);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int m = pairs[2 * i], w = pairs[2 * i + 1];
+    float x = qnan, y = 0.f, z = 0.f, u = 0.f, v = 0.f;
+    if (m >= 0 && m < a.n_meas && w >= 0 && w < a.n_world) {
+      x = world[3 * (size_t)w]; y = world[3 * (size_t)w + 1]; z = world[3 * (size_t)w + 2];
+      u = meas[2 * (size_t)m]; v = meas[2 * (size_t)m + 1];
+    }
+    dst[i] = x; dst[a.cap + i] = y; dst[2 * a.cap + i] = z; dst[3 * a.cap + i] = u; dst[4 * a.cap + i] = v;
+  }
+}
+
+__global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs a) {
+  __shared__ float s_red[(PICP_BATCH_BLOCK / 64) * 4 * 32];
+  __shared__ float s_pose[12];
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x;
+  int n = a.n_pairs[p];
+  if (n < 0) n = 0;
+  if ((size_t)n > a.cap) n = (int)a.cap;
+  const float* X = a.packed + (size_t)p * 5 * a.cap;
+  const float* Y = X + a.cap;
+  const float* Z = Y + a.cap;
+  const float* U = Z + a.cap;
+  const float* V = U + a.cap;
+  Pose T;
+  if (a.T0) {
+    T = pose_from_T16(a.T0 + 16 * (size_t)p);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) T.R[k] = (k % 4 == 0) ? 1.f : 0.f;
+    T.t[0] = T.t[1] = T.t[2] = 0.f;
+  }
+  T = uniform_pose(T);
+  const CamK cam = a.cam;
+  const int n4 = n & ~3;
+  for (int it = 0; it < a.n_iters; ++it) {
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    const bool keep = a.keep_outliers != 0;
+    for (int i = tid * 4; i < n4; i += PICP_BATCH_BLOCK * 4) {
+      const float4 x = *reinterpret_cast<const float4*>(X + i);
+      const float4 y = *reinterpret_cast<const float4*>(Y + i);
+      const float4 z = *reinterpret_cast<const float4*>(Z + i);
+      const float4 u = *reinterpret_cast<const float4*>(U + i);
+      const float4 v = *reinterpret_cast<const float4*>(V + i);
+      // the four terms are kept apart (sched_barrier) so that their temporaries
+      // do not overlap: 1024-thread workgroups have 128 VGPRs per lane
+      picp_accumulate(cam, T, a.thr, keep, x.x, y.x, z.x, u.x, v.x, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      picp_accumulate(cam, T, a.thr, keep, x.y, y.y, z.y, u.y, v.y, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      picp_accumulate(cam, T, a.thr, keep, x.z, y.z, z.z, u.z, v.z, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      picp_accumulate(cam, T, a.thr, keep, x.w, y.w, z.w, u.w, v.w, acc);
+    }
+    for (int i = n4 + tid; i < n; i += PICP_BATCH_BLOCK) {
+      picp_accumulate(cam, T, a.thr, keep, X[i], Y[i], Z[i], U[i], V[i], acc);
+    }
+    const float tot = block_reduce_acc<PICP_BATCH_BLOCK / 64>(acc, s_red);
+    __syncthreads();            // every partial has been read
+    if (tid < 32) s_red[tid] = tot;
+    __syncthreads();
+    if (tid == 0) {
+      if (it == 0) store_pose12(s_pose, T);
+      picp_update_outofline(s_red, a.damping, s_pose, s_pose);
+      if (it == a.n_iters - 1 && a.stats_out) {
+        float* so = a.stats_out + 4 * (size_t)p;
+        so[0] = s_red[27]; so[1] = s_red[28]; so[2] = s_red[29]; so[3] = 0.f;
+      }
+    }
+    __syncthreads();
+    T = uniform_pose(load_pose12(s_pose));
+  }
+  if (tid == 0) {
+    float T16[16];
+    pose_to_T16(T, T16);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a.T_out[16 * (size_t)p + k] = T16[k];
+  }
+}
+
+hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a) {
+  if (a.n_problems <= 0) return hipSuccess;
+  int gx = (int)((a.cap + 255) / 256);
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(picp_batch_pack_kernel, dim3(gx, a.n_problems), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(picp_batch_kernel, dim3(a.n_problems), dim3(PICP_BATCH_BLOCK), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace vo

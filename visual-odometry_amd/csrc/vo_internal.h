@@ -1,0 +1,103 @@
+// vo_internal.h -- declarations shared by the translation units of libvo_hip.so
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "vo_math.h"
+
+namespace vo {
+
+// ---- PICP ------------------------------------------------------------------
+constexpr int PICP_BLOCK = 256;       // threads per workgroup of the single-problem kernels
+constexpr int PICP_PSTRIDE = 32;      // floats per workgroup partial (NACC padded)
+constexpr int PICP_MAX_BLOCKS = 2048; // grid cap (grid-stride beyond it)
+constexpr int PICP_BATCH_BLOCK = 1024;
+
+// Solver parameters, resident in device memory so that a captured graph of
+// iteration launches stays valid when the camera / threshold / count change.
+struct PicpParams {
+  CamK cam;
+  float thr;
+  float damping;
+  int keep_outliers;
+  int n_corr;
+};
+
+// Solver state in device memory.
+struct PicpState {
+  float pose[2][12];   // double buffer: R (col-major 3x3) then t
+  float H[36];         // last round, damping included (col-major)
+  float b[6];
+  float chi_in, chi_out;
+  int n_in;
+  int n_bad;           // correspondences whose indices were out of range (dropped)
+};
+
+// packed correspondences: five SoA arrays of `cap` floats each (x,y,z,u,v)
+struct PackedCorr {
+  float* base;
+  size_t cap;
+  __host__ __device__ const float* arr(int k) const { return base + (size_t)k * cap; }
+  __host__ __device__ float* arr(int k) { return base + (size_t)k * cap; }
+};
+
+hipError_t launch_picp_pack(hipStream_t st, const int32_t* d_pairs, const int* d_n, int n_max,
+                            const float* d_world, int n_world, const float* d_meas, int n_meas,
+                            PackedCorr pk, PicpParams* d_params, PicpState* d_state);
+
+// Enqueue n_iters Gauss-Newton rounds (n_iters+1 launches).  d_partials holds
+// 2 * grid * PICP_PSTRIDE floats.
+hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpState* d_state,
+                              PackedCorr pk, float* d_partials, int grid, int n_iters);
+
+int picp_grid_for(int n_corr, int n_cu);
+
+struct BatchArgs {
+  CamK cam;
+  float thr, damping;
+  int keep_outliers;
+  int n_iters;
+  int n_problems;
+  const float* world; size_t world_stride;   // strides in points
+  const float* meas; size_t meas_stride;
+  const int32_t* pairs; size_t pairs_stride; // stride in pairs
+  const int* n_pairs;
+  const float* T0;     // n_problems x 16 or null
+  float* T_out;        // n_problems x 16
+  float* stats_out;    // n_problems x 4 or null
+  float* packed;       // workspace: n_problems x 5 x cap floats
+  size_t cap;          // per-array capacity (multiple of 4)
+  int n_world, n_meas; // bounds for index checks (per problem)
+};
+hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a);
+
+// ---- geometry / matcher / join (geom.hip, match.hip) -------------------------
+struct Workspace;  // scratch owned by the context
+
+// d_scratch: compaction_scratch_ints(n) ints (per-workgroup counts / offsets)
+size_t compaction_scratch_ints(int n);
+hipError_t launch_project_points(hipStream_t st, const CamK& cam, const Pose& T, const float* d_world,
+                                 int n, int keep_indices, float* d_out_uv, int* d_counts,
+                                 int* d_scratch);
+
+hipError_t launch_transform_points(hipStream_t st, const Pose& T, const float* d_in, int n,
+                                   const int* d_n, float* d_out);
+
+hipError_t launch_triangulate(hipStream_t st, const float K[9], const Pose* X_host,
+                              const float* d_X16, const int32_t* d_pairs, int n, const int* d_n,
+                              const float* d_p1, int n1, const float* d_p2, int n2,
+                              const float* d_app2, float* d_out_xyz, int32_t* d_out_pairs,
+                              float* d_out_app, int* d_n_out, int* d_scratch);
+
+hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const int* d_n_img,
+                       const int32_t* d_world, int n_world, const int* d_n_world, int n_ref,
+                       int32_t* d_out, int* d_n_out, int* d_table /* n_ref ints */,
+                       int* d_scratch);
+
+hipError_t launch_match(hipStream_t st, const float* d_a1, int n1, const float* d_a2, int n2,
+                        float radius, int32_t* d_out_pairs, int* d_n_out,
+                        unsigned long long* d_best /* min(n1,n2) u64 */, int* d_scratch, int n_cu);
+
+}  // namespace vo

@@ -1,0 +1,394 @@
+// vo_math.h -- small fixed-size math shared by the HIP kernels and the host
+// side of libvo_hip.so.  Everything is float32, column-major like the Eigen
+// objects of the reference (defs.h:7-29).
+//
+// The library is compiled with -ffp-contract=off: the decision-making chains
+// (projection, depth/image gates, chi^2 test, cheirality test) are written in
+// the operation order of the reference so that they round like its SSE2 build
+// (CMakeLists.txt:6-7, no FMA).  Fused multiply-adds are used only where they
+// are requested explicitly (vo_fma), i.e. in the accumulators, whose summation
+// order differs from the reference's sequential loop anyway.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define VO_HD __host__ __device__ __forceinline__
+#else
+#define VO_HD inline
+#endif
+
+namespace vo {
+
+VO_HD float vo_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// Eigen 3.4 sums a fixed-size, non-vectorised 3-term inner product as
+// x0 + (x1 + x2) (Core/Redux.h, redux_novec_unroller).
+VO_HD float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+  return a0 * b0 + (a1 * b1 + a2 * b2);
+}
+
+// y = M * x, M 3x3 col-major with leading dimension ld
+VO_HD void mat3_vec(const float* M, int ld, const float x[3], float y[3]) {
+  for (int i = 0; i < 3; ++i) y[i] = dot3(M[i], x[0], M[i + ld], x[1], M[i + 2 * ld], x[2]);
+}
+
+VO_HD void mat3_mul(const float* A, int la, const float* B, int lb, float* C, int lc) {
+  float tmp[9];
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r)
+      tmp[r + 3 * c] = dot3(A[r], B[lb * c], A[r + la], B[1 + lb * c], A[r + 2 * la], B[2 + lb * c]);
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) C[r + lc * c] = tmp[r + 3 * c];
+}
+
+// Rigid pose as the kernels hold it: R col-major 3x3 + t.
+struct Pose {
+  float R[9];
+  float t[3];
+};
+
+VO_HD Pose pose_from_T16(const float T[16]) {
+  Pose p;
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) p.R[r + 3 * c] = T[r + 4 * c];
+  p.t[0] = T[12]; p.t[1] = T[13]; p.t[2] = T[14];
+  return p;
+}
+
+VO_HD void pose_to_T16(const Pose& p, float T[16]) {
+  for (int c = 0; c < 3; ++c) {
+    for (int r = 0; r < 3; ++r) T[r + 4 * c] = p.R[r + 3 * c];
+    T[3 + 4 * c] = 0.f;
+  }
+  T[12] = p.t[0]; T[13] = p.t[1]; T[14] = p.t[2]; T[15] = 1.f;
+}
+
+// Isometry3f * Vector3f: res = t; res += R * p   (camera.h:27, PointCloud.h:80)
+VO_HD void pose_apply(const Pose& X, float px, float py, float pz, float& ox, float& oy, float& oz) {
+  ox = X.t[0] + dot3(X.R[0], px, X.R[3], py, X.R[6], pz);
+  oy = X.t[1] + dot3(X.R[1], px, X.R[4], py, X.R[7], pz);
+  oz = X.t[2] + dot3(X.R[2], px, X.R[5], py, X.R[8], pz);
+}
+
+// Isometry * Isometry: R = Ra*Rb, t = Ra*tb + ta   (picp_solver.cpp:110)
+VO_HD Pose pose_mul(const Pose& A, const Pose& B) {
+  Pose C;
+  mat3_mul(A.R, 3, B.R, 3, C.R, 3);
+  float rt[3];
+  mat3_vec(A.R, 3, B.t, rt);
+  for (int i = 0; i < 3; ++i) C.t[i] = rt[i] + A.t[i];
+  return C;
+}
+
+// Isometry inverse: R^T, -(R^T t)   (utils.cpp:79)
+VO_HD Pose pose_inverse(const Pose& X) {
+  Pose I;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) I.R[r + 3 * c] = X.R[c + 3 * r];
+  float rt[3];
+  mat3_vec(I.R, 3, X.t, rt);
+  for (int i = 0; i < 3; ++i) I.t[i] = -rt[i];
+  return I;
+}
+
+// Matrix3f::inverse(): cofactors over the determinant (utils.cpp:80)
+VO_HD void mat3_inverse(const float m[9], float inv[9]) {
+#define VO_A(r, c) m[(r) + 3 * (c)]
+#define VO_COF(i1, i2, j1, j2) (VO_A(i1, j1) * VO_A(i2, j2) - VO_A(i1, j2) * VO_A(i2, j1))
+  const float c00 = VO_COF(1, 2, 1, 2), c10 = VO_COF(2, 0, 1, 2), c20 = VO_COF(0, 1, 1, 2);
+  const float det = c00 * VO_A(0, 0) + (c10 * VO_A(1, 0) + c20 * VO_A(2, 0));
+  const float invdet = 1.f / det;
+  const float c01 = VO_COF(1, 2, 2, 0), c11 = VO_COF(2, 0, 2, 0), c21 = VO_COF(0, 1, 2, 0);
+  const float c02 = VO_COF(1, 2, 0, 1), c12 = VO_COF(2, 0, 0, 1), c22 = VO_COF(0, 1, 0, 1);
+  inv[0] = c00 * invdet; inv[3] = c10 * invdet; inv[6] = c20 * invdet;
+  inv[1] = c01 * invdet; inv[4] = c11 * invdet; inv[7] = c21 * invdet;
+  inv[2] = c02 * invdet; inv[5] = c12 * invdet; inv[8] = c22 * invdet;
+#undef VO_COF
+#undef VO_A
+}
+
+// ---- camera ---------------------------------------------------------------
+struct CamK {
+  float K[9];
+  int rows, cols, z_near, z_far;
+};
+
+// Camera::projectPoint (camera.h:25-37).  pc = camera-frame point, ph = K*pc.
+// `inv` is the reciprocal the reference takes in double and rounds to float:
+// identical to the correctly rounded float division (53 >= 2*24+2).
+VO_HD bool project_point(const CamK& cam, const Pose& T, float px, float py, float pz, float& u,
+                         float& v, float pc[3], float ph[3], float& inv) {
+  pose_apply(T, px, py, pz, pc[0], pc[1], pc[2]);
+  const bool z_ok = !(pc[2] > (float)cam.z_far || pc[2] < (float)cam.z_near);
+  mat3_vec(cam.K, 3, pc, ph);
+  inv = 1.0f / ph[2];
+  u = ph[0] * inv;
+  v = ph[1] * inv;
+  const bool in_img = !(u < 0.f || u > (float)(cam.cols - 1)) && !(v < 0.f || v > (float)(cam.rows - 1));
+  return z_ok && in_img;
+}
+
+// ---- PICP per-correspondence term ----------------------------------------
+// Accumulator layout (NACC floats): 0..20 upper triangle of H row by row
+// ((0,0),(0,1)..(0,5),(1,1)..(5,5)), 21..26 b, 27 chi_inliers, 28 chi_outliers,
+// 29 number of inliers.
+constexpr int NACC = 30;
+
+// errorAndJacobian + the body of linearize's loop (picp_solver.cpp:25-53,
+// :62-95) for one correspondence: world point w, measurement z.
+// Written without divergent control flow: the reference's "continue"/"if"
+// decisions become predicates, and a term that must not contribute has the
+// inputs of its Jacobian zeroed so that no inf/nan of a rejected projection
+// can reach an accumulator.  A NaN world x marks a dropped correspondence.
+VO_HD void picp_accumulate(const CamK& cam, const Pose& T, float thr, bool keep_outliers, float wx,
+                           float wy, float wz, float zu, float zv, float acc[NACC]) {
+  float pc[3], ph[3], u, v, iz;
+  const bool ok = project_point(cam, T, wx, wy, wz, u, v, pc, ph, iz) && (wx == wx);  // :32-34, :72-73
+  float e0 = u - zu, e1 = v - zv;                                     // :35
+  const float chi = e0 * e0 + e1 * e1;                                // :75
+  const bool inl = ok && !(chi > thr);                                // :78 (strict >)
+  const bool outl = ok && (chi > thr);
+  acc[27] += inl ? chi : 0.f;                                         // :86
+  acc[28] += outl ? chi : 0.f;                                        // :82
+  acc[29] += inl ? 1.f : 0.f;                                         // :87
+  float lambda = inl ? 1.f : 0.f;
+  if (keep_outliers) lambda = outl ? sqrtf(thr / chi) : lambda;       // :80, :90
+  const bool use = lambda != 0.f;
+  iz = use ? iz : 0.f;
+  e0 = use ? e0 : 0.f;
+  e1 = use ? e1 : 0.f;
+  const float p0 = use ? pc[0] : 0.f, p1 = use ? pc[1] : 0.f, p2 = use ? pc[2] : 0.f;
+  const float h0 = use ? ph[0] : 0.f, h1 = use ? ph[1] : 0.f;
+  // Jp*K (2x3): rows [iz 0 g0], [0 iz g1] times K            (:44-51)
+  const float iz2 = iz * iz;
+  const float g0 = -h0 * iz2, g1 = -h1 * iz2;
+  float A0[3], A1[3];
+  for (int c = 0; c < 3; ++c) {
+    A0[c] = iz * cam.K[3 * c] + g0 * cam.K[2 + 3 * c];
+    A1[c] = iz * cam.K[1 + 3 * c] + g1 * cam.K[2 + 3 * c];
+  }
+  // J = (Jp K) [I | skew(-pc)]; skew(v) = [0 -v2 v1; v2 0 -v0; -v1 v0 0], v=-pc (:39-41)
+  const float v0 = -p0, v1 = -p1, v2 = -p2;
+  float J0[6], J1[6];
+  J0[0] = A0[0]; J0[1] = A0[1]; J0[2] = A0[2];
+  J1[0] = A1[0]; J1[1] = A1[1]; J1[2] = A1[2];
+  J0[3] = A0[1] * v2 + A0[2] * (-v1);
+  J1[3] = A1[1] * v2 + A1[2] * (-v1);
+  J0[4] = A0[0] * (-v2) + A0[2] * v0;
+  J1[4] = A1[0] * (-v2) + A1[2] * v0;
+  J0[5] = A0[0] * v1 + A0[1] * (-v0);
+  J1[5] = A1[0] * v1 + A1[1] * (-v0);
+  // H += J^T J * lambda ; b += J^T e * lambda                 (:92-93)
+  int k = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) {
+      const float jtj = vo_fma(J1[r], J1[c], J0[r] * J0[c]);
+      acc[k] = vo_fma(jtj, lambda, acc[k]);
+      ++k;
+    }
+  for (int r = 0; r < 6; ++r) {
+    const float jte = vo_fma(J1[r], e1, J0[r] * e0);
+    acc[21 + r] = vo_fma(jte, lambda, acc[21 + r]);
+  }
+}
+
+// ---- Eigen::LDLT (pivoted, lower) for the 6x6 normal equations ------------
+// Restates ldlt_inplace<Lower>::unblocked + LDLT::_solve_impl
+// (picp_solver.cpp:109).  `a` is the full symmetric matrix (row r, col c at
+// a[r][c]); every index below is a compile-time constant after unrolling so
+// the matrix lives in registers; the data-dependent pivot is handled by
+// comparing against constants.
+VO_HD void sym_swap6(float a[6][6], int k, int p) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j) { const float t = a[k][j]; a[k][j] = a[p][j]; a[p][j] = t; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { const float t = a[i][k]; a[i][k] = a[i][p]; a[i][p] = t; }
+}
+
+VO_HD void ldlt6_solve(float a[6][6], const float rhs[6], float x[6]) {
+  int tr[6];
+  bool zero = false;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (zero) { tr[k] = k; continue; }
+    int piv = k;
+    float big = fabsf(a[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const float v = fabsf(a[i][i]);
+      if (v > big) { big = v; piv = i; }
+    }
+    tr[k] = piv;
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p)
+      if (piv == p) sym_swap6(a, k, p);
+    if (k > 0) {
+      float tmp[6];
+#pragma unroll
+      for (int j = 0; j < k; ++j) tmp[j] = a[j][j] * a[k][j];
+      float accd = 0.f;
+#pragma unroll
+      for (int j = 0; j < k; ++j) accd += a[k][j] * tmp[j];
+      a[k][k] -= accd;
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < k; ++j) s += a[i][j] * tmp[j];
+        a[i][k] -= s;
+      }
+    }
+    const float akk = a[k][k];
+    const bool ok = fabsf(akk) > 0.f;
+    if (k == 0 && !ok) { zero = true; tr[0] = 0; continue; }
+    if (ok) {
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) a[i][k] /= akk;
+    }
+  }
+  float y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] = rhs[i];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p)
+      if (tr[k] == p) { const float t = y[k]; y[k] = y[p]; y[p] = t; }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float s = y[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) s -= a[i][j] * y[j];
+    y[i] = s;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] = (fabsf(a[i][i]) > 1.17549435e-38f) ? y[i] / a[i][i] : 0.f;
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float s = y[i];
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) s -= a[j][i] * y[j];
+    y[i] = s;
+  }
+#pragma unroll
+  for (int k = 5; k >= 0; --k) {
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p)
+      if (tr[k] == p) { const float t = y[k]; y[k] = y[p]; y[p] = t; }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = y[i];
+}
+
+// 2x2 instance of the same algorithm (utils.cpp:40): solves [m00 m10; m10 m11] x = rhs.
+VO_HD void ldlt2_solve(float m00, float m10, float m11, float r0, float r1, float& x0, float& x1) {
+  const bool sw = fabsf(m11) > fabsf(m00);
+  if (sw) { const float t = m00; m00 = m11; m11 = t; }
+  if (!(fabsf(m00) > 0.f)) { x0 = 0.f; x1 = 0.f; return; }   // zero matrix: D^+ = 0
+  m10 /= m00;
+  const float tmp0 = m00 * m10;
+  m11 -= m10 * tmp0;
+  float y0 = sw ? r1 : r0, y1 = sw ? r0 : r1;
+  y1 -= m10 * y0;
+  y0 = (fabsf(m00) > 1.17549435e-38f) ? y0 / m00 : 0.f;
+  y1 = (fabsf(m11) > 1.17549435e-38f) ? y1 / m11 : 0.f;
+  y0 -= m10 * y1;
+  x0 = sw ? y1 : y0;
+  x1 = sw ? y0 : y1;
+}
+
+// v2tEuler (utils.h:64-78): t = v[0:3], R = Rx(v3) Ry(v4) Rz(v5).  The
+// reference's sin/cos resolve to the double libm functions rounded to float.
+VO_HD Pose v2t_euler(const float v[6]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // device: float sincos (ocml); differs from the double-then-round value by
+  // at most an ulp of the matrix entry -- far inside the pose tolerance.
+  float sx, cx, sy, cy, sz, cz;
+  sincosf(v[3], &sx, &cx);
+  sincosf(v[4], &sy, &cy);
+  sincosf(v[5], &sz, &cz);
+#else
+  const float sx = (float)sin((double)v[3]), cx = (float)cos((double)v[3]);
+  const float sy = (float)sin((double)v[4]), cy = (float)cos((double)v[4]);
+  const float sz = (float)sin((double)v[5]), cz = (float)cos((double)v[5]);
+#endif
+  const float Rx[9] = {1.f, 0.f, 0.f, 0.f, cx, sx, 0.f, -sx, cx};
+  const float Ry[9] = {cy, 0.f, -sy, 0.f, 1.f, 0.f, sy, 0.f, cy};
+  const float Rz[9] = {cz, sz, 0.f, -sz, cz, 0.f, 0.f, 0.f, 1.f};
+  float Rxy[9];
+  Pose P;
+  mat3_mul(Rx, 3, Ry, 3, Rxy, 3);
+  mat3_mul(Rxy, 3, Rz, 3, P.R, 3);
+  P.t[0] = v[0]; P.t[1] = v[1]; P.t[2] = v[2];
+  return P;
+}
+
+// Tail of PICPSolver::oneRound (picp_solver.cpp:102-110): from the reduced
+// accumulators build H (+damping), solve H dx = -b, T <- v2tEuler(dx) * T.
+// H_out (36, col-major, damping included) and b_out are what the reference
+// leaves in _H/_b.
+VO_HD Pose picp_update(const float acc[NACC], float damping, const Pose& T, float* H_out,
+                       float* b_out) {
+  float a[6][6];
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 6; ++c) { a[r][c] = acc[k]; a[c][r] = acc[k]; ++k; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) a[i][i] += 1.f * damping;
+  if (H_out) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) H_out[r + 6 * c] = a[r][c];
+  }
+  float nb[6], dx[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { nb[i] = -acc[21 + i]; if (b_out) b_out[i] = acc[21 + i]; }
+  ldlt6_solve(a, nb, dx);
+  const Pose dT = v2t_euler(dx);
+  return pose_mul(dT, T);
+}
+
+// ---- triangulate_point (utils.cpp:36-49) -----------------------------------
+VO_HD bool triangulate_point(const float d1[3], const float d2[3], const float p2[3], float p[3]) {
+  const float D0[3] = {-d1[0], -d1[1], -d1[2]};
+  const float m00 = dot3(D0[0], D0[0], D0[1], D0[1], D0[2], D0[2]);
+  const float m10 = dot3(d2[0], D0[0], d2[1], D0[1], d2[2], D0[2]);
+  const float m11 = dot3(d2[0], d2[0], d2[1], d2[1], d2[2], d2[2]);
+  const float r0 = dot3(D0[0], p2[0], D0[1], p2[1], D0[2], p2[2]);
+  const float r1 = dot3(d2[0], p2[0], d2[1], p2[1], d2[2], p2[2]);
+  float s0, s1;
+  ldlt2_solve(m00, m10, m11, r0, r1, s0, s1);
+  s0 = -s0; s1 = -s1;
+  if (s0 < 0.f || s1 < 0.f) return false;                              // :41
+  for (int i = 0; i < 3; ++i) {
+    const float a = s0 * d1[i];
+    const float b = p2[i] + s1 * d2[i];
+    p[i] = 0.5f * (a + b);                                             // :44-47
+  }
+  return true;
+}
+
+// Per-frame constants of triangulate_points (utils.cpp:79-82)
+struct TriConst {
+  float iK[9];
+  float iRiK[9];
+  float t[3];
+};
+
+VO_HD TriConst tri_constants(const float K[9], const Pose& X) {
+  TriConst c;
+  const Pose iX = pose_inverse(X);
+  mat3_inverse(K, c.iK);
+  mat3_mul(iX.R, 3, c.iK, 3, c.iRiK, 3);
+  c.t[0] = iX.t[0]; c.t[1] = iX.t[1]; c.t[2] = iX.t[2];
+  return c;
+}
+
+}  // namespace vo
