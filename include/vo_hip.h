@@ -98,6 +98,8 @@ int vo_picp_set_points(vo_picp *s, const float *world_xyz, int n_world, const fl
 int vo_picp_set_points_dev(vo_picp *s, const float *d_world_xyz, int n_world,
                            const float *d_meas_uv, int n_meas);
 int vo_picp_set_pose(vo_picp *s, const float T[16]);            /* camera.h:50 */
+/* same from a 4x4 in device memory, enqueued on the stream (no host sync) */
+int vo_picp_set_pose_dev(vo_picp *s, const float *d_T16);
 int vo_picp_set_kernel_threshold(vo_picp *s, float thr);        /* picp_solver.h:35 */
 int vo_picp_get_kernel_threshold(vo_picp *s, float *thr);       /* picp_solver.h:33 */
 /* oneRound(correspondences, keep_outliers) (picp_solver.cpp:98-112):

@@ -501,6 +501,20 @@ int vo_picp_get_pose(vo_picp* s, float T[16]) {
   return r;
 }
 
+__global__ void T16_to_pose12_kernel(const float* T, float* p) {
+  const int k = threadIdx.x;
+  if (k < 9) p[k] = T[(k % 3) + 4 * (k / 3)];
+  else if (k < 12) p[k] = T[12 + (k - 9)];
+}
+
+int vo_picp_set_pose_dev(vo_picp* s, const float* d_T16) {
+  VO_REQUIRE(s && d_T16, "null argument");
+  if (int r = set_device(s->ctx)) return r;
+  hipLaunchKernelGGL(T16_to_pose12_kernel, dim3(1), dim3(64), 0, s->ctx->stream, d_T16, s->d_state->pose[0]);
+  VO_HIP_CHECK(hipGetLastError());
+  return VO_OK;
+}
+
 __global__ void pose12_to_T16_kernel(const float* p, float* T) {
   const int k = threadIdx.x;
   if (k < 16) {

@@ -1,0 +1,122 @@
+"""Device-resident frame step of the VO loop (vo_complete.cpp:150-179):
+
+    match -> join -> rigid transform of the model -> n x oneRound -> triangulate
+
+Every stage is enqueued on the context's stream through the *_dev entry points
+of the C ABI; counts travel between stages in device memory, so a frame costs
+no host synchronisation.  Used by bench.py and the GPU tests; the production
+host loop is the C++ one in apps/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .api import Context, _chk, _colmajor, _ptr
+
+
+class FramePipeline:
+    def __init__(self, ctx: Context, fp: dict, n_iters: int = 50, kernel_threshold: float = 10000.0):
+        """fp: a synth.frame_pair() dict; its arrays are uploaded once (inputs
+        resident in HBM before any timed region starts)."""
+        self.ctx, self.lib = ctx, ctx.lib
+        self.n_iters = n_iters
+        self.K = _colmajor(fp["K"], 3)
+        self.cam = (int(fp["rows"]), int(fp["cols"]), int(fp["z_near"]), int(fp["z_far"]))
+        self.n_ref, self.n_cur = len(fp["ref_app"]), len(fp["cur_app"])
+        self.n_model, self.n_mp = len(fp["model"]), len(fp["model_pairs"])
+        self.nq = min(self.n_ref, self.n_cur)
+        up = ctx.to_device
+        self.d_ref_app, self.d_cur_app = up(fp["ref_app"]), up(fp["cur_app"])
+        self.d_ref_pts, self.d_cur_pts = up(fp["ref_pts"]), up(fp["cur_pts"])
+        self.d_model, self.d_model_pairs = up(fp["model"]), up(fp["model_pairs"])
+        a = ctx.alloc
+        self.d_m = a(max(self.nq, 1) * 8)          # (ref_idx, cur_idx)
+        self.d_j = a(max(self.nq, 1) * 8)          # (cur_idx, model_idx)
+        self.d_model_t = a(max(self.n_model, 1) * 12)
+        self.d_tri_xyz = a(max(self.nq, 1) * 12)
+        self.d_tri_pairs = a(max(self.nq, 1) * 8)
+        self.d_tri_app = a(max(self.nq, 1) * 40)
+        self.d_counts = a(64)                       # [0]=n_match [1]=n_join [2]=n_tri
+        self.d_pose = a(64)
+        self.d_ident = up(np.eye(4, dtype=np.float32))
+        self.X_prev = _colmajor(np.eye(4), 4)       # pose of the previous frame (vo_complete.cpp:159)
+        h = C.c_void_p()
+        _chk(self.lib.vo_picp_create(ctx.h, C.byref(h)))
+        self.solver = h
+        _chk(self.lib.vo_picp_set_camera(h, *map(C.c_int, self.cam), _ptr(self.K), _ptr(_colmajor(np.eye(4), 4))))
+        _chk(self.lib.vo_picp_set_kernel_threshold(h, C.c_float(kernel_threshold)))
+        _chk(self.lib.vo_picp_set_points_dev(h, C.c_void_p(self.d_model_t), C.c_int(self.n_model),
+                                             C.c_void_p(self.d_cur_pts), C.c_int(self.n_cur)))
+
+    def _cnt(self, i):
+        return C.c_void_p(self.d_counts + 4 * i)
+
+    # -- stages (all asynchronous) -------------------------------------------
+    def match(self):
+        _chk(self.lib.vo_match_appearances_dev(self.ctx.h, C.c_void_p(self.d_ref_app), C.c_int(self.n_ref),
+                                               C.c_void_p(self.d_cur_app), C.c_int(self.n_cur), C.c_float(0.1),
+                                               C.c_void_p(self.d_m), self._cnt(0)))
+
+    def join(self):
+        _chk(self.lib.vo_join_correspondences_dev(self.ctx.h, C.c_void_p(self.d_m), C.c_int(self.nq), self._cnt(0),
+                                                  C.c_void_p(self.d_model_pairs), C.c_int(self.n_mp), None,
+                                                  C.c_int(self.n_ref), C.c_void_p(self.d_j), self._cnt(1)))
+
+    def transform(self):
+        _chk(self.lib.vo_transform_points_dev(self.ctx.h, _ptr(self.X_prev), C.c_void_p(self.d_model),
+                                              C.c_int(self.n_model), None, C.c_void_p(self.d_model_t)))
+
+    def picp(self):
+        """solver re-initialised at identity every frame (vo_complete.cpp:161-164)"""
+        _chk(self.lib.vo_picp_set_pose_dev(self.solver, C.c_void_p(self.d_ident)))
+        _chk(self.lib.vo_picp_solve_dev(self.solver, C.c_void_p(self.d_j), C.c_int(self.nq), self._cnt(1),
+                                        C.c_int(0), C.c_int(self.n_iters)))
+        _chk(self.lib.vo_picp_get_pose_dev(self.solver, C.c_void_p(self.d_pose)))
+
+    def triangulate(self):
+        _chk(self.lib.vo_triangulate_dev(self.ctx.h, _ptr(self.K), None, C.c_void_p(self.d_pose),
+                                         C.c_void_p(self.d_m), C.c_int(self.nq), self._cnt(0),
+                                         C.c_void_p(self.d_ref_pts), C.c_int(self.n_ref),
+                                         C.c_void_p(self.d_cur_pts), C.c_int(self.n_cur),
+                                         C.c_void_p(self.d_cur_app), C.c_void_p(self.d_tri_xyz),
+                                         C.c_void_p(self.d_tri_pairs), C.c_void_p(self.d_tri_app), self._cnt(2)))
+
+    def frame(self):
+        self.match(); self.join(); self.transform(); self.picp(); self.triangulate()
+
+    # -- results (synchronise) -------------------------------------------------
+    def counts(self):
+        c = np.zeros(3, np.int32)
+        self.ctx.d2h(c, self.d_counts)
+        return c
+
+    def pose(self):
+        T = np.zeros(16, np.float32)
+        self.ctx.d2h(T, self.d_pose)
+        return T.reshape(4, 4).T.copy()
+
+    def fetch(self, what):
+        c = self.counts()
+        spec = {"match": (self.d_m, c[0], 2, np.int32), "join": (self.d_j, c[1], 2, np.int32),
+                "tri_xyz": (self.d_tri_xyz, c[2], 3, np.float32), "tri_pairs": (self.d_tri_pairs, c[2], 2, np.int32),
+                "tri_app": (self.d_tri_app, c[2], 10, np.float32)}[what]
+        out = np.zeros((int(spec[1]), spec[2]), spec[3])
+        if len(out):
+            self.ctx.d2h(out, spec[0])
+        return out
+
+    def stats(self):
+        ci, co, ni = C.c_float(), C.c_float(), C.c_int()
+        _chk(self.lib.vo_picp_get_stats(self.solver, C.byref(ci), C.byref(co), C.byref(ni)))
+        return ci.value, co.value, ni.value
+
+    def close(self):
+        if self.solver:
+            self.lib.vo_picp_destroy(self.solver)
+            self.solver = None
+        for d in (self.d_ref_app, self.d_cur_app, self.d_ref_pts, self.d_cur_pts, self.d_model, self.d_model_pairs,
+                  self.d_m, self.d_j, self.d_model_t, self.d_tri_xyz, self.d_tri_pairs, self.d_tri_app,
+                  self.d_counts, self.d_pose, self.d_ident):
+            self.ctx.free(d)
