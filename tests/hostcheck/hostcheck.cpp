@@ -44,6 +44,13 @@ void hc_ldlt6(const float* A_colmajor, const float* rhs, float* x) {
   ldlt6_solve(a, rhs, x);
 }
 
+// latency-optimised variant used by the kernels: permutation up front
+void hc_ldlt6_perm(const float* A_colmajor, const float* rhs, float* x) {
+  float full[36], scratch[6];
+  for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) full[6 * r + c] = A_colmajor[r + 6 * c];
+  ldlt6_solve_perm(full, rhs, scratch, x);
+}
+
 void hc_ldlt2(const float* m, const float* rhs, float* x) { ldlt2_solve(m[0], m[1], m[3], rhs[0], rhs[1], x[0], x[1]); }
 
 int hc_triangulate_point(const float* d1, const float* d2, const float* p2, float* p) {

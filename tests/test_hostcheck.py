@@ -90,9 +90,27 @@ def test_ldlt6_bit_exact_with_oracle(hc, o32):
         x = np.zeros(6, np.float32)
         hc.hc_ldlt6(p(np.ascontiguousarray(S.T).ravel()), p(b), p(x))
         assert x.tobytes() == o32.ldlt_solve(S, b).tobytes()
+        # the kernels' variant (pivot order derived up front, FMA updates, one
+        # reciprocal per column): same algorithm, rounding-level differences only
+        xp = np.zeros(6, np.float32)
+        hc.hc_ldlt6_perm(p(np.ascontiguousarray(S.T).ravel()), p(b), p(xp))
+        S64, b64 = S.astype(np.float64), b.astype(np.float64)
+        # backward error of both variants at float32 level (conditioning-independent)
+        for sol in (x, xp):
+            res = np.abs(S64 @ sol - b64).max()
+            assert res <= 2e-5 * (np.abs(S64).sum(1).max() * np.abs(sol).max() + np.abs(b64).max())
+        if k % 3 != 0:   # well conditioned: forward errors comparable
+            x64 = np.linalg.solve(S64, b64)
+            assert np.abs(xp - x64).max() <= 8 * max(np.abs(x - x64).max(), 1e-6 * np.abs(x64).max())
     z = np.zeros(6, np.float32)
     hc.hc_ldlt6(p(np.zeros(36, np.float32)), p(np.ones(6, np.float32)), p(z))
     assert np.all(z == 0)
+    hc.hc_ldlt6_perm(p(np.zeros(36, np.float32)), p(np.ones(6, np.float32)), p(z))
+    assert np.all(z == 0)
+    # ties on the diagonal (H = I + 0): identity permutation, exact solution
+    I6 = np.eye(6, dtype=np.float32) * np.float32(4.0)
+    hc.hc_ldlt6_perm(p(I6.ravel()), p(np.arange(6, dtype=np.float32)), p(z))
+    assert np.array_equal(z, np.arange(6, dtype=np.float32) / np.float32(4.0))
 
 
 def test_ldlt2_and_triangulate_point_bit_exact(hc, o32):

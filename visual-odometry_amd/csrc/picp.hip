@@ -88,6 +88,50 @@ __device__ __forceinline__ void store_pose12(float* p, const Pose& P) {
   for (int i = 0; i < 3; ++i) p[9 + i] = P.t[i];
 }
 
+// ---- tail of oneRound (picp_solver.cpp:102-110), latency-optimised -----------------
+// Stage 1 (any 42 threads, before a workgroup barrier): expand the reduced
+// accumulators into the full symmetric H (+damping) and -b in LDS.
+// Stage 2 (all 64 lanes of ONE wave, redundantly and identically, so nothing
+// diverges): pivot order from the diagonal, gather of P H P^T from LDS,
+// swap-free LDLT, dx.  The three sin/cos pairs are evaluated by three lanes at
+// once and shared through v_readlane.  Lane 0 publishes the new pose.
+//   s_sys: 48 floats of LDS: [0,36) H row-major, [36,42) -b, [42,48) scratch.
+__device__ __forceinline__ void picp_tail_expand(const float* s_tot, float* s_sys, float damping,
+                                                 float* H_out, float* b_out) {
+  const int t = threadIdx.x;
+  if (t < 36) {
+    const int r = t / 6, c = t - 6 * r;
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    const int idx = (13 * lo - lo * lo) / 2 + (hi - lo);   // row-major upper triangle
+    float v = s_tot[idx];
+    if (r == c) v += 1.f * damping;                        // picp_solver.cpp:102
+    s_sys[t] = v;
+    if (H_out) H_out[r + 6 * c] = v;
+  } else if (t < 42) {
+    const float bv = s_tot[21 + (t - 36)];
+    s_sys[t] = -bv;                                        // picp_solver.cpp:109 solve(-b)
+    if (b_out) b_out[t - 36] = bv;
+  }
+}
+
+__device__ __forceinline__ Pose picp_tail_wave(float* s_sys, const Pose& T) {
+  float dx[6];
+  ldlt6_solve_perm(s_sys, s_sys + 36, s_sys + 42, dx);
+  const int lane = threadIdx.x & 63;
+  const int m = lane % 3;
+  const float ang = m == 0 ? dx[3] : (m == 1 ? dx[4] : dx[5]);
+  float sn, cs;
+  sincosf(ang, &sn, &cs);
+  const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 0));
+  const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 0));
+  const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 1));
+  const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 1));
+  const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 2));
+  const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 2));
+  const Pose dT = v2t_from_sincos(dx, sx, cx, sy, cy, sz, cz);
+  return pose_mul(dT, T);                                  // picp_solver.cpp:110
+}
+
 // ---- pack -------------------------------------------------------------------
 __global__ __launch_bounds__(256) void picp_pack_kernel(const int32_t* __restrict__ pairs,
                                                         const int* __restrict__ d_n, int n_max,
@@ -121,6 +165,7 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams
                                                                 float* partials, int it, int nb) {
   __shared__ float s_red[16 * 32];
   __shared__ float s_tot[32];
+  __shared__ float s_sys[48];
   __shared__ float s_pose[12];
   const int tid = threadIdx.x;
   const int n = P->n_corr;
@@ -133,47 +178,46 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams
 
   Pose T;
   if (PRE) {
+    // Sum the previous launch's workgroup partials: one 128-B row per thread
+    // (eight independent 16-B loads in flight), then the same DPP/LDS tree
+    // as for the accumulators.  The rows were written by workgroups on all
+    // eight XCDs, so each load is an Infinity-Cache/HBM round trip: they must
+    // overlap, not chain.  Fixed order => every workgroup gets the same bits.
     const float* prev = partials + (size_t)((it - 1) & 1) * nb * PICP_PSTRIDE;
-    const int slot = tid & 31, grp = tid >> 5;   // 8 groups of 32 slots
-    float sf = 0.f;
-    int si = 0;
-    for (int b = grp; b < nb; b += PICP_BLOCK / 32) {
-      const float f = prev[b * PICP_PSTRIDE + slot];
-      sf += f;
-      si += __float_as_int(f);
-    }
-    s_red[grp * 32 + slot] = (slot == 29) ? __int_as_float(si) : sf;
-    __syncthreads();
-    if (tid < 32) {
-      float tf = 0.f;
-      int ti = 0;
+    float racc[NACC];
 #pragma unroll
-      for (int g = 0; g < PICP_BLOCK / 32; ++g) {
-        const float f = s_red[g * 32 + tid];
-        tf += f;
-        ti += __float_as_int(f);
+    for (int k = 0; k < NACC; ++k) racc[k] = 0.f;
+    for (int b = tid; b < nb; b += PICP_BLOCK) {
+      const float4* row = reinterpret_cast<const float4*>(prev + (size_t)b * PICP_PSTRIDE);
+      float4 r[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r[q] = row[q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (4 * q + 0 < NACC) racc[4 * q + 0] += r[q].x;
+        if (4 * q + 1 < NACC) racc[4 * q + 1] += r[q].y;
+        if (4 * q + 2 < NACC) racc[4 * q + 2] += r[q].z;
+        if (4 * q + 3 < NACC) racc[4 * q + 3] += r[q].w;
       }
-      s_tot[tid] = (tid == 29) ? __int_as_float(ti) : tf;
     }
+    const float rtot = block_reduce_acc<PICP_BLOCK / 64>(racc, s_red);
+    if (tid < 32) s_tot[tid] = rtot;
     __syncthreads();
-    if (tid == 0) {
-      float acc[NACC];
-#pragma unroll
-      for (int k = 0; k < NACC; ++k) acc[k] = s_tot[k];
-      const Pose Told = load_pose12(S->pose[(it - 1) & 1]);
-      float H[36], b[6];
-      const Pose Tn = picp_update(acc, P->damping, Told, FINISH ? H : nullptr, FINISH ? b : nullptr);
-      store_pose12(s_pose, Tn);
-      if (blockIdx.x == 0) {
-        store_pose12(S->pose[FINISH ? 0 : (it & 1)], Tn);
-        if (FINISH) {
-#pragma unroll
-          for (int k = 0; k < 36; ++k) S->H[k] = H[k];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) S->b[k] = b[k];
-          S->chi_in = acc[27];
-          S->chi_out = acc[28];
-          S->n_in = __float_as_int(s_tot[29]);
+    picp_tail_expand(s_tot, s_sys, P->damping, (FINISH && blockIdx.x == 0) ? S->H : nullptr,
+                     (FINISH && blockIdx.x == 0) ? S->b : nullptr);
+    __syncthreads();
+    if (tid < 64) {
+      const Pose Told = uniform_pose(load_pose12(S->pose[(it - 1) & 1]));
+      const Pose Tn = picp_tail_wave(s_sys, Told);
+      if (tid == 0) {
+        store_pose12(s_pose, Tn);
+        if (blockIdx.x == 0) {
+          store_pose12(S->pose[FINISH ? 0 : (it & 1)], Tn);
+          if (FINISH) {
+            S->chi_in = s_tot[27];
+            S->chi_out = s_tot[28];
+            S->n_in = (int)(s_tot[29] + 0.5f);
+          }
         }
       }
     }
@@ -200,8 +244,7 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams
   }
   const float tot = block_reduce_acc<PICP_BLOCK / 64>(acc, s_red);
   if (tid < PICP_PSTRIDE) {
-    float o = tot;
-    if (tid == 29) o = __int_as_float((int)(tot + 0.5f));
+    float o = tot;   // slot 29 (inlier count) is an exact integer in float: < 2^24 correspondences
     if (tid >= NACC) o = 0.f;
     partials[((size_t)(it & 1) * nb + blockIdx.x) * PICP_PSTRIDE + tid] = o;
   }
@@ -246,18 +289,6 @@ hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpSt
 }
 
 // ---- batched solver -----------------------------------------------------------
-// The 6x6 solve runs on one lane once per iteration; keeping it out of line
-// stops its ~90 live registers from setting the whole kernel's VGPR budget.
-__device__ __attribute__((noinline)) void picp_update_outofline(const float* acc_lds, float damping,
-                                                                 const float* pose_in, float* pose_out) {
-  float r[NACC];
-#pragma unroll
-  for (int k = 0; k < NACC; ++k) r[k] = acc_lds[k];
-  const Pose T = load_pose12(pose_in);
-  const Pose Tn = picp_update(r, damping, T, nullptr, nullptr);
-  store_pose12(pose_out, Tn);
-}
-
 __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
   const int p = blockIdx.y;
   int n = a.n_pairs[p];
@@ -281,6 +312,8 @@ __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
 
 __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs a) {
   __shared__ float s_red[(PICP_BATCH_BLOCK / 64) * 4 * 32];
+  __shared__ float s_tot[32];
+  __shared__ float s_sys[48];
   __shared__ float s_pose[12];
   const int tid = threadIdx.x;
   const int p = blockIdx.x;
@@ -328,15 +361,18 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
       picp_accumulate(cam, T, a.thr, keep, X[i], Y[i], Z[i], U[i], V[i], acc);
     }
     const float tot = block_reduce_acc<PICP_BATCH_BLOCK / 64>(acc, s_red);
-    __syncthreads();            // every partial has been read
-    if (tid < 32) s_red[tid] = tot;
+    if (tid < 32) s_tot[tid] = tot;
     __syncthreads();
-    if (tid == 0) {
-      if (it == 0) store_pose12(s_pose, T);
-      picp_update_outofline(s_red, a.damping, s_pose, s_pose);
-      if (it == a.n_iters - 1 && a.stats_out) {
-        float* so = a.stats_out + 4 * (size_t)p;
-        so[0] = s_red[27]; so[1] = s_red[28]; so[2] = s_red[29]; so[3] = 0.f;
+    picp_tail_expand(s_tot, s_sys, a.damping, nullptr, nullptr);
+    __syncthreads();
+    if (tid < 64) {
+      const Pose Tn = picp_tail_wave(s_sys, T);
+      if (tid == 0) {
+        store_pose12(s_pose, Tn);
+        if (it == a.n_iters - 1 && a.stats_out) {
+          float* so = a.stats_out + 4 * (size_t)p;
+          so[0] = s_tot[27]; so[1] = s_tot[28]; so[2] = s_tot[29]; so[3] = 0.f;
+        }
       }
     }
     __syncthreads();

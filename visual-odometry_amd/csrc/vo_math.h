@@ -284,6 +284,122 @@ VO_HD void ldlt6_solve(float a[6][6], const float rhs[6], float x[6]) {
   for (int i = 0; i < 6; ++i) x[i] = y[i];
 }
 
+// ---- latency-optimised form of the same factorisation ------------------------
+// Eigen's unblocked LDLT is left-looking: at step k it has updated only the
+// columns < k, so the "largest remaining diagonal" it pivots on is always an
+// ORIGINAL diagonal entry.  The whole pivot sequence therefore follows from the
+// six original diagonal values alone (simulated below exactly as Eigen swaps
+// them, ties included), and applying that permutation up front turns the
+// factorisation into the swap-free algorithm on P A P^T -- the same arithmetic
+// in the same order as ldlt6_solve, without 15 data-dependent symmetric swaps.
+// The permuted entries are gathered from memory (LDS on the device) with
+// computed addresses; everything after that uses compile-time indices.
+// Device build: one Newton-refined reciprocal per column replaces Eigen's
+// per-element divisions and the updates use FMA (<= ~1 ulp per entry).
+VO_HD float vo_recip(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r = __builtin_amdgcn_rcpf(x);
+  r = vo_fma(vo_fma(-x, r, 1.0f), r, r);
+  return r;
+#else
+  return 1.0f / x;
+#endif
+}
+
+// full36: symmetric 6x6 (row r, col c at full36[6*r+c], damping included);
+// rhs6: right-hand side; scratch6: 6 writable floats in the same memory space.
+VO_HD void ldlt6_solve_perm(const float* full36, const float* rhs6, float* scratch6, float x[6]) {
+  float dv[6];
+  int org[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { dv[i] = fabsf(full36[7 * i]); org[i] = i; }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    int piv = k;
+    float big = dv[k];
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const bool g = dv[i] > big;       // strict: first maximum wins, as maxCoeff
+      big = g ? dv[i] : big;
+      piv = g ? i : piv;
+    }
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p) {
+      const bool sel = piv == p;
+      const float tv = dv[k]; dv[k] = sel ? dv[p] : dv[k]; dv[p] = sel ? tv : dv[p];
+      const int to = org[k]; org[k] = sel ? org[p] : org[k]; org[p] = sel ? to : org[p];
+    }
+  }
+  // B = P A P^T (lower triangle), y = P rhs
+  float B[6][6];
+  float y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    y[i] = rhs6[org[i]];
+#pragma unroll
+    for (int j = 0; j <= i; ++j) B[i][j] = full36[6 * org[i] + org[j]];
+  }
+  float inv[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (k > 0) {
+      float tmp[6];
+#pragma unroll
+      for (int j = 0; j < k; ++j) tmp[j] = B[j][j] * B[k][j];
+      float accd = 0.f;
+#pragma unroll
+      for (int j = 0; j < k; ++j) accd = vo_fma(B[k][j], tmp[j], accd);
+      B[k][k] -= accd;
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < k; ++j) sacc = vo_fma(B[i][j], tmp[j], sacc);
+        B[i][k] -= sacc;
+      }
+    }
+    const float akk = B[k][k];
+    inv[k] = (fabsf(akk) > 1.17549435e-38f) ? vo_recip(akk) : 0.f;
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) B[i][k] *= inv[k];
+  }
+#pragma unroll
+  for (int i = 1; i < 6; ++i) {
+    float sacc = y[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) sacc = vo_fma(-B[i][j], y[j], sacc);
+    y[i] = sacc;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] *= inv[i];
+#pragma unroll
+  for (int i = 4; i >= 0; --i) {
+    float sacc = y[i];
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) sacc = vo_fma(-B[j][i], y[j], sacc);
+    y[i] = sacc;
+  }
+  // x = P^T y
+#pragma unroll
+  for (int i = 0; i < 6; ++i) scratch6[org[i]] = y[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = scratch6[i];
+}
+
+// R = Rx Ry Rz written out: the 3-term products of utils.h:64-78 with the
+// structural zeros/ones of the three factors removed (x*1, x+0 and 0*x are
+// exact), so the entries round exactly like the generic product.
+VO_HD Pose v2t_from_sincos(const float v[6], float sx, float cx, float sy, float cy, float sz, float cz) {
+  // Rx*Ry = [cy 0 sy; sx*sy cx -sx*cy; -cx*sy sx cx*cy]
+  const float a10 = sx * sy, a12 = -sx * cy, a20 = -cx * sy, a22 = cx * cy;
+  Pose P;
+  P.R[0] = cy * cz;              P.R[3] = cy * (-sz);            P.R[6] = sy;
+  P.R[1] = a10 * cz + cx * sz;   P.R[4] = a10 * (-sz) + cx * cz; P.R[7] = a12;
+  P.R[2] = a20 * cz + sx * sz;   P.R[5] = a20 * (-sz) + sx * cz; P.R[8] = a22;
+  P.t[0] = v[0]; P.t[1] = v[1]; P.t[2] = v[2];
+  return P;
+}
+
 // 2x2 instance of the same algorithm (utils.cpp:40): solves [m00 m10; m10 m11] x = rhs.
 VO_HD void ldlt2_solve(float m00, float m10, float m11, float r0, float r1, float& x0, float& x1) {
   const bool sw = fabsf(m11) > fabsf(m00);
@@ -316,15 +432,7 @@ VO_HD Pose v2t_euler(const float v[6]) {
   const float sy = (float)sin((double)v[4]), cy = (float)cos((double)v[4]);
   const float sz = (float)sin((double)v[5]), cz = (float)cos((double)v[5]);
 #endif
-  const float Rx[9] = {1.f, 0.f, 0.f, 0.f, cx, sx, 0.f, -sx, cx};
-  const float Ry[9] = {cy, 0.f, -sy, 0.f, 1.f, 0.f, sy, 0.f, cy};
-  const float Rz[9] = {cz, sz, 0.f, -sz, cz, 0.f, 0.f, 0.f, 1.f};
-  float Rxy[9];
-  Pose P;
-  mat3_mul(Rx, 3, Ry, 3, Rxy, 3);
-  mat3_mul(Rxy, 3, Rz, 3, P.R, 3);
-  P.t[0] = v[0]; P.t[1] = v[1]; P.t[2] = v[2];
-  return P;
+  return v2t_from_sincos(v, sx, cx, sy, cy, sz, cz);
 }
 
 // Tail of PICPSolver::oneRound (picp_solver.cpp:102-110): from the reduced
