@@ -1,0 +1,8 @@
+// vo/vo.hpp -- umbrella header of the C++ facade.
+#pragma once
+#include "camera.hpp"
+#include "context.hpp"
+#include "picp_solver.hpp"
+#include "point_cloud.hpp"
+#include "types.hpp"
+#include "utils.hpp"

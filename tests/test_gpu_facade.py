@@ -1,0 +1,75 @@
+"""The C++ facade (include/vo/*.hpp: Camera, PICPSolver, triangulate_points,
+compute_correspondences_images, extract_correspondences_world, Isometry*cloud)
+driven by compiled C++ programs, checked against the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Camera as OCam
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "apps", "bin")
+
+
+def _build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "apps"), "-s"])
+
+
+def test_picp_test_app_converges():
+    _build()
+    for seed in ("7", "11"):
+        r = subprocess.run([os.path.join(BIN, "picp_test"), seed, "1000", "300"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "max abs error" in r.stdout
+
+
+def test_frame_through_cpp_facade(tmp_path, vo, o32):
+    _build()
+    fp = vo.synth.frame_pair(1200, seed=123, drop=0.1, distractors=30, model_drop=0.1)
+    rng = np.random.default_rng(0)
+    X_prev = vo.synth.random_isometry(rng, 0.01, 0.02)          # pose of the previous frame
+    model_prev = o32.transform_points(np.linalg.inv(X_prev.astype(np.float64)).astype(np.float32), fp["model"])
+    n_iters, thr = 12, 10000.0
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("9i", fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], len(fp["ref_pts"]), len(fp["cur_pts"]),
+                            len(model_prev), len(fp["model_pairs"]), n_iters))
+        f.write(struct.pack("f", thr))
+        f.write(np.ascontiguousarray(fp["K"].T, np.float32).tobytes())
+        f.write(np.ascontiguousarray(X_prev.T, np.float32).tobytes())
+        for a in (fp["ref_pts"], fp["ref_app"], fp["cur_pts"], fp["cur_app"], model_prev):
+            f.write(np.ascontiguousarray(a, np.float32).tobytes())
+        f.write(np.ascontiguousarray(fp["model_pairs"], np.int32).tobytes())
+    r = subprocess.run([os.path.join(BIN, "frame_check"), str(inp), str(outp)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(outp, "rb").read()
+    off = 0
+
+    def take(dtype, count, shape):
+        nonlocal off
+        a = np.frombuffer(raw, dtype=dtype, count=count, offset=off).reshape(shape)
+        off += a.nbytes
+        return a
+    n_m, n_j, n_t, n_in = take(np.int32, 4, (4,)).tolist()
+    m = take(np.int32, 2 * n_m, (-1, 2)); j = take(np.int32, 2 * n_j, (-1, 2))
+    T = take(np.float32, 16, (4, 4)).T
+    chi_in, chi_out = take(np.float32, 2, (2,)).tolist()
+    tri = take(np.float32, 3 * n_t, (-1, 3)); tri_pairs = take(np.int32, 2 * n_t, (-1, 2)); tri_app = take(np.float32, 10 * n_t, (-1, 10))
+    moved = take(np.float32, 3 * len(model_prev), (-1, 3))
+    assert off == len(raw)
+    # oracle, stage by stage on the same inputs
+    m_o = o32.match(fp["ref_app"], fp["cur_app"]); j_o = o32.join(m_o, fp["model_pairs"])
+    assert np.array_equal(m, m_o) and np.array_equal(j, j_o)
+    moved_o = o32.transform_points(X_prev, model_prev)
+    assert np.array_equal(moved, moved_o)
+    ro = o32.picp_solve(OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4)), moved_o,
+                        fp["cur_pts"], j_o, n_iters, thr, False, trace=False)
+    assert n_in == ro["num_inliers"] and np.abs(T - ro["T"]).max() < 1e-4
+    assert abs(chi_in - ro["chi_inliers"]) <= 1e-3 * max(1.0, ro["chi_inliers"]) and chi_out == ro["chi_outliers"] == 0
+    xo, po, ao = o32.triangulate(fp["K"], T, m_o, fp["ref_pts"], fp["cur_pts"], fp["cur_app"])
+    assert np.array_equal(tri_pairs, po) and np.array_equal(tri_app, ao)
+    assert np.all(np.abs(tri - xo) <= 1e-4 * np.maximum(1, np.abs(xo)))
