@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--frame-steps", type=int, default=30, help="frames of the whole-frame leg (0: skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU-baseline leg (0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="headline measurement only")
+    ap.add_argument("--legs", default="frame,batched,cpu", help="extra legs to run (comma list of frame,batched,cpu)")
     return ap.parse_args()
 
 
@@ -142,13 +143,14 @@ def main():
                              "event time over the timed region / launches, i.e. it includes the kernel boundary"},
     }
 
-    if rank == 0 and not args.no_extras:
+    legs = set() if args.no_extras else set(args.legs.split(","))
+    if rank == 0 and legs:
         with torch.cuda.stream(stream):
-            if args.frame_steps > 0:
+            if args.frame_steps > 0 and "frame" in legs:
                 out["frame"] = frame_leg(torch, ctx, stream, pipe, fp, args)
-            if args.batch_pairs > 0:
+            if args.batch_pairs > 0 and "batched" in legs:
                 out["batched"] = batched_leg(torch, vo, ctx, stream, args)
-        if args.cpu_seconds > 0 and world == 1:
+        if args.cpu_seconds > 0 and world == 1 and "cpu" in legs:
             out["cpu_baseline"] = cpu_leg(fp, pipe, args)
     pipe.close()
     if dist is not None:

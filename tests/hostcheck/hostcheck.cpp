@@ -33,6 +33,22 @@ void hc_picp_accumulate(int rows, int cols, int zn, int zf, const float* K, cons
   }
 }
 
+// PINHOLE instantiation (structural zeros of K removed): must equal the general one bit for bit
+void hc_picp_accumulate_pinhole(int rows, int cols, int zn, int zf, const float* K, const float* T16, float thr,
+                                int keep, const float* world, const float* meas, const int* corr, int n, float* acc) {
+  const CamK cam = mk(rows, cols, zn, zf, K);
+  const Pose T = pose_from_T16(T16);
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float* w = world + 3 * corr[2 * i + 1];
+    const float* z = meas + 2 * corr[2 * i];
+    if (keep) picp_accumulate_t<true, true>(cam, T, thr, w[0], w[1], w[2], z[0], z[1], acc);
+    else picp_accumulate_t<true, false>(cam, T, thr, w[0], w[1], w[2], z[0], z[1], acc);
+  }
+}
+
+int hc_is_pinhole(const float* K) { return is_pinhole(K) ? 1 : 0; }
+
 void hc_picp_update(const float* acc, float damping, const float* T16, float* T16_out, float* H, float* b) {
   const Pose Tn = picp_update(acc, damping, pose_from_T16(T16), H, b);
   pose_to_T16(Tn, T16_out);

@@ -62,6 +62,12 @@ def test_picp_term_and_update(hc, o32, o64, vo):
         hc.hc_picp_accumulate(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], p(cm(fp["K"], 3)),
                               p(cm(np.eye(4), 4)), C.c_float(thr), keep, p(fp["model"]), p(fp["cur_pts"]),
                               p(j), len(j), p(acc))
+        accp = np.zeros(30, np.float32)
+        assert hc.hc_is_pinhole(p(cm(fp["K"], 3))) == 1
+        hc.hc_picp_accumulate_pinhole(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], p(cm(fp["K"], 3)),
+                                      p(cm(np.eye(4), 4)), C.c_float(thr), keep, p(fp["model"]), p(fp["cur_pts"]),
+                                      p(j), len(j), p(accp))
+        assert accp.tobytes() == acc.tobytes()          # pinhole specialisation == general 3x3 K, bit for bit
         H = np.zeros((6, 6), np.float32)
         H[np.triu_indices(6)] = acc[:21]
         H = H + np.triu(H, 1).T

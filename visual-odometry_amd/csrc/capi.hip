@@ -95,8 +95,9 @@ struct vo_picp {
   bool key_dev = false;
   bool packed_valid = false;
   int grid = 1;
+  int zeroed_for_grid = -1;   // grid the (zero-padded) partial buffers were last cleared for
   int use_graph = 1;
-  std::map<std::tuple<int, int, const void*, size_t, const void*>, hipGraphExec_t> graphs;
+  std::map<std::tuple<int, int, const void*, size_t, const void*, int>, hipGraphExec_t> graphs;
 };
 
 static int set_device(vo_ctx* ctx) {
@@ -397,7 +398,16 @@ static int picp_prepare(vo_picp* s, const int32_t* d_pairs, int n_pairs, const i
     const size_t cap = ((size_t)(n_pairs > 0 ? n_pairs : 1) + 3) & ~(size_t)3;
     VO_HIP_CHECK(s->packed.ensure(sizeof(float) * 5 * cap, c->stream));
     s->grid = picp_grid_for(n_pairs, c->n_cu);
-    VO_HIP_CHECK(s->partials.ensure(sizeof(float) * 2 * (size_t)s->grid * PICP_PSTRIDE, c->stream));
+    {
+      // two buffers of round_up(grid,256) rows; rows >= grid are never written and must read as zero
+      const size_t rows = ((size_t)s->grid + 255) & ~(size_t)255;
+      const size_t bytes = sizeof(float) * 2 * rows * PICP_PSTRIDE;
+      if (bytes > s->partials.cap || s->grid != s->zeroed_for_grid) {
+        VO_HIP_CHECK(s->partials.ensure(bytes, c->stream));
+        VO_HIP_CHECK(hipMemsetAsync(s->partials.p, 0, s->partials.cap, c->stream));
+        s->zeroed_for_grid = s->grid;
+      }
+    }
     PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
     VO_HIP_CHECK(launch_picp_pack(c->stream, d_pairs, d_n, n_pairs, s->d_world, s->n_world, s->d_meas,
                                   s->n_meas, pk, s->d_params, s->d_state));
@@ -410,15 +420,17 @@ static int picp_enqueue(vo_picp* s, int n_iters) {
   vo_ctx* c = s->ctx;
   PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
   float* partials = s->partials.as<float>();
+  const bool pinhole = is_pinhole(s->hp.cam.K), keep = s->hp.keep_outliers != 0;
   if (s->use_graph && n_iters >= 2) {
-    auto key = std::make_tuple(n_iters, s->grid, (const void*)pk.base, pk.cap, (const void*)partials);
+    auto key = std::make_tuple(n_iters, s->grid, (const void*)pk.base, pk.cap, (const void*)partials,
+                               (pinhole ? 1 : 0) | (keep ? 2 : 0));
     auto it = s->graphs.find(key);
     if (it == s->graphs.end()) {
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
       hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
       if (e == hipSuccess) {
-        hipError_t el = launch_picp_rounds(c->stream, s->d_params, s->d_state, pk, partials, s->grid, n_iters);
+        hipError_t el = launch_picp_rounds(c->stream, s->d_params, s->d_state, pk, partials, s->grid, n_iters, pinhole, keep);
         e = hipStreamEndCapture(c->stream, &graph);
         if (e == hipSuccess && el != hipSuccess) e = el;
       }
@@ -440,7 +452,7 @@ static int picp_enqueue(vo_picp* s, int n_iters) {
       return VO_OK;
     }
   }
-  VO_HIP_CHECK(launch_picp_rounds(c->stream, s->d_params, s->d_state, pk, partials, s->grid, n_iters));
+  VO_HIP_CHECK(launch_picp_rounds(c->stream, s->d_params, s->d_state, pk, partials, s->grid, n_iters, pinhole, keep));
   return VO_OK;
 }
 

@@ -26,9 +26,11 @@
 namespace vo {
 
 // ---- wave-level helpers -----------------------------------------------------
+// bound_ctrl=true with the source as "old" lets the DPP-combine pass fold the
+// move into the add (v_add_f32_dpp): one instruction per reduction step.
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
 // sum over the 16 lanes of a DPP row; every lane of the row gets the result
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void picp_pack_kernel(const int32_t* __restric
 // ---- one Gauss-Newton round ---------------------------------------------------
 // PRE:    first derive this round's pose from the partials of launch it-1.
 // FINISH: only derive the pose (single workgroup), publish the statistics.
-template <bool PRE, bool FINISH>
+template <bool PRE, bool FINISH, bool PINHOLE, bool KEEP>
 __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams* __restrict__ P,
                                                                 PicpState* S, PackedCorr pk,
                                                                 float* partials, int it, int nb) {
@@ -178,30 +180,34 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams
 
   Pose T;
   if (PRE) {
-    // Sum the previous launch's workgroup partials: one 128-B row per thread
-    // (eight independent 16-B loads in flight), then the same DPP/LDS tree
-    // as for the accumulators.  The rows were written by workgroups on all
-    // eight XCDs, so each load is an Infinity-Cache/HBM round trip: they must
-    // overlap, not chain.  Fixed order => every workgroup gets the same bits.
-    const float* prev = partials + (size_t)((it - 1) & 1) * nb * PICP_PSTRIDE;
-    float racc[NACC];
+    // Sum the previous launch's workgroup partials (nb rows of 32 floats).
+    // Thread t owns slot t%32 of rows t/32 + 8j: all of a thread's loads are
+    // issued before the first add (the rows come from all eight XCDs, i.e.
+    // Infinity-Cache/HBM round trips that must overlap, not chain), 32 lanes
+    // read one 128-B row.  Fixed order => every workgroup gets the same bits.
+    // The partial buffers are padded to a multiple of 256 rows and the padding
+    // rows stay zero, so neither the loads nor the adds need a bound check.
+    const int nb_pad = (nb + 255) & ~255;
+    const float* prev = partials + (size_t)((it - 1) & 1) * nb_pad * PICP_PSTRIDE;
+    const int slot = tid & 31, grp = tid >> 5;
+    constexpr int RPT = 32;                    // rows per thread per pass (8*32 = 256 rows per pass)
+    const float* src = prev + (size_t)grp * PICP_PSTRIDE + slot;
+    float sum = 0.f;
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+      float r[RPT];
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) racc[k] = 0.f;
-    for (int b = tid; b < nb; b += PICP_BLOCK) {
-      const float4* row = reinterpret_cast<const float4*>(prev + (size_t)b * PICP_PSTRIDE);
-      float4 r[8];
+      for (int j = 0; j < RPT; ++j) r[j] = src[(size_t)(b0 + 8 * j) * PICP_PSTRIDE];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) r[q] = row[q];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if (4 * q + 0 < NACC) racc[4 * q + 0] += r[q].x;
-        if (4 * q + 1 < NACC) racc[4 * q + 1] += r[q].y;
-        if (4 * q + 2 < NACC) racc[4 * q + 2] += r[q].z;
-        if (4 * q + 3 < NACC) racc[4 * q + 3] += r[q].w;
-      }
+      for (int j = 0; j < RPT; ++j) sum += r[j];
     }
-    const float rtot = block_reduce_acc<PICP_BLOCK / 64>(racc, s_red);
-    if (tid < 32) s_tot[tid] = rtot;
+    s_red[grp * 32 + slot] = sum;
+    __syncthreads();
+    if (tid < 32) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int g = 0; g < PICP_BLOCK / 32; ++g) tsum += s_red[g * 32 + tid];
+      s_tot[tid] = tsum;
+    }
     __syncthreads();
     picp_tail_expand(s_tot, s_sys, P->damping, (FINISH && blockIdx.x == 0) ? S->H : nullptr,
                      (FINISH && blockIdx.x == 0) ? S->b : nullptr);
@@ -230,7 +236,6 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams
 
   const CamK cam = P->cam;
   const float thr = P->thr;
-  const bool keep = P->keep_outliers != 0;
   float acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
@@ -240,13 +245,13 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams
     i += stride;
     have = i < n;
     if (have) { x = pk.arr(0)[i]; y = pk.arr(1)[i]; z = pk.arr(2)[i]; u = pk.arr(3)[i]; v = pk.arr(4)[i]; }
-    picp_accumulate(cam, T, thr, keep, cx, cy, cz, cu, cv, acc);
+    picp_accumulate_t<PINHOLE, KEEP>(cam, T, thr, cx, cy, cz, cu, cv, acc);
   }
   const float tot = block_reduce_acc<PICP_BLOCK / 64>(acc, s_red);
   if (tid < PICP_PSTRIDE) {
     float o = tot;   // slot 29 (inlier count) is an exact integer in float: < 2^24 correspondences
     if (tid >= NACC) o = 0.f;
-    partials[((size_t)(it & 1) * nb + blockIdx.x) * PICP_PSTRIDE + tid] = o;
+    partials[((size_t)(it & 1) * ((nb + 255) & ~255) + blockIdx.x) * PICP_PSTRIDE + tid] = o;
   }
 }
 
@@ -275,16 +280,29 @@ hipError_t launch_picp_pack(hipStream_t st, const int32_t* d_pairs, const int* d
   return hipGetLastError();
 }
 
-hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpState* d_state,
-                              PackedCorr pk, float* d_partials, int grid, int n_iters) {
-  if (n_iters <= 0) return hipSuccess;
-  hipLaunchKernelGGL((picp_round_kernel<false, false>), dim3(grid), dim3(PICP_BLOCK), 0, st,
+template <bool PINHOLE, bool KEEP>
+static void launch_rounds_t(hipStream_t st, const PicpParams* d_params, PicpState* d_state, PackedCorr pk,
+                            float* d_partials, int grid, int n_iters) {
+  hipLaunchKernelGGL((picp_round_kernel<false, false, PINHOLE, KEEP>), dim3(grid), dim3(PICP_BLOCK), 0, st,
                      d_params, d_state, pk, d_partials, 0, grid);
   for (int it = 1; it < n_iters; ++it)
-    hipLaunchKernelGGL((picp_round_kernel<true, false>), dim3(grid), dim3(PICP_BLOCK), 0, st,
+    hipLaunchKernelGGL((picp_round_kernel<true, false, PINHOLE, KEEP>), dim3(grid), dim3(PICP_BLOCK), 0, st,
                        d_params, d_state, pk, d_partials, it, grid);
-  hipLaunchKernelGGL((picp_round_kernel<true, true>), dim3(1), dim3(PICP_BLOCK), 0, st, d_params,
+  hipLaunchKernelGGL((picp_round_kernel<true, true, false, false>), dim3(1), dim3(PICP_BLOCK), 0, st, d_params,
                      d_state, pk, d_partials, n_iters, grid);
+}
+
+hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpState* d_state,
+                              PackedCorr pk, float* d_partials, int grid, int n_iters, bool pinhole,
+                              bool keep_outliers) {
+  if (n_iters <= 0) return hipSuccess;
+  if (pinhole) {
+    if (keep_outliers) launch_rounds_t<true, true>(st, d_params, d_state, pk, d_partials, grid, n_iters);
+    else launch_rounds_t<true, false>(st, d_params, d_state, pk, d_partials, grid, n_iters);
+  } else {
+    if (keep_outliers) launch_rounds_t<false, true>(st, d_params, d_state, pk, d_partials, grid, n_iters);
+    else launch_rounds_t<false, false>(st, d_params, d_state, pk, d_partials, grid, n_iters);
+  }
   return hipGetLastError();
 }
 
@@ -310,6 +328,7 @@ __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
   }
 }
 
+template <bool PINHOLE, bool KEEP>
 __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs a) {
   __shared__ float s_red[(PICP_BATCH_BLOCK / 64) * 4 * 32];
   __shared__ float s_tot[32];
@@ -340,25 +359,32 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
-    const bool keep = a.keep_outliers != 0;
-    for (int i = tid * 4; i < n4; i += PICP_BATCH_BLOCK * 4) {
-      const float4 x = *reinterpret_cast<const float4*>(X + i);
-      const float4 y = *reinterpret_cast<const float4*>(Y + i);
-      const float4 z = *reinterpret_cast<const float4*>(Z + i);
-      const float4 u = *reinterpret_cast<const float4*>(U + i);
-      const float4 v = *reinterpret_cast<const float4*>(V + i);
-      // the four terms are kept apart (sched_barrier) so that their temporaries
-      // do not overlap: 1024-thread workgroups have 128 VGPRs per lane
-      picp_accumulate(cam, T, a.thr, keep, x.x, y.x, z.x, u.x, v.x, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      picp_accumulate(cam, T, a.thr, keep, x.y, y.y, z.y, u.y, v.y, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      picp_accumulate(cam, T, a.thr, keep, x.z, y.z, z.z, u.z, v.z, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      picp_accumulate(cam, T, a.thr, keep, x.w, y.w, z.w, u.w, v.w, acc);
+    // register double buffering: the next trip's five 16-B loads are in flight
+    // while the current four correspondences are linearised
+    int i = tid * 4;
+    bool have = i < n4;
+    float4 x, y, z, u, v;
+    if (have) {
+      x = *reinterpret_cast<const float4*>(X + i); y = *reinterpret_cast<const float4*>(Y + i);
+      z = *reinterpret_cast<const float4*>(Z + i); u = *reinterpret_cast<const float4*>(U + i);
+      v = *reinterpret_cast<const float4*>(V + i);
+    }
+    while (have) {
+      const float4 cx = x, cy = y, cz = z, cu = u, cv = v;
+      i += PICP_BATCH_BLOCK * 4;
+      have = i < n4;
+      if (have) {
+        x = *reinterpret_cast<const float4*>(X + i); y = *reinterpret_cast<const float4*>(Y + i);
+        z = *reinterpret_cast<const float4*>(Z + i); u = *reinterpret_cast<const float4*>(U + i);
+        v = *reinterpret_cast<const float4*>(V + i);
+      }
+      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, cx.x, cy.x, cz.x, cu.x, cv.x, acc);
+      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, cx.y, cy.y, cz.y, cu.y, cv.y, acc);
+      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, cx.z, cy.z, cz.z, cu.z, cv.z, acc);
+      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, cx.w, cy.w, cz.w, cu.w, cv.w, acc);
     }
     for (int i = n4 + tid; i < n; i += PICP_BATCH_BLOCK) {
-      picp_accumulate(cam, T, a.thr, keep, X[i], Y[i], Z[i], U[i], V[i], acc);
+      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, X[i], Y[i], Z[i], U[i], V[i], acc);
     }
     const float tot = block_reduce_acc<PICP_BATCH_BLOCK / 64>(acc, s_red);
     if (tid < 32) s_tot[tid] = tot;
@@ -392,7 +418,12 @@ hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a) {
   if (gx > 64) gx = 64;
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(picp_batch_pack_kernel, dim3(gx, a.n_problems), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(picp_batch_kernel, dim3(a.n_problems), dim3(PICP_BATCH_BLOCK), 0, st, a);
+  const bool ph = is_pinhole(a.cam.K), keep = a.keep_outliers != 0;
+  const dim3 g(a.n_problems), b(PICP_BATCH_BLOCK);
+  if (ph && !keep) hipLaunchKernelGGL((picp_batch_kernel<true, false>), g, b, 0, st, a);
+  else if (ph) hipLaunchKernelGGL((picp_batch_kernel<true, true>), g, b, 0, st, a);
+  else if (!keep) hipLaunchKernelGGL((picp_batch_kernel<false, false>), g, b, 0, st, a);
+  else hipLaunchKernelGGL((picp_batch_kernel<false, true>), g, b, 0, st, a);
   return hipGetLastError();
 }
 

@@ -13,7 +13,7 @@ namespace vo {
 constexpr int PICP_BLOCK = 256;       // threads per workgroup of the single-problem kernels
 constexpr int PICP_PSTRIDE = 32;      // floats per workgroup partial (NACC padded)
 constexpr int PICP_MAX_BLOCKS = 2048; // grid cap (grid-stride beyond it)
-constexpr int PICP_BATCH_BLOCK = 1024;
+constexpr int PICP_BATCH_BLOCK = 768;   // 12 waves: 3 per SIMD, 168 VGPRs each (room for load double-buffering)
 
 // Solver parameters, resident in device memory so that a captured graph of
 // iteration launches stays valid when the camera / threshold / count change.
@@ -48,9 +48,10 @@ hipError_t launch_picp_pack(hipStream_t st, const int32_t* d_pairs, const int* d
                             PackedCorr pk, PicpParams* d_params, PicpState* d_state);
 
 // Enqueue n_iters Gauss-Newton rounds (n_iters+1 launches).  d_partials holds
-// 2 * grid * PICP_PSTRIDE floats.
+// 2 * round_up(grid,256) * PICP_PSTRIDE floats, zero-initialised.
 hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpState* d_state,
-                              PackedCorr pk, float* d_partials, int grid, int n_iters);
+                              PackedCorr pk, float* d_partials, int grid, int n_iters, bool pinhole,
+                              bool keep_outliers);
 
 int picp_grid_for(int n_corr, int n_cu);
 

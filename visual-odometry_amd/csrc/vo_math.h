@@ -137,62 +137,119 @@ VO_HD bool project_point(const CamK& cam, const Pose& T, float px, float py, flo
 // 29 number of inliers.
 constexpr int NACC = 30;
 
+// True iff K = [fx 0 cx; 0 fy cy; 0 0 1] exactly.  For such a K every product
+// with a structural 0/1 of K is exact (0*x = 0, x+0 = x, x*1 = x), so the
+// PINHOLE instantiations below drop those terms and still round bit for bit
+// like the general 3x3 formulas.
+VO_HD bool is_pinhole(const float K[9]) {
+  return K[1] == 0.f && K[2] == 0.f && K[3] == 0.f && K[5] == 0.f && K[8] == 1.f;
+}
+
 // errorAndJacobian + the body of linearize's loop (picp_solver.cpp:25-53,
 // :62-95) for one correspondence: world point w, measurement z.
 // Written without divergent control flow: the reference's "continue"/"if"
 // decisions become predicates, and a term that must not contribute has the
 // inputs of its Jacobian zeroed so that no inf/nan of a rejected projection
 // can reach an accumulator.  A NaN world x marks a dropped correspondence.
-VO_HD void picp_accumulate(const CamK& cam, const Pose& T, float thr, bool keep_outliers, float wx,
-                           float wy, float wz, float zu, float zv, float acc[NACC]) {
-  float pc[3], ph[3], u, v, iz;
-  const bool ok = project_point(cam, T, wx, wy, wz, u, v, pc, ph, iz) && (wx == wx);  // :32-34, :72-73
-  float e0 = u - zu, e1 = v - zv;                                     // :35
-  const float chi = e0 * e0 + e1 * e1;                                // :75
-  const bool inl = ok && !(chi > thr);                                // :78 (strict >)
+//
+// Decisions (depth/image gates, chi^2 test) use the reference's operation
+// order without FMA.  The accumulators use one FMA per product:
+// H_rc += J0r*J0c ; H_rc += J1r*J1c  (lambda, when it is not 1, is folded into
+// the left factor), instead of the reference's (J0r*J0c + J1r*J1c)*lambda
+// followed by an add -- same sum, fewer roundings.
+template <bool PINHOLE, bool KEEP>
+VO_HD void picp_accumulate_t(const CamK& cam, const Pose& T, float thr, float wx, float wy, float wz,
+                             float zu, float zv, float acc[NACC]) {
+  constexpr bool keep_outliers = KEEP;
+  float pc[3], ph[3];
+  pose_apply(T, wx, wy, wz, pc[0], pc[1], pc[2]);                       // camera.h:27
+  const bool z_ok = !(pc[2] > (float)cam.z_far || pc[2] < (float)cam.z_near);   // camera.h:28
+  if (PINHOLE) {
+    ph[0] = cam.K[0] * pc[0] + cam.K[6] * pc[2];
+    ph[1] = cam.K[4] * pc[1] + cam.K[7] * pc[2];
+    ph[2] = pc[2];
+  } else {
+    mat3_vec(cam.K, 3, pc, ph);                                        // camera.h:30
+  }
+  float iz = 1.0f / ph[2];                                              // camera.h:31, picp_solver.cpp:44
+  const float u = ph[0] * iz, v = ph[1] * iz;
+  const bool in_img = !(u < 0.f || u > (float)(cam.cols - 1)) && !(v < 0.f || v > (float)(cam.rows - 1));
+  const bool ok = z_ok && in_img && (wx == wx);                         // :32-34, :72-73
+  float e0 = u - zu, e1 = v - zv;                                       // :35
+  const float chi = e0 * e0 + e1 * e1;                                  // :75
+  const bool inl = ok && !(chi > thr);                                  // :78 (strict >)
   const bool outl = ok && (chi > thr);
-  acc[27] += inl ? chi : 0.f;                                         // :86
-  acc[28] += outl ? chi : 0.f;                                        // :82
-  acc[29] += inl ? 1.f : 0.f;                                         // :87
+  acc[27] += inl ? chi : 0.f;                                           // :86
+  acc[28] += outl ? chi : 0.f;                                          // :82
+  acc[29] += inl ? 1.f : 0.f;                                           // :87
   float lambda = inl ? 1.f : 0.f;
-  if (keep_outliers) lambda = outl ? sqrtf(thr / chi) : lambda;       // :80, :90
+  if (keep_outliers) lambda = outl ? sqrtf(thr / chi) : lambda;         // :80, :90
   const bool use = lambda != 0.f;
   iz = use ? iz : 0.f;
   e0 = use ? e0 : 0.f;
   e1 = use ? e1 : 0.f;
   const float p0 = use ? pc[0] : 0.f, p1 = use ? pc[1] : 0.f, p2 = use ? pc[2] : 0.f;
   const float h0 = use ? ph[0] : 0.f, h1 = use ? ph[1] : 0.f;
-  // Jp*K (2x3): rows [iz 0 g0], [0 iz g1] times K            (:44-51)
-  const float iz2 = iz * iz;
-  const float g0 = -h0 * iz2, g1 = -h1 * iz2;
-  float A0[3], A1[3];
-  for (int c = 0; c < 3; ++c) {
-    A0[c] = iz * cam.K[3 * c] + g0 * cam.K[2 + 3 * c];
-    A1[c] = iz * cam.K[1 + 3 * c] + g1 * cam.K[2 + 3 * c];
-  }
-  // J = (Jp K) [I | skew(-pc)]; skew(v) = [0 -v2 v1; v2 0 -v0; -v1 v0 0], v=-pc (:39-41)
-  const float v0 = -p0, v1 = -p1, v2 = -p2;
+  const float iz2 = iz * iz;                                            // :45
+  const float g0 = -h0 * iz2, g1 = -h1 * iz2;                           // :47-49
   float J0[6], J1[6];
-  J0[0] = A0[0]; J0[1] = A0[1]; J0[2] = A0[2];
-  J1[0] = A1[0]; J1[1] = A1[1]; J1[2] = A1[2];
-  J0[3] = A0[1] * v2 + A0[2] * (-v1);
-  J1[3] = A1[1] * v2 + A1[2] * (-v1);
-  J0[4] = A0[0] * (-v2) + A0[2] * v0;
-  J1[4] = A1[0] * (-v2) + A1[2] * v0;
-  J0[5] = A0[0] * v1 + A0[1] * (-v0);
-  J1[5] = A1[0] * v1 + A1[1] * (-v0);
+  if (PINHOLE) {
+    // Jp*K = [iz*fx 0 iz*cx+g0 ; 0 iz*fy iz*cy+g1];  J = (Jp K)[I | skew(-pc)]   (:39-51)
+    const float a = iz * cam.K[0], b = iz * cam.K[4];
+    const float c0 = iz * cam.K[6] + g0, c1 = iz * cam.K[7] + g1;
+    J0[0] = a;   J0[1] = 0.f; J0[2] = c0;
+    J1[0] = 0.f; J1[1] = b;   J1[2] = c1;
+    J0[3] = c0 * p1;
+    J1[3] = b * (-p2) + c1 * p1;
+    J0[4] = a * p2 + c0 * (-p0);
+    J1[4] = c1 * (-p0);
+    J0[5] = a * (-p1);
+    J1[5] = b * p0;
+  } else {
+    float A0[3], A1[3];
+    for (int c = 0; c < 3; ++c) {
+      A0[c] = iz * cam.K[3 * c] + g0 * cam.K[2 + 3 * c];
+      A1[c] = iz * cam.K[1 + 3 * c] + g1 * cam.K[2 + 3 * c];
+    }
+    // skew(v) = [0 -v2 v1; v2 0 -v0; -v1 v0 0] with v = -pc  (utils.h:96-102)
+    const float v0 = -p0, v1 = -p1, v2 = -p2;
+    J0[0] = A0[0]; J0[1] = A0[1]; J0[2] = A0[2];
+    J1[0] = A1[0]; J1[1] = A1[1]; J1[2] = A1[2];
+    J0[3] = A0[1] * v2 + A0[2] * (-v1);
+    J1[3] = A1[1] * v2 + A1[2] * (-v1);
+    J0[4] = A0[0] * (-v2) + A0[2] * v0;
+    J1[4] = A1[0] * (-v2) + A1[2] * v0;
+    J0[5] = A0[0] * v1 + A0[1] * (-v0);
+    J1[5] = A1[0] * v1 + A1[1] * (-v0);
+  }
+  // left factors, scaled by lambda only when it can differ from 1
+  float L0[6], L1[6];
+  for (int r = 0; r < 6; ++r) {
+    L0[r] = keep_outliers ? J0[r] * lambda : J0[r];
+    L1[r] = keep_outliers ? J1[r] * lambda : J1[r];
+  }
   // H += J^T J * lambda ; b += J^T e * lambda                 (:92-93)
   int k = 0;
   for (int r = 0; r < 6; ++r)
     for (int c = r; c < 6; ++c) {
-      const float jtj = vo_fma(J1[r], J1[c], J0[r] * J0[c]);
-      acc[k] = vo_fma(jtj, lambda, acc[k]);
+      // structural zeros of the pinhole Jacobian: J0[1] = 0, J1[0] = 0
+      const bool z0 = PINHOLE && (r == 1 || c == 1);
+      const bool z1 = PINHOLE && (r == 0 || c == 0);
+      if (!z0) acc[k] = vo_fma(L0[r], J0[c], acc[k]);
+      if (!z1) acc[k] = vo_fma(L1[r], J1[c], acc[k]);
       ++k;
     }
   for (int r = 0; r < 6; ++r) {
-    const float jte = vo_fma(J1[r], e1, J0[r] * e0);
-    acc[21 + r] = vo_fma(jte, lambda, acc[21 + r]);
+    const bool z0 = PINHOLE && r == 1, z1 = PINHOLE && r == 0;
+    if (!z0) acc[21 + r] = vo_fma(L0[r], e0, acc[21 + r]);
+    if (!z1) acc[21 + r] = vo_fma(L1[r], e1, acc[21 + r]);
   }
+}
+
+VO_HD void picp_accumulate(const CamK& cam, const Pose& T, float thr, bool keep_outliers, float wx,
+                           float wy, float wz, float zu, float zv, float acc[NACC]) {
+  if (keep_outliers) picp_accumulate_t<false, true>(cam, T, thr, wx, wy, wz, zu, zv, acc);
+  else picp_accumulate_t<false, false>(cam, T, thr, wx, wy, wz, zu, zv, acc);
 }
 
 // ---- Eigen::LDLT (pivoted, lower) for the 6x6 normal equations ------------
