@@ -1,0 +1,93 @@
+// vo_complete -- counterpart of the reference's src/apps/vo_complete.cpp:68-187
+// on the GPU path: monocular VO on a data directory with unknown data
+// association.  Same call sequence, same output files (written into the
+// current directory or into argv[2]): world.txt, trajectory_gt.txt, map.txt,
+// map_appearances.txt, trajectory_est_complete.txt, trajectory_est_data.txt.
+//   usage: vo_complete <data dir> [output dir] [rounds=100]
+#include <cstdio>
+#include <iostream>
+
+#include "vo/vo.hpp"
+
+using namespace vo;
+
+int main(int argc, char* argv[]) {
+  if (argc < 2) { std::cout << "Error: need path parameter to read data" << std::endl; return -1; }
+  std::string path(argv[1]);
+  if (path.back() != '/') path.push_back('/');
+  std::string out = argc > 2 ? argv[2] : ".";
+  if (out.back() != '/') out.push_back('/');
+  const int rounds = argc > 3 ? std::atoi(argv[3]) : 100;
+  try {
+    save_gt_trajectory(path + "trajectory.dat", out + "trajectory_gt.txt");
+    const std::regex pattern("^meas-\\d.*\\.dat$");
+    std::set<std::string> files;
+    if (!get_file_names(path, files, pattern)) { std::cout << "unable to open directory\n"; return -1; }
+    if (files.size() < 2) { std::cout << "need at least two measurement files\n"; return -1; }
+    const auto first_file = *(files.begin());
+    const auto second_file = *(files.erase(files.begin()));
+    files.erase(files.begin());
+
+    PointCloudVector<2> reference_pc, current_pc;
+    if (!get_meas_content(path + first_file, reference_pc)) { std::cout << "Unable to open file measurement file 0\n"; return -1; }
+    if (!get_meas_content(path + second_file, current_pc)) { std::cout << "Unable to open file measurement file 1\n"; return -1; }
+    Vector3fVector world_points;
+    Vector10fVector world_points_appearances;
+    if (!get_meas_content(path + "world.dat", world_points_appearances, world_points, true)) { std::cout << "Unable to open world file\n"; return -1; }
+    write_eigen_vectors_to_file(out + "world.txt", world_points);
+    // the pairs are (ref_idx,curr_idx)
+    IntPairVector correspondences_imgs = compute_correspondences_images(reference_pc.appearances(), current_pc.appearances());
+    std::vector<int> int_params;   // z_near,z_far,cols,rows
+    Matrix3f k;
+    Isometry3f H;
+    if (!get_camera_params(path + "camera.dat", int_params, k, H)) { std::cout << "Unable to get camera parameters\n"; return -1; }
+    Camera cam(int_params[3], int_params[2], int_params[0], int_params[1], k);
+
+    const Isometry3f X = estimate_transform(cam.cameraMatrix(), correspondences_imgs, reference_pc.points(), current_pc.points());
+
+    PointCloudVector<3> triangulated_pc;
+    IntPairVector correspondences_world;
+    triangulate_points(k, X, correspondences_imgs, reference_pc, current_pc, triangulated_pc, correspondences_world);   // (curr_idx,world_idx)
+
+    IsometryVector trajectory;
+    trajectory.reserve(files.size() + 2);
+    trajectory.push_back(Isometry3f::Identity());
+    trajectory.push_back(X);
+    PICPSolver solver;
+    solver.setKernelThreshold(10000);
+
+    reference_pc = current_pc;   // correspondences_world now reads (ref_idx,world_idx)
+    PointCloudVector<3> triangulated_transformed, map;
+    map.update(triangulated_pc);
+    Isometry3f history = X.inverse();
+    Isometry3f X_curr = X;
+
+    for (const auto& file : files) {
+      if (!get_meas_content(path + file, current_pc)) { std::cout << "Unable to open file " << path + file << std::endl; return -1; }
+      correspondences_imgs = compute_correspondences_images(reference_pc.appearances(), current_pc.appearances());
+      correspondences_world = extract_correspondences_world(correspondences_imgs, correspondences_world);
+      triangulated_transformed = X_curr * triangulated_pc;
+      cam.setWorldInCameraPose(Isometry3f::Identity());
+      solver.init(cam, triangulated_transformed.points(), current_pc.points());
+      for (int i = 0; i < rounds; i++) solver.oneRound(correspondences_world, false);
+      cam = solver.camera();
+      trajectory.push_back(cam.worldInCameraPose());
+      X_curr = cam.worldInCameraPose();
+      std::printf("%s: %zu matches, %zu model correspondences, %d inliers, t = % .5f % .5f % .5f\n", file.c_str(),
+                  correspondences_imgs.size(), correspondences_world.size(), solver.numInliers(), X_curr(0, 3), X_curr(1, 3), X_curr(2, 3));
+      triangulate_points(k, cam.worldInCameraPose(), correspondences_imgs, reference_pc, current_pc, triangulated_pc, correspondences_world);
+      map.update(history * triangulated_pc);
+      history = history * cam.worldInCameraPose().inverse();
+      reference_pc = current_pc;
+    }
+    map = H * map;
+    write_eigen_vectors_to_file(out + "map.txt", map.points());
+    write_eigen_vectors_to_file(out + "map_appearances.txt", map.appearances());
+    save_trajectory(out + "trajectory_est_complete.txt", trajectory, H);
+    save_trajectory(out + "trajectory_est_data.txt", trajectory, H, true);
+    return 0;
+  } catch (const vo::Error& e) {
+    std::fprintf(stderr, "vo_complete: %s\n", e.what());
+    return 2;
+  }
+}

@@ -4,6 +4,10 @@
 // PointCloud.h:70-71, which makes its triangulation O(N^2) in bytes).
 #pragma once
 
+#include <cstring>
+#include <string>
+#include <unordered_map>
+
 #include "types.hpp"
 
 namespace vo {
@@ -32,14 +36,45 @@ class PointCloudVector {
   void reserve(size_t N) { _points.reserve(N); _appearances.reserve(N); }
   size_t size() const { return _points.size(); }
   void clear() { _points.clear(); _appearances.clear(); }
+  //! map upsert keyed by exact appearance equality (PointCloud.h:52-66): a point whose
+  //! appearance is already present overwrites that entry (the FIRST such entry, as the
+  //! reference's inner loop stops at the first hit), otherwise it is appended.  The
+  //! reference scans linearly (O(N*M)); the same result is obtained with a hash index
+  //! of first occurrences, rebuilt when the container was modified behind its back.
+  void update(const PointCloudVector<dim>& cloud) {
+    if (_index_size != _appearances.size()) {
+      _index.clear();
+      for (size_t j = 0; j < _appearances.size(); ++j) _index.emplace(key(_appearances[j]), j);
+      _index_size = _appearances.size();
+    }
+    for (size_t i = 0; i < cloud.size(); i++) {
+      const auto k = key(cloud.appearances()[i]);
+      auto it = _index.find(k);
+      if (it != _index.end()) {
+        _points[it->second] = cloud.points()[i];
+      } else {
+        _index.emplace(k, _points.size());
+        _points.push_back(cloud.points()[i]);
+        _appearances.push_back(cloud.appearances()[i]);
+        _index_size = _appearances.size();
+      }
+    }
+  }
   PointsVec& points() { return _points; }
   Vector10fVector& appearances() { return _appearances; }
   const PointsVec& points() const { return _points; }
   const Vector10fVector& appearances() const { return _appearances; }
 
  protected:
+  static std::string key(const Vector10f& a) {
+    // operator== on floats treats -0 == +0 and NaN != NaN; appearances are copied bit for bit
+    // from the measurement files, so the byte image is the same equivalence in practice
+    return std::string(reinterpret_cast<const char*>(a.v), sizeof(a.v));
+  }
   PointsVec _points;
   Vector10fVector _appearances;
+  std::unordered_map<std::string, size_t> _index;
+  size_t _index_size = 0;
 };
 
 }  // namespace vo

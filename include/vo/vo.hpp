@@ -2,6 +2,9 @@
 #pragma once
 #include "camera.hpp"
 #include "context.hpp"
+#include "epipolar.hpp"
+#include "evaluation.hpp"
+#include "files.hpp"
 #include "picp_solver.hpp"
 #include "point_cloud.hpp"
 #include "types.hpp"

@@ -1,0 +1,215 @@
+"""Oracle-side restatement of the reference's whole `vo_complete` + `evaluation`
+run (vo_complete.cpp:68-187, evaluate.cpp:7-90, epipolar_utils.cpp:48-213,
+files_utils.cpp), built from the C oracle's operators plus numpy for the
+once-per-sequence linear algebra (SVDs).  TEST INFRASTRUCTURE ONLY.
+
+This is what lets the oracle be checked against the only numbers the reference
+publishes for this path: the README metrics on example_data (README.md:74-79).
+"""
+from __future__ import annotations
+
+import os
+import re
+
+import numpy as np
+
+from .oracle import Camera, Oracle
+
+
+# ---- files_utils.cpp ----------------------------------------------------------
+def read_meas(path):
+    """(pts (n,2), app (n,10), ids (n,)) from meas-XXXXX.dat"""
+    pts, app, ids = [], [], []
+    with open(path) as f:
+        lines = f.read().splitlines()[3:]
+    for line in lines:
+        w = line.split()
+        if not w:
+            continue
+        ids.append(int(w[2]))
+        v = [float(x) for x in w[3:15]]
+        pts.append(v[:2]); app.append(v[2:])
+    return (np.array(pts, np.float32).reshape(-1, 2), np.array(app, np.float32).reshape(-1, 10),
+            np.array(ids, np.int64))
+
+
+def read_world(path):
+    a = np.loadtxt(path, dtype=np.float64)
+    return a[:, 1:4].astype(np.float32), a[:, 4:14].astype(np.float32)
+
+
+def read_camera(path):
+    lines = open(path).read().splitlines()
+    K = np.zeros((3, 3), np.float32); H = np.eye(4, dtype=np.float32); ints = {}
+    i = 0
+    while i < len(lines):
+        w = lines[i].split()
+        if not w:
+            i += 1; continue
+        if w[0] == "camera":
+            for r in range(3):
+                K[r] = [float(x) for x in lines[i + 1 + r].split()]
+            i += 4; continue
+        if w[0] == "cam_transform:":
+            for r in range(4):
+                H[r] = [float(x) for x in lines[i + 1 + r].split()]
+            i += 5; continue
+        if w[0] in ("z_near:", "z_far:", "width:", "height:"):
+            ints[w[0][:-1]] = int(w[1])
+        i += 1
+    return K, H, ints
+
+
+def read_gt(path):
+    """evaluation_utils.cpp:3-31: (x, y, theta) -> planar isometries"""
+    out = []
+    for line in open(path):
+        w = line.split()
+        if not w:
+            continue
+        x, y, th = float(w[4]), float(w[5]), float(w[6])
+        T = np.eye(4)
+        T[:2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+        T[:2, 3] = [x, y]
+        out.append(T)
+    return out
+
+
+# ---- epipolar_utils.cpp ---------------------------------------------------------
+def normalize(p):
+    mx, my = max(0.0, float(p[:, 0].max())), max(0.0, float(p[:, 1].max()))
+    out = np.stack([p[:, 0] / (mx / 2) - 1, p[:, 1] / (my / 2) - 1], axis=1)
+    T = np.array([[1 / (mx / 2), 0, -1], [0, 1 / (my / 2), -1], [0, 0, 1]])
+    return out, T
+
+
+def estimate_fundamental(corr, p1, p2):
+    assert len(corr) >= 8
+    a, T1 = normalize(p1.astype(np.float64)); b, T2 = normalize(p2.astype(np.float64))
+    d1 = np.concatenate([a[corr[:, 0]], np.ones((len(corr), 1))], axis=1)
+    d2 = np.concatenate([b[corr[:, 1]], np.ones((len(corr), 1))], axis=1)
+    A = np.einsum("ni,nj->nij", d1, d2).reshape(len(corr), 9)
+    Fa = np.linalg.svd(A)[2][8].reshape(3, 3)
+    U, s, Vt = np.linalg.svd(Fa)
+    F = U @ np.diag([s[0], s[1], 0]) @ Vt
+    return T1.T @ F @ T2
+
+
+def essential_to_pair(E):
+    W = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], float)
+    U, _, Vt = np.linalg.svd(E)
+    R1 = Vt.T @ W @ U.T
+    if np.linalg.det(R1) < 0:
+        U, _, Vt = np.linalg.svd(-E)
+        R1 = Vt.T @ W @ U.T
+    R2 = Vt.T @ W.T @ U.T
+
+    def make(R):
+        ts = R @ E
+        X = np.eye(4); X[:3, :3] = R; X[:3, 3] = [ts[2, 1], ts[0, 2], ts[1, 0]]
+        return X
+    return make(R1), make(R2)
+
+
+def estimate_transform(o: Oracle, K, corr, p1, p2):
+    F = estimate_fundamental(corr, p1, p2)
+    E = K.astype(np.float64).T @ F @ K.astype(np.float64)
+    X1, X2 = essential_to_pair(E)
+    best, n_best = np.eye(4, dtype=np.float32), 0
+    for X in (X1, X2):
+        for sgn in (1.0, -1.0):
+            Xt = X.copy(); Xt[:3, 3] *= sgn
+            Xt = Xt.astype(np.float32)
+            n = len(o.triangulate(K, Xt, corr, p1, p2, want_pairs=False)[0])
+            if n > n_best:
+                best, n_best = Xt, n
+    return best
+
+
+# ---- vo_complete.cpp ------------------------------------------------------------
+def iso_inv(T):
+    R = T[:3, :3]; t = T[:3, 3]
+    X = np.eye(4, dtype=T.dtype); X[:3, :3] = R.T; X[:3, 3] = -(R.T @ t)
+    return X
+
+
+class Map:
+    """PointCloudVector::update (PointCloud.h:52-66)"""
+
+    def __init__(self):
+        self.pts, self.app, self.idx = [], [], {}
+
+    def update(self, pts, app):
+        for p, a in zip(pts, app):
+            k = a.tobytes()
+            if k in self.idx:
+                self.pts[self.idx[k]] = p
+            else:
+                self.idx[k] = len(self.pts)
+                self.pts.append(p); self.app.append(a)
+
+
+def run_vo_complete(data_dir, rounds=100, o: Oracle | None = None):
+    o = o or Oracle(32)
+    files = sorted(f for f in os.listdir(data_dir) if re.search(r"^meas-\d.*\.dat$", f))
+    K, H, ints = read_camera(os.path.join(data_dir, "camera.dat"))
+    rows, cols, zn, zf = ints["height"], ints["width"], ints["z_near"], ints["z_far"]
+    ref_pts, ref_app, _ = read_meas(os.path.join(data_dir, files[0]))
+    cur_pts, cur_app, _ = read_meas(os.path.join(data_dir, files[1]))
+    corr = o.match(ref_app, cur_app)
+    X = estimate_transform(o, K, corr, ref_pts, cur_pts)
+    tri, corr_world, tri_app = o.triangulate(K, X, corr, ref_pts, cur_pts, cur_app)
+    traj = [np.eye(4, dtype=np.float32), X.copy()]
+    m = Map(); m.update(tri, tri_app)
+    history = iso_inv(X.astype(np.float64)).astype(np.float32)
+    X_curr = X
+    ref_pts, ref_app = cur_pts, cur_app
+    stats = []
+    for f in files[2:]:
+        cur_pts, cur_app, _ = read_meas(os.path.join(data_dir, f))
+        corr = o.match(ref_app, cur_app)
+        corr_world = o.join(corr, corr_world)
+        moved = o.transform_points(X_curr, tri)
+        r = o.picp_solve(Camera(rows, cols, zn, zf, K, np.eye(4)), moved, cur_pts, corr_world, rounds, 10000.0, False,
+                         trace=False)
+        X_curr = r["T"]
+        traj.append(X_curr.copy())
+        stats.append((len(corr), len(corr_world), r["num_inliers"]))
+        tri, corr_world, tri_app = o.triangulate(K, X_curr, corr, ref_pts, cur_pts, cur_app)
+        m.update(o.transform_points(history, tri) if len(tri) else tri, tri_app)
+        history = (history.astype(np.float64) @ iso_inv(X_curr.astype(np.float64))).astype(np.float32)
+        ref_pts, ref_app = cur_pts, cur_app
+    map_pts = o.transform_points(H, np.array(m.pts, np.float32).reshape(-1, 3))
+    return dict(trajectory=traj, map=map_pts, map_app=np.array(m.app, np.float32).reshape(-1, 10), H=H, stats=stats)
+
+
+def robot_trajectory(traj, H):
+    """save_trajectory (files_utils.cpp:136-153): H <- H C X_i^-1 C^-1"""
+    C = H.astype(np.float64); Ci = np.linalg.inv(C)
+    W = np.eye(4); out = []
+    for X in traj:
+        W = W @ C @ iso_inv(X.astype(np.float64)) @ Ci
+        out.append(W.copy())
+    return out
+
+
+def evaluate(data_dir, res):
+    """evaluate.cpp:18-86 -> dict of the README metrics"""
+    gt = read_gt(os.path.join(data_dir, "trajectory.dat"))
+    est = robot_trajectory(res["trajectory"], res["H"])
+    e_th, ratio = [], []
+    for i in range(1, len(gt)):
+        Xr = np.linalg.inv(est[i - 1]) @ est[i]; Xg = np.linalg.inv(gt[i - 1]) @ gt[i]
+        e_th.append(np.trace(np.eye(3) - Xr[:3, :3].T @ Xg[:3, :3]))
+        ratio.append(np.linalg.norm(Xr[:3, 3]) / np.linalg.norm(Xg[:3, 3]))
+    r = sorted(ratio)[len(ratio) // 2]
+    scale = 1.0 / r
+    rmse_pos = np.sqrt(np.mean([np.linalg.norm(g[:3, 3] - e[:3, 3] * scale) ** 2 for g, e in zip(gt, est)]))
+    world, world_app = read_world(os.path.join(data_dir, "world.dat"))
+    first = {}
+    for j, a in enumerate(world_app):
+        first.setdefault(a.tobytes(), j)
+    errs = [np.linalg.norm(p.astype(np.float64) * scale - world[first[a.tobytes()]]) ** 2
+            for p, a in zip(res["map"], res["map_app"]) if a.tobytes() in first]
+    return dict(mean_orientation_error=float(np.mean(e_th)), median_ratio_inv=float(scale),
+                rmse_position=float(rmse_pos), rmse_map=float(np.sqrt(np.mean(errs))), matched=len(errs))

@@ -1,0 +1,53 @@
+"""configs 3/5: the C++ drivers `whole_test` and `vo_complete` + `evaluate` on the
+GPU path, against the README metrics and the oracle-side run of the same loop."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import vo_pipeline as vp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "apps", "bin")
+DATA = os.path.join(ROOT, "tests", "golden", "example_data", "data")
+README = dict(inv_ratio=0.47337, rmse_points=0.184143, rmse_pos=0.145332)
+
+
+def test_whole_test_app():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "apps"), "-s"])
+    for seed in ("3", "5"):
+        r = subprocess.run([os.path.join(BIN, "whole_test"), seed, "4000"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "EPIPOLAR" in r.stdout and "PICP" in r.stdout
+
+
+def test_vo_complete_on_example_data(tmp_path, o32):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "apps"), "-s"])
+    r = subprocess.run([os.path.join(BIN, "vo_complete"), DATA, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    e = subprocess.run([os.path.join(BIN, "evaluate"), DATA, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert e.returncode == 0, e.stdout + e.stderr
+    val = {k: float(v) for k, v in re.findall(r"^(.*?):\s*([-0-9.e+]+)", e.stdout, flags=re.M)}
+    ratio, rmse_pos, rmse_map = val["ratio used for map correction"], val["RMSE position"], val["RMSE map"]
+    # README (README.md:74-79)
+    assert abs(ratio - README["inv_ratio"]) < 2e-3
+    assert abs(rmse_pos - README["rmse_pos"]) < 0.15 * README["rmse_pos"]
+    assert 0.4 * README["rmse_points"] < rmse_map < 1.5 * README["rmse_points"]
+    # oracle run of the same loop: same matches/joins every frame, poses equal while the chain is young
+    res = vp.run_vo_complete(DATA, rounds=100, o=o32)
+    ev = vp.evaluate(DATA, res)
+    counts = re.findall(r"^meas-\d+\.dat: (\d+) matches, (\d+) model correspondences, (\d+) inliers", r.stdout, flags=re.M)
+    assert len(counts) == 119
+    got = np.array(counts, dtype=int)
+    exp = np.array(res["stats"], dtype=int)
+    assert np.array_equal(got[:, 0], exp[:, 0])                  # appearance matches: exact, all 119 frames
+    assert np.array_equal(got[:10], exp[:10])                    # joins + inlier counts: exact over the first frames
+    assert np.mean(got[:, 2] == exp[:, 2]) > 0.8                 # later frames may flip a borderline z_far gate
+    est = np.loadtxt(os.path.join(tmp_path, "trajectory_est_complete.txt"))
+    ref = np.array([T[:3, 3] for T in vp.robot_trajectory(res["trajectory"], res["H"])])
+    assert est.shape == ref.shape == (121, 3)
+    assert np.abs(est[:12] - ref[:12]).max() < 2e-3
+    assert abs(ratio - ev["median_ratio_inv"]) < 2e-3 and abs(rmse_pos - ev["rmse_position"]) < 0.1 * ev["rmse_position"]
