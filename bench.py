@@ -65,7 +65,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = vdist.init("nccl", local_rank) if world > 1 else None
+    # under torch.distributed.run (RANK set) the RCCL path runs even with one rank, so that a
+    # 1-GPU box exercises exactly the code the N-GPU launch uses
+    dist = vdist.init("nccl", local_rank) if (world > 1 or "RANK" in os.environ) else None
 
     stream = torch.cuda.Stream(device=dev)
     ctx = vo.Context(local_rank, stream.cuda_stream)
