@@ -170,6 +170,36 @@ def test_gates_match_oracle_bitwise(vo, ctx, o32):
     assert uvc.tobytes() == uvc_o.tobytes() and 0 < len(uvc) < len(pts)
 
 
+def test_matcher_variants_agree(vo, o32):
+    """Full scan (mode 1) and bucket-pruned scan (mode 2) must return the oracle's pairs on every
+    input, including duplicates (ties -> lowest index), degenerate spreads and tiny sets."""
+    import ctypes as C
+    c1, c2 = vo.Context(0), vo.Context(0)
+    assert c1.lib.vo_match_set_mode(c1.h, 1) == 0 and c2.lib.vo_match_set_mode(c2.h, 2) == 0
+    assert c1.lib.vo_match_set_mode(c1.h, 7) != 0
+    rng = np.random.default_rng(17)
+    cases = []
+    for n, seed, kw in ((50, 1, dict(drop=0.2, distractors=3)), (1500, 3, dict(drop=0.3, distractors=9)),
+                        (6000, 4, dict(drop=0.05, distractors=200))):
+        fp = vo.synth.frame_pair(n, seed=seed, **kw)
+        cases.append((fp["ref_app"], fp["cur_app"]))
+    base = rng.uniform(-1, 1, (400, 10)).astype(np.float32)
+    cases.append((np.concatenate([base, base, base[::-1]]), base))                 # exact duplicates: ties
+    cases.append((np.concatenate([base + rng.normal(0, 0.01, base.shape).astype(np.float32) for _ in range(4)]), base))
+    flat = base.copy(); flat[:, :] = flat[:, :1] * 0 + rng.uniform(-1e-3, 1e-3, base.shape).astype(np.float32)
+    cases.append((flat, flat[:100] + np.float32(1e-4)))                             # everything within the radius
+    const = np.zeros((300, 10), np.float32)
+    cases.append((const, const[:7]))                                               # zero spread in every dimension
+    one_dim = base.copy(); one_dim[:, 1:] = 0
+    cases.append((one_dim, one_dim[:50] + np.float32(0.05)))
+    for a, b in cases:
+        for x, y in ((a, b), (b, a)):
+            exp = o32.match(x, y)
+            assert np.array_equal(vo.compute_correspondences_images(x, y, ctx=c1), exp)
+            assert np.array_equal(vo.compute_correspondences_images(x, y, ctx=c2), exp)
+    c1.close(); c2.close()
+
+
 def test_matcher_sizes_and_branches(vo, ctx, o32):
     """Both tree/query role assignments, sizes that are not multiples of any
     tile, and a query set larger than one workgroup."""

@@ -75,6 +75,8 @@ struct vo_ctx {
   DevBuf out[3];
   DevBuf counts;      // small device ints
   DevBuf batch_pack;  // packed correspondences of the batched solver
+  DevBuf prune_ws;    // bucket-sorted copies of the matcher
+  int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan
 };
 
 struct vo_picp {
@@ -145,7 +147,7 @@ int vo_ctx_destroy(vo_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   c->scratch.release(); c->best.release(); c->table.release(); c->counts.release();
-  c->batch_pack.release();
+  c->batch_pack.release(); c->prune_ws.release();
   for (auto& b : c->in) b.release();
   for (auto& b : c->out) b.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -597,6 +599,13 @@ int vo_picp_solve_batch_dev(vo_ctx* c, int n_problems, int rows, int cols, int z
 }
 
 // ---- matcher ------------------------------------------------------------------------------
+int vo_match_set_mode(vo_ctx* c, int mode) {
+  VO_REQUIRE(c, "ctx is null");
+  VO_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (auto), 1 (full scan) or 2 (bucket-pruned scan)");
+  c->match_mode = mode;
+  return VO_OK;
+}
+
 int vo_match_appearances_dev(vo_ctx* c, const float* d_a1, int n1, const float* d_a2, int n2,
                              float radius, int32_t* d_out_pairs, int* d_n_out) {
   VO_REQUIRE(c && d_n_out, "null argument");
@@ -607,8 +616,16 @@ int vo_match_appearances_dev(vo_ctx* c, const float* d_a1, int n1, const float* 
   if (int r = set_device(c)) return r;
   if (int r = ensure_scratch(c, nq)) return r;
   VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)(nq ? nq : 1), c->stream));
+  // the pruned scan pays ~8 small launches of sorting: worth it from ~4 M candidate pairs on
+  const int nt = n1 > n2 ? n1 : n2;
+  const bool prune = c->match_mode == 2 || (c->match_mode == 0 && (double)nt * (double)nq >= 4.0e6);
+  void* ws = nullptr;
+  if (prune && nq > 0) {
+    VO_HIP_CHECK(c->prune_ws.ensure(match_pruned_workspace_bytes(nt, nq), c->stream));
+    ws = c->prune_ws.p;
+  }
   VO_HIP_CHECK(launch_match(c->stream, d_a1, n1, d_a2, n2, radius, d_out_pairs, d_n_out,
-                            c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu));
+                            c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws));
   return VO_OK;
 }
 

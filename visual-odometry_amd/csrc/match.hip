@@ -115,15 +115,266 @@ __global__ __launch_bounds__(MB) void match_kernel(const float* __restrict__ tre
   }
 }
 
+// ---- pruned variant ---------------------------------------------------------------
+// For large sets the same exact scan runs over a pruned candidate set: both
+// sets are counting-sorted into 1024 buckets along the appearance dimension
+// with the largest spread, and a workgroup of (bucket-sorted) queries scans only
+// the tree buckets within +-W of its own bucket range, W = ceil(R*scale)+1,
+// R = 1.001*radius.  A tree point outside that window differs from every query
+// of the workgroup by more than the radius in one coordinate, so that single
+// term of the (non-negative, monotonically accumulated) sum already reaches
+// radius^2 and the point can never pass the strict "d2 < best" test: pruning
+// changes no decision.  Inside the window the scan is the one above (4-term
+// bit-exact prefix, then the remaining terms in the reference's order).  Worst
+// case (no spread in any dimension) it degenerates to the full scan.
+constexpr int NBUCKET = 1024;
+
+struct BucketParams {
+  int dim;       // appearance component used for bucketing
+  float lo;      // minimum of that component over both sets
+  float scale;   // NBUCKET / (hi - lo), 0 when hi == lo
+  int W;         // half window in buckets
+};
+
+__device__ __forceinline__ int bucket_of(float x, const BucketParams& bp) {
+  float v = (x - bp.lo) * bp.scale;                      // monotone non-decreasing in x
+  v = fminf(fmaxf(v, 0.f), (float)(NBUCKET - 1));        // NaN -> 0, +-inf clamp
+  return (int)v;
+}
+
+// one workgroup: per-component min/max over both sets, choice of the dimension
+__global__ __launch_bounds__(1024) void match_minmax_kernel(const float* __restrict__ a, int na,
+                                                            const float* __restrict__ b, int nb,
+                                                            float radius, BucketParams* out) {
+  __shared__ float s_lo[16][10], s_hi[16][10];
+  float lo[10], hi[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+  for (int i = threadIdx.x; i < na + nb; i += 1024) {
+    const float* p = i < na ? a + 10 * (size_t)i : b + 10 * (size_t)(i - na);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { const float v = p[k]; lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v); }
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k)
+    for (int d = 32; d >= 1; d >>= 1) {
+      lo[k] = fminf(lo[k], __shfl_xor(lo[k], d));
+      hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], d));
+    }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int best = 0;
+    float best_span = -1.f, blo = 0.f;
+    for (int k = 0; k < 10; ++k) {
+      float l = INFINITY, h = -INFINITY;
+      for (int w = 0; w < 16; ++w) { l = fminf(l, s_lo[w][k]); h = fmaxf(h, s_hi[w][k]); }
+      const float span = h - l;
+      if (span > best_span && span < INFINITY) { best_span = span; best = k; blo = l; }
+    }
+    BucketParams bp;
+    bp.dim = best;
+    bp.lo = blo;
+    bp.scale = best_span > 0.f ? (float)NBUCKET / best_span : 0.f;
+    const float w = ceilf(radius * 1.001f * bp.scale) + 1.f;
+    bp.W = w < (float)NBUCKET ? (int)w : NBUCKET;
+    *out = bp;
+  }
+}
+
+// counts[0..NB) tree, counts[NB..2NB) queries
+__global__ __launch_bounds__(256) void match_bucket_count_kernel(const float* __restrict__ tree, int nt,
+                                                                 const float* __restrict__ qry, int nq,
+                                                                 const BucketParams* __restrict__ bpp, int* counts) {
+  const BucketParams bp = *bpp;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nt + nq; i += gridDim.x * blockDim.x) {
+    const bool is_t = i < nt;
+    const float x = is_t ? tree[10 * (size_t)i + bp.dim] : qry[10 * (size_t)(i - nt) + bp.dim];
+    atomicAdd(&counts[(is_t ? 0 : NBUCKET) + bucket_of(x, bp)], 1);
+  }
+}
+
+// two workgroups: exclusive scan of each half; starts has 2*(NB+1) entries, cursor 2*NB
+__global__ __launch_bounds__(NBUCKET) void match_bucket_scan_kernel(const int* __restrict__ counts, int* starts,
+                                                                    int* cursor) {
+  __shared__ int s_w[NBUCKET / 64];
+  const int half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int v = counts[half * NBUCKET + tid];
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NBUCKET / 64; ++w) { const int c = s_w[w]; if (w < wave) woff += c; tot += c; }
+  const int excl = woff + incl - v;
+  starts[half * (NBUCKET + 1) + tid] = excl;
+  cursor[half * NBUCKET + tid] = excl;
+  if (tid == 0) starts[half * (NBUCKET + 1) + NBUCKET] = tot;
+}
+
+// 12-float records: 10 appearance components, original index (int bits), bucket (int bits)
+__global__ __launch_bounds__(256) void match_bucket_scatter_kernel(const float* __restrict__ tree, int nt,
+                                                                   const float* __restrict__ qry, int nq,
+                                                                   const BucketParams* __restrict__ bpp, int* cursor,
+                                                                   float* tree_rec, float* qry_rec,
+                                                                   unsigned long long* best, float r2) {
+  const BucketParams bp = *bpp;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nt + nq; i += gridDim.x * blockDim.x) {
+    const bool is_t = i < nt;
+    const int idx = is_t ? i : i - nt;
+    const float2* src = reinterpret_cast<const float2*>((is_t ? tree : qry) + 10 * (size_t)idx);
+    float2 v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = src[k];
+    const float x = (bp.dim & 1) ? v[bp.dim >> 1].y : v[bp.dim >> 1].x;
+    const int b = bucket_of(x, bp);
+    const int pos = atomicAdd(&cursor[(is_t ? 0 : NBUCKET) + b], 1);
+    float4* dst = reinterpret_cast<float4*>((is_t ? tree_rec : qry_rec) + 12 * (size_t)pos);
+    dst[0] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+    dst[1] = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+    dst[2] = make_float4(v[4].x, v[4].y, __int_as_float(idx), __int_as_float(b));
+    if (!is_t) best[idx] = ((unsigned long long)__float_as_uint(r2) << 32) | 0xffffffffull;
+  }
+}
+
+__global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restrict__ tree_rec, int nt,
+                                                          const float* __restrict__ qry_rec, int nq,
+                                                          const int* __restrict__ starts,
+                                                          const BucketParams* __restrict__ bpp, int nchunks, float r2,
+                                                          unsigned long long* __restrict__ best) {
+  __shared__ __attribute__((aligned(16))) float s_t[TILE * TP];
+  const int tid = threadIdx.x;
+  const int qbase = blockIdx.x * MB * QPT;
+  const int q0 = qbase + tid * QPT;
+  float q[QPT][10];
+  float bd[QPT];
+  int bi[QPT], qorig[QPT];
+#pragma unroll
+  for (int j = 0; j < QPT; ++j) {
+    const int qi = q0 + j < nq ? q0 + j : nq - 1;          // clamp: result discarded
+    const float4* src = reinterpret_cast<const float4*>(qry_rec + 12 * (size_t)qi);
+    const float4 a = src[0], b = src[1], c = src[2];
+    q[j][0] = a.x; q[j][1] = a.y; q[j][2] = a.z; q[j][3] = a.w;
+    q[j][4] = b.x; q[j][5] = b.y; q[j][6] = b.z; q[j][7] = b.w;
+    q[j][8] = c.x; q[j][9] = c.y;
+    qorig[j] = __float_as_int(c.z);
+    bd[j] = r2;
+    bi[j] = -1;
+  }
+  // bucket range of this workgroup's queries (sorted by bucket) widened by W
+  const int W = bpp->W;
+  const int q_last = qbase + MB * QPT - 1 < nq ? qbase + MB * QPT - 1 : nq - 1;
+  int b_lo = __float_as_int(qry_rec[12 * (size_t)qbase + 11]) - W;
+  int b_hi = __float_as_int(qry_rec[12 * (size_t)q_last + 11]) + W;
+  b_lo = b_lo < 0 ? 0 : b_lo;
+  b_hi = b_hi > NBUCKET - 1 ? NBUCKET - 1 : b_hi;
+  const int r_begin = starts[b_lo], r_end = starts[b_hi + 1];
+  const int span = r_end - r_begin;
+  const int per = ((span + nchunks - 1) / nchunks + TILE - 1) / TILE * TILE;   // whole tiles per chunk
+  const int t_begin = r_begin + blockIdx.y * per;
+  const int t_end = t_begin + per < r_end ? t_begin + per : r_end;
+  for (int tb = t_begin; tb < t_end; tb += TILE) {
+    const int cnt = t_end - tb < TILE ? t_end - tb : TILE;
+    __syncthreads();
+    const float4* src = reinterpret_cast<const float4*>(tree_rec + 12 * (size_t)tb);
+    float4* dst = reinterpret_cast<float4*>(s_t);
+    for (int f = tid; f < cnt * 3; f += MB) dst[f] = src[f];
+    __syncthreads();
+#pragma unroll 4
+    for (int p = 0; p < cnt; ++p) {
+      const float4 ta = *reinterpret_cast<const float4*>(&s_t[p * TP]);
+      float pre[QPT];
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        const float d0 = ta.x - q[j][0], d1 = ta.y - q[j][1], d2 = ta.z - q[j][2], d3 = ta.w - q[j][3];
+        float s = d0 * d0;
+        s += d1 * d1;
+        s += d2 * d2;
+        s += d3 * d3;
+        pre[j] = s;
+        any = any || (s <= bd[j]);   // <=: an exact tie with a lower original index must still be seen
+      }
+      if (__builtin_expect(any, 0)) {
+        const float4 tb4 = *reinterpret_cast<const float4*>(&s_t[p * TP + 4]);
+        const float4 tc = *reinterpret_cast<const float4*>(&s_t[p * TP + 8]);
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+          float s = pre[j];
+          float d;
+          d = tb4.x - q[j][4]; s += d * d;
+          d = tb4.y - q[j][5]; s += d * d;
+          d = tb4.z - q[j][6]; s += d * d;
+          d = tb4.w - q[j][7]; s += d * d;
+          d = tc.x - q[j][8]; s += d * d;
+          d = tc.y - q[j][9]; s += d * d;
+          // ties: lowest ORIGINAL index (the sorted order is arbitrary inside a bucket)
+          const int ti = __float_as_int(tc.z);
+          if (s < bd[j] || (s == bd[j] && bi[j] >= 0 && ti < bi[j])) { bd[j] = s; bi[j] = ti; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < QPT; ++j) {
+    if (bi[j] >= 0 && q0 + j < nq) {
+      const unsigned long long key =
+          ((unsigned long long)__float_as_uint(bd[j]) << 32) | (unsigned long long)(unsigned)bi[j];
+      atomicMin(&best[qorig[j]], key);
+    }
+  }
+}
+
+size_t match_pruned_workspace_bytes(int nt, int nq) {
+  return sizeof(float) * 12 * ((size_t)nt + (size_t)nq) + sizeof(int) * (2 * NBUCKET + 2 * (NBUCKET + 1) + 2 * NBUCKET) +
+         sizeof(BucketParams) + 256;
+}
+
+static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt, const float* qry, int nq,
+                                      float radius, float r2, unsigned long long* d_best, void* ws, int n_cu) {
+  // workspace carve (all offsets multiples of 16 bytes)
+  char* p = static_cast<char*>(ws);
+  float* tree_rec = reinterpret_cast<float*>(p); p += sizeof(float) * 12 * (size_t)nt;
+  float* qry_rec = reinterpret_cast<float*>(p); p += sizeof(float) * 12 * (size_t)nq;
+  int* counts = reinterpret_cast<int*>(p); p += sizeof(int) * 2 * NBUCKET;
+  int* cursor = reinterpret_cast<int*>(p); p += sizeof(int) * 2 * NBUCKET;
+  int* starts = reinterpret_cast<int*>(p); p += sizeof(int) * (2 * (NBUCKET + 1) + 2);
+  BucketParams* bp = reinterpret_cast<BucketParams*>(p);
+  hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * 2 * NBUCKET, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(match_minmax_kernel, dim3(1), dim3(1024), 0, st, tree, nt, qry, nq, radius, bp);
+  int g = (nt + nq + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(match_bucket_count_kernel, dim3(g), dim3(256), 0, st, tree, nt, qry, nq, bp, counts);
+  hipLaunchKernelGGL(match_bucket_scan_kernel, dim3(2), dim3(NBUCKET), 0, st, counts, starts, cursor);
+  hipLaunchKernelGGL(match_bucket_scatter_kernel, dim3(g), dim3(256), 0, st, tree, nt, qry, nq, bp, cursor, tree_rec,
+                     qry_rec, d_best, r2);
+  const int qblocks = (nq + MB * QPT - 1) / (MB * QPT);
+  int nchunks = (6 * (n_cu > 0 ? n_cu : 256) + qblocks - 1) / qblocks;
+  if (nchunks < 1) nchunks = 1;
+  if (nchunks > 64) nchunks = 64;
+  hipLaunchKernelGGL(match_pruned_kernel, dim3(qblocks, nchunks), dim3(MB), 0, st, tree_rec, nt, qry_rec, nq, starts,
+                     bp, nchunks, r2, d_best);
+  return hipGetLastError();
+}
+
 hipError_t launch_match(hipStream_t st, const float* d_a1, int n1, const float* d_a2, int n2,
                         float radius, int32_t* d_out_pairs, int* d_n_out,
-                        unsigned long long* d_best, int* d_scratch, int n_cu) {
+                        unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws) {
   const int tree_is_1 = n1 >= n2;                 // vo_complete.cpp:15-20 (ties: a1 is the tree)
   const float* tree = tree_is_1 ? d_a1 : d_a2;
   const float* qry = tree_is_1 ? d_a2 : d_a1;
   const int nt = tree_is_1 ? n1 : n2, nq = tree_is_1 ? n2 : n1;
   const float r2 = radius * radius;
-  if (nq > 0) {
+  if (nq > 0 && nt > 0 && d_prune_ws) {
+    hipError_t ep = launch_match_pruned(st, tree, nt, qry, nq, radius, r2, d_best, d_prune_ws, n_cu);
+    if (ep != hipSuccess) return ep;
+  } else if (nq > 0) {
     hipLaunchKernelGGL(match_init_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, d_best, nq, r2);
     if (nt > 0) {
       const int qblocks = (nq + MB * QPT - 1) / (MB * QPT);

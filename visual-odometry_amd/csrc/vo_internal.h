@@ -97,8 +97,11 @@ hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const in
                        int32_t* d_out, int* d_n_out, int* d_table /* n_ref ints */,
                        int* d_scratch);
 
+// d_prune_ws: null -> full scan; else match_pruned_workspace_bytes(nt, nq) bytes -> bucket-pruned scan
+size_t match_pruned_workspace_bytes(int nt, int nq);
 hipError_t launch_match(hipStream_t st, const float* d_a1, int n1, const float* d_a2, int n2,
                         float radius, int32_t* d_out_pairs, int* d_n_out,
-                        unsigned long long* d_best /* min(n1,n2) u64 */, int* d_scratch, int n_cu);
+                        unsigned long long* d_best /* min(n1,n2) u64 */, int* d_scratch, int n_cu,
+                        void* d_prune_ws);
 
 }  // namespace vo
