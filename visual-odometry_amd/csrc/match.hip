@@ -142,18 +142,31 @@ __device__ __forceinline__ int bucket_of(float x, const BucketParams& bp) {
   return (int)v;
 }
 
-// one workgroup: per-component min/max over both sets, choice of the dimension
-__global__ __launch_bounds__(1024) void match_minmax_kernel(const float* __restrict__ a, int na,
-                                                            const float* __restrict__ b, int nb,
-                                                            float radius, BucketParams* out) {
-  __shared__ float s_lo[16][10], s_hi[16][10];
+// per-component min/max over both sets: workgroup partials merged with atomic
+// min/max on an order-preserving integer image of the floats (NaNs are skipped)
+__device__ __forceinline__ unsigned f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// mm[0..9] = min (init 0xffffffff), mm[10..19] = max (init 0)
+__global__ __launch_bounds__(256) void match_minmax_kernel(const float* __restrict__ a, int na,
+                                                           const float* __restrict__ b, int nb, unsigned* mm) {
+  __shared__ float s_lo[4][10], s_hi[4][10];
   float lo[10], hi[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
-  for (int i = threadIdx.x; i < na + nb; i += 1024) {
-    const float* p = i < na ? a + 10 * (size_t)i : b + 10 * (size_t)(i - na);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < na + nb; i += gridDim.x * 256) {
+    const float2* p = reinterpret_cast<const float2*>(i < na ? a + 10 * (size_t)i : b + 10 * (size_t)(i - na));
 #pragma unroll
-    for (int k = 0; k < 10; ++k) { const float v = p[k]; lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v); }
+    for (int k = 0; k < 5; ++k) {
+      const float2 v = p[k];
+      lo[2 * k] = fminf(lo[2 * k], v.x); hi[2 * k] = fmaxf(hi[2 * k], v.x);          // fmin/fmax drop NaNs
+      lo[2 * k + 1] = fminf(lo[2 * k + 1], v.y); hi[2 * k + 1] = fmaxf(hi[2 * k + 1], v.y);
+    }
   }
 #pragma unroll
   for (int k = 0; k < 10; ++k)
@@ -166,23 +179,32 @@ __global__ __launch_bounds__(1024) void match_minmax_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < 10; ++k) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int best = 0;
-    float best_span = -1.f, blo = 0.f;
-    for (int k = 0; k < 10; ++k) {
-      float l = INFINITY, h = -INFINITY;
-      for (int w = 0; w < 16; ++w) { l = fminf(l, s_lo[w][k]); h = fmaxf(h, s_hi[w][k]); }
-      const float span = h - l;
-      if (span > best_span && span < INFINITY) { best_span = span; best = k; blo = l; }
-    }
-    BucketParams bp;
-    bp.dim = best;
-    bp.lo = blo;
-    bp.scale = best_span > 0.f ? (float)NBUCKET / best_span : 0.f;
-    const float w = ceilf(radius * 1.001f * bp.scale) + 1.f;
-    bp.W = w < (float)NBUCKET ? (int)w : NBUCKET;
-    *out = bp;
+  if (threadIdx.x < 10) {
+    const int k = threadIdx.x;
+    float l = INFINITY, h = -INFINITY;
+    for (int w = 0; w < 4; ++w) { l = fminf(l, s_lo[w][k]); h = fmaxf(h, s_hi[w][k]); }
+    atomicMin(&mm[k], f2ord(l));
+    atomicMax(&mm[10 + k], f2ord(h));
   }
+}
+
+// choice of the bucketing dimension (largest finite spread) and of the window
+__global__ void match_params_kernel(const unsigned* __restrict__ mm, float radius, BucketParams* out) {
+  if (threadIdx.x != 0) return;
+  int best = 0;
+  float best_span = -1.f, blo = 0.f;
+  for (int k = 0; k < 10; ++k) {
+    const float l = ord2f(mm[k]), h = ord2f(mm[10 + k]);
+    const float span = h - l;
+    if (span > best_span && span < INFINITY) { best_span = span; best = k; blo = l; }
+  }
+  BucketParams bp;
+  bp.dim = best;
+  bp.lo = blo;
+  bp.scale = best_span > 0.f ? (float)NBUCKET / best_span : 0.f;
+  const float w = ceilf(radius * 1.001f * bp.scale) + 1.f;
+  bp.W = w < (float)NBUCKET ? (int)w : NBUCKET;
+  *out = bp;
 }
 
 // counts[0..NB) tree, counts[NB..2NB) queries
@@ -332,7 +354,7 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
 
 size_t match_pruned_workspace_bytes(int nt, int nq) {
   return sizeof(float) * 12 * ((size_t)nt + (size_t)nq) + sizeof(int) * (2 * NBUCKET + 2 * (NBUCKET + 1) + 2 * NBUCKET) +
-         sizeof(BucketParams) + 256;
+         sizeof(BucketParams) + 20 * sizeof(unsigned) + 512;
 }
 
 static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt, const float* qry, int nq,
@@ -344,12 +366,16 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
   int* counts = reinterpret_cast<int*>(p); p += sizeof(int) * 2 * NBUCKET;
   int* cursor = reinterpret_cast<int*>(p); p += sizeof(int) * 2 * NBUCKET;
   int* starts = reinterpret_cast<int*>(p); p += sizeof(int) * (2 * (NBUCKET + 1) + 2);
-  BucketParams* bp = reinterpret_cast<BucketParams*>(p);
+  BucketParams* bp = reinterpret_cast<BucketParams*>(p); p += 64;
+  unsigned* mm = reinterpret_cast<unsigned*>(p);
   hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * 2 * NBUCKET, st);
+  if (e == hipSuccess) e = hipMemsetAsync(mm, 0xff, 10 * sizeof(unsigned), st);
+  if (e == hipSuccess) e = hipMemsetAsync(mm + 10, 0x00, 10 * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(match_minmax_kernel, dim3(1), dim3(1024), 0, st, tree, nt, qry, nq, radius, bp);
   int g = (nt + nq + 255) / 256;
   if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(match_minmax_kernel, dim3(g > 256 ? 256 : g), dim3(256), 0, st, tree, nt, qry, nq, mm);
+  hipLaunchKernelGGL(match_params_kernel, dim3(1), dim3(64), 0, st, mm, radius, bp);
   hipLaunchKernelGGL(match_bucket_count_kernel, dim3(g), dim3(256), 0, st, tree, nt, qry, nq, bp, counts);
   hipLaunchKernelGGL(match_bucket_scan_kernel, dim3(2), dim3(NBUCKET), 0, st, counts, starts, cursor);
   hipLaunchKernelGGL(match_bucket_scatter_kernel, dim3(g), dim3(256), 0, st, tree, nt, qry, nq, bp, cursor, tree_rec,
