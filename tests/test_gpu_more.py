@@ -1,0 +1,124 @@
+"""Further GPU parity cases: general (non-pinhole) K, many correspondences per
+thread (grid-stride path), a solver reused across sizes, keep_outliers in the
+batched solver, empty problems in a batch, the device-resident frame pipeline."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle.oracle import Camera as OCam
+
+pytestmark = pytest.mark.gpu
+
+
+def _corr(fp):
+    mp = np.full(len(fp["ref_app"]), -1, np.int64)
+    mp[fp["model_pairs"][:, 0]] = fp["model_pairs"][:, 1]
+    gt = fp["gt_matches"]
+    ok = mp[gt[:, 0]] >= 0
+    return np.stack([gt[ok, 1], mp[gt[ok, 0]]], axis=1).astype(np.int32)
+
+
+def test_general_camera_matrix(vo, ctx, o32, o64):
+    """K with skew and a non-unit K22: the general 3x3 instantiation (not the pinhole one)."""
+    fp = vo.synth.frame_pair(3000, seed=301, drop=0.05, distractors=5, model_drop=0.05)
+    K = fp["K"].copy()
+    K[0, 1] = 0.7            # skew
+    K[2, 2] = 1.0009765625   # exactly representable, != 1
+    corr = _corr(fp)
+    for thr, keep in ((10000.0, False), (40.0, True)):
+        cam = vo.Camera(480, 640, 0, 10, K, np.eye(4), ctx=ctx)
+        s = vo.PICPSolver(ctx); s.setKernelThreshold(thr)
+        s.init(cam, fp["model"], fp["cur_pts"])
+        s.oneRound(corr, keep)
+        H, b = s.system()
+        ocam = OCam(480, 640, 0, 10, K, np.eye(4))
+        r64 = o64.picp_solve(ocam, fp["model"], fp["cur_pts"], corr, 6, thr, keep)
+        r32 = o32.picp_solve(ocam, fp["model"], fp["cur_pts"], corr, 6, thr, keep)
+        assert rel_err(H - np.eye(6, dtype=np.float32), r64["H"][0]) < 1e-5 and rel_err(b, r64["b"][0]) < 1e-5
+        assert s.numInliers() == int(r32["stats"][0, 2])
+        s.solve(corr, keep, 5)
+        assert np.abs(s.camera().worldInCameraPose() - r32["T"]).max() < 1e-4
+        assert s.numInliers() == r32["num_inliers"]
+        s.close()
+
+
+def test_many_correspondences_per_thread_and_reuse(vo, ctx, o32):
+    """300k correspondences: the grid is capped at 4 workgroups per CU, threads loop; then the same
+    solver handle is reused for a much smaller problem (partial buffers must be re-zeroed)."""
+    fp = vo.synth.frame_pair(20000, seed=302)
+    base = _corr(fp)
+    big = np.concatenate([base] * 15)                     # repeats are legal: 300k terms
+    cam = vo.Camera(480, 640, 0, 10, fp["K"], np.eye(4), ctx=ctx)
+    s = vo.PICPSolver(ctx); s.setKernelThreshold(10000.0)
+    s.init(cam, fp["model"], fp["cur_pts"])
+    s.solve(big, False, 3)
+    ocam = OCam(480, 640, 0, 10, fp["K"], np.eye(4))
+    r = o32.picp_solve(ocam, fp["model"], fp["cur_pts"], big, 3, 10000.0, False, trace=False)
+    assert s.numInliers() == r["num_inliers"] == len(big)
+    assert np.abs(s.camera().worldInCameraPose() - r["T"]).max() < 1e-4
+    small = base[:300]
+    cam2 = vo.Camera(480, 640, 0, 10, fp["K"], np.eye(4), ctx=ctx)
+    s.init(cam2, fp["model"], fp["cur_pts"])
+    s.solve(small, False, 4)
+    r2 = o32.picp_solve(ocam, fp["model"], fp["cur_pts"], small, 4, 10000.0, False, trace=False)
+    assert s.numInliers() == r2["num_inliers"] == 300
+    assert np.abs(s.camera().worldInCameraPose() - r2["T"]).max() < 1e-4
+    s.close()
+
+
+def test_batched_keep_outliers_and_empty_problems(vo, ctx, o32):
+    P, n, iters, thr = 4, 2000, 6, 40.0
+    fps = [vo.synth.frame_pair(n, seed=5000 + p) for p in range(P)]
+    pairs = [_corr(f) for f in fps]
+    pairs[2] = pairs[2][:0]                               # an empty problem: pose must stay at T0
+    lib = ctx.lib
+    world = np.stack([f["model"] for f in fps]); meas = np.stack([f["cur_pts"] for f in fps])
+    pbuf = np.zeros((P, n, 2), np.int32)
+    for i, p in enumerate(pairs):
+        pbuf[i, : len(p)] = p
+    npairs = np.array([len(p) for p in pairs], np.int32)
+    rng = np.random.default_rng(1)
+    T0 = np.stack([vo.synth.random_isometry(rng, 0.01, 0.02) for _ in range(P)])
+    T0_cm = np.ascontiguousarray(np.transpose(T0, (0, 2, 1))).reshape(P, 16)
+    d = [ctx.to_device(a) for a in (world, meas, pbuf, npairs, T0_cm)]
+    d_T = ctx.alloc(P * 64); d_stats = ctx.alloc(P * 16)
+    K = np.ascontiguousarray(fps[0]["K"].T).ravel()
+    rc = lib.vo_picp_solve_batch_dev(ctx.h, P, 480, 640, 0, 10, K.ctypes.data_as(C.c_void_p), C.c_float(thr), 1,
+                                     C.c_void_p(d[0]), C.c_size_t(n), C.c_void_p(d[1]), C.c_size_t(n),
+                                     C.c_void_p(d[2]), C.c_size_t(n), C.c_void_p(d[3]), C.c_void_p(d[4]), iters,
+                                     C.c_void_p(d_T), C.c_void_p(d_stats))
+    assert rc == 0, lib.vo_last_error()
+    T = np.zeros((P, 16), np.float32); st = np.zeros((P, 4), np.float32)
+    ctx.d2h(T, d_T); ctx.d2h(st, d_stats)
+    for p in range(P):
+        Tp = T[p].reshape(4, 4).T
+        r = o32.picp_solve(OCam(480, 640, 0, 10, fps[p]["K"], T0[p]), fps[p]["model"], fps[p]["cur_pts"], pairs[p],
+                           iters, thr, True, trace=False)
+        assert np.abs(Tp - r["T"]).max() < 1e-4
+        assert int(st[p, 2]) == r["num_inliers"]
+        assert abs(st[p, 1] - r["chi_outliers"]) <= 1e-4 * max(1.0, r["chi_outliers"])
+    assert np.array_equal(T[2].reshape(4, 4).T, T0[2])    # H = I, b = 0: dx = 0 exactly
+    for x in d + [d_T, d_stats]:
+        ctx.free(x)
+
+
+def test_frame_pipeline_device_resident(vo, ctx, o32):
+    """FramePipeline (every stage through the *_dev entry points, counts in device memory)."""
+    fp = vo.synth.frame_pair(4000, seed=303, drop=0.1, distractors=50, model_drop=0.1)
+    pipe = vo.FramePipeline(ctx, fp, n_iters=10, kernel_threshold=10000.0)
+    for _ in range(2):                                    # run twice: state must not leak between frames
+        pipe.frame()
+    m, j = pipe.fetch("match"), pipe.fetch("join")
+    m_o = o32.match(fp["ref_app"], fp["cur_app"]); j_o = o32.join(m_o, fp["model_pairs"])
+    assert np.array_equal(m, m_o) and np.array_equal(j, j_o)
+    r = o32.picp_solve(OCam(480, 640, 0, 10, fp["K"], np.eye(4)), fp["model"], fp["cur_pts"], j_o, 10, 10000.0, False,
+                       trace=False)
+    T = pipe.pose()
+    assert np.abs(T - r["T"]).max() < 1e-4 and pipe.stats()[2] == r["num_inliers"]
+    xyz, pairs, app = pipe.fetch("tri_xyz"), pipe.fetch("tri_pairs"), pipe.fetch("tri_app")
+    xo, po, ao = o32.triangulate(fp["K"], T, m_o, fp["ref_pts"], fp["cur_pts"], fp["cur_app"])
+    assert np.array_equal(pairs, po) and np.array_equal(app, ao)
+    assert np.all(np.abs(xyz - xo) <= 1e-4 * np.maximum(1, np.abs(xo)))
+    pipe.close()
