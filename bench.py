@@ -137,8 +137,10 @@ def main():
                    "points": args.points, "iters_per_step": args.iters, "parallelism": f"pairs x{world}",
                    "device": dev_name, "compute_units": n_cu},
         "pose_err_vs_gt": pose_err, "num_inliers": n_in,
-        "roofline": {"bound": "hbm", "kernel": "picp_round_kernel<true,false>", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": "picp_round_kernel<true,false,true,false>", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": _pmc_traffic("vo::picp_round_kernel<true, false, true, false>")[0],
+                     "traffic_note": _pmc_traffic("vo::picp_round_kernel<true, false, true, false>")[1],
                      "algorithmic_bytes_per_launch": alg_bytes, "launch_us": per_round_us,
                      "note": "one launch = one Gauss-Newton round over one 50k pair (1.0 MB, L2-resident): "
                              "latency-bound by the serial solve->linearize dependency, not by HBM; launch_us is "
@@ -161,6 +163,22 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch from the committed PMC summary (profiles/r01_pmc_fetch_write_v2.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very script).  Returns
+    (bytes, note) or (None, reason)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_v2.json")
+    try:
+        k = json.load(open(path))["kernels"][kernel]
+        fetch_kb, write_kb = k["FETCH_SIZE_KB_mean"], k["WRITE_SIZE_KB_mean"]
+    except (OSError, KeyError, ValueError):
+        return None, "no committed PMC summary for this kernel"
+    wide = k.get("wide_16B_loads", False)
+    b = (2.0 * fetch_kb if wide else fetch_kb) * 1024.0 + write_kb * 1024.0
+    return b, ("FETCH_SIZE x2 (gfx950 counts half of 16-B/lane coalesced reads) + WRITE_SIZE" if wide else
+               "FETCH_SIZE + WRITE_SIZE as reported (4-B/lane loads: uncalibrated width)") + ", from " + os.path.basename(path)
 
 
 def _chk(lib, rc):
@@ -235,20 +253,24 @@ def batched_leg(torch, vo, ctx, stream, args):
     d_T = ctx.alloc(P * 64); d_stats = ctx.alloc(P * 16)
     K = np.ascontiguousarray(fps[0]["K"].T).ravel()
 
-    def run():
+    def run(n_it=iters):
         _chk(lib, lib.vo_picp_solve_batch_dev(ctx.h, P, 480, 640, 0, 10, K.ctypes.data_as(C.c_void_p),
                                               C.c_float(10000.0), 0, C.c_void_p(d_world), C.c_size_t(n),
                                               C.c_void_p(d_meas), C.c_size_t(n), C.c_void_p(d_pairs), C.c_size_t(n),
-                                              C.c_void_p(d_n), None, iters, C.c_void_p(d_T), C.c_void_p(d_stats)))
-    run(); ctx.synchronize()
-    reps = 5
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(reps):
-        run()
-    e1.record(stream)
-    ctx.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+                                              C.c_void_p(d_n), None, n_it, C.c_void_p(d_T), C.c_void_p(d_stats)))
+
+    def timed(n_it, reps):
+        run(n_it); ctx.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            run(n_it)
+        e1.record(stream)
+        ctx.synchronize()
+        return e0.elapsed_time(e1) / reps
+    pack_ms = timed(0, 5)          # gather pass + an iteration-less solver launch
+    ms = timed(iters, 5)           # gather pass + all rounds
+    kernel_ms = ms - pack_ms       # picp_batch_kernel alone (rocprofv3 average must agree)
     T = np.zeros((P, 16), np.float32); st = np.zeros((P, 4), np.float32)
     ctx.d2h(T, d_T); ctx.d2h(st, d_stats)
     err = max(float(np.abs(T[p].reshape(4, 4).T - fps[p % distinct]["X_gt"]).max()) for p in range(P))
@@ -257,14 +279,18 @@ def batched_leg(torch, vo, ctx, stream, args):
         ctx.free(d)
     # per call: one gather pass (8 B pair + 20 B point data read, 20 B written) + iters streaming passes of 20 B
     alg = P * n * BYTES_PER_CORR_ITER * iters
-    gbs = alg / (ms * 1e-3) / 1e9
-    return {"pairs": P, "ms_per_call": ms, "iters_per_sec": P * iters / (ms * 1e-3),
+    gbs = alg / (kernel_ms * 1e-3) / 1e9
+    return {"pairs": P, "ms_per_call": ms, "pack_ms": pack_ms, "kernel_ms": kernel_ms,
+            "iters_per_sec": P * iters / (ms * 1e-3),
             "pair_solves_per_sec": P / (ms * 1e-3), "pose_err_vs_gt": err,
-            "roofline": {"bound": "hbm", "kernel": "picp_batch_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "picp_batch_kernel<true,false>", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": _pmc_traffic("vo::picp_batch_kernel<true, false>")[0] if (P, n, iters) == (200, 50000, 50) else None,
+                         "traffic_note": _pmc_traffic("vo::picp_batch_kernel<true, false>")[1],
                          "algorithmic_bytes_per_launch": alg,
-                         "note": "ms_per_call also contains the pack kernel (one gather pass); "
-                                 f"{P} x {n} x 20 B x {iters} rounds of algorithmic bytes"}}
+                         "launch_us": kernel_ms * 1e3,
+                         "note": f"{P} x {n} x 20 B x {iters} rounds of algorithmic bytes over kernel_ms = ms_per_call - "
+                                 "pack_ms (the gather pass is a separate kernel); iters_per_sec uses the whole call"}}
 
 
 def cpu_leg(fp, pipe, args):
@@ -282,7 +308,16 @@ def cpu_leg(fp, pipe, args):
         t_used += time.perf_counter() - t0
         runs += 1
     gpu_T = pipe.pose()
-    return {"value": runs * args.iters / t_used, "unit": "iter/s", "cores": 1, "kind": "port",
+    # other stages of the frame on the host, bounded samples
+    m = pipe.fetch("match")
+    t0 = time.perf_counter(); o.triangulate(fp["K"], gpu_T, m, fp["ref_pts"], fp["cur_pts"]); t_tri = time.perf_counter() - t0
+    t0 = time.perf_counter(); o.join(m, fp["model_pairs"], linear=True); t_join = time.perf_counter() - t0
+    nq_s = min(200, len(fp["cur_app"]))
+    t0 = time.perf_counter(); o.match(fp["ref_app"], fp["cur_app"][:nq_s]); t_match = (time.perf_counter() - t0) * len(fp["cur_app"]) / nq_s
+    stages = {"triangulate_ms": t_tri * 1e3, "join_linear_ms": t_join * 1e3,
+              "match_bruteforce_ms_extrapolated": t_match * 1e3,
+              "match_sample": f"{nq_s} queries x {len(fp['ref_app'])} points, scaled to {len(fp['cur_app'])} queries"}
+    return {"value": runs * args.iters / t_used, "unit": "iter/s", "cores": 1, "kind": "port", "other_stages": stages,
             "sample": f"{runs} x {args.iters} rounds of the C float32 restatement (oracle/, gcc -O3 -ffp-contract=off) "
                       f"on the same {len(corr)}-correspondence pair; the reference itself needs Eigen3 (absent)",
             "pose_diff_gpu_vs_cpu": float(np.abs(gpu_T - r["T"]).max()),

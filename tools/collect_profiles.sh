@@ -1,0 +1,15 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel trace + separate PMC passes of bench.py.
+# Output: gpurun_out/prof_<tag>/{stats,FETCH_SIZE,WRITE_SIZE}/...
+set -e
+TAG=${1:-r01}
+R=$PWD
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 50 --warmup 5 --cpu-seconds 0 > $OUT/stats.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-seconds 0 --frame-steps 3 > $OUT/$C.log 2>&1
+done
+cd $R
+echo done; ls $OUT
