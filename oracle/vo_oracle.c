@@ -9,7 +9,7 @@
  *
  * PARITY UNPINNED (kernel level): see vo_oracle_impl.h.  The only numbers the
  * reference publishes for this path are the end-to-end README metrics on
- * example_data (README.md:74-79).
+ * example_data (README.md:74-79); oracle/vo_pipeline.py reproduces them.
  *
  * Build: make -C oracle   (gcc -O3 -ffp-contract=off, no -march: mirrors the
  * reference's "-O3 -DNDEBUG" x86-64 baseline build, CMakeLists.txt:6-7)

@@ -9,6 +9,9 @@
  * PARITY UNPINNED at kernel level: the reference (lucanunz/Visual-odometry)
  * ships no golden vectors / assertions for this path and cannot be compiled
  * here (needs Eigen3, un-vendored, version unpinned, absent from the image).
+ * Pinned END TO END only: the oracle-side run of the whole vo_complete +
+ * evaluation loop (oracle/vo_pipeline.py) reproduces the README metrics on
+ * example_data (README.md:74-79; 1/r_t to 5 digits) -- tests/test_vo_complete_cpu.py.
  * This file restates the reference's algorithm, sequential float arithmetic,
  * one correspondence after the other, each function citing the file:line it
  * follows under /root/reference.  Where the arithmetic lives inside Eigen
