@@ -314,7 +314,12 @@ def cpu_leg(fp, pipe, args):
     t0 = time.perf_counter(); o.join(m, fp["model_pairs"], linear=True); t_join = time.perf_counter() - t0
     nq_s = min(200, len(fp["cur_app"]))
     t0 = time.perf_counter(); o.match(fp["ref_app"], fp["cur_app"][:nq_s]); t_match = (time.perf_counter() - t0) * len(fp["cur_app"]) / nq_s
-    stages = {"triangulate_ms": t_tri * 1e3, "join_linear_ms": t_join * 1e3,
+    mk, t_build, t_query = o.match_kdtree(fp["ref_app"], fp["cur_app"], timing=True)
+    assert np.array_equal(mk, m), "reference kd-tree matcher disagrees with the GPU matcher"
+    stages = {"match_kdtree_ms": (t_build + t_query) * 1e3, "match_kdtree_build_ms": t_build * 1e3,
+              "match_kdtree_note": "the reference's own matcher (PCA kd-tree, leaf 10, bestMatchFull) restated in "
+                                   "oracle/vo_kdtree.c; same pairs as the GPU matcher",
+              "triangulate_ms": t_tri * 1e3, "join_linear_ms": t_join * 1e3,
               "match_bruteforce_ms_extrapolated": t_match * 1e3,
               "match_sample": f"{nq_s} queries x {len(fp['ref_app'])} points, scaled to {len(fp['cur_app'])} queries"}
     return {"value": runs * args.iters / t_used, "unit": "iter/s", "cores": 1, "kind": "port", "other_stages": stages,

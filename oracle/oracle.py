@@ -27,7 +27,7 @@ _LIB = None
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libvo_oracle.so")
-    src = [os.path.join(_HERE, f) for f in ("vo_oracle.c", "vo_oracle_impl.h")]
+    src = [os.path.join(_HERE, f) for f in ("vo_oracle.c", "vo_oracle_impl.h", "vo_kdtree.c")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -195,6 +195,19 @@ class Oracle:
         f.restype = C.c_int
         n = f(self._p(x), C.c_int(len(x)), self._p(y), C.c_int(len(y)), self.real(radius), self._p(out))
         return out[:n].copy()
+
+    def match_kdtree(self, a1, a2, radius=0.1, max_leaf=10, timing=False):
+        """The reference's own matcher: PCA kd-tree + bestMatchFull (float32 only)."""
+        x = np.ascontiguousarray(a1, dtype=np.float32).reshape(-1, 10)
+        y = np.ascontiguousarray(a2, dtype=np.float32).reshape(-1, 10)
+        out = np.zeros((max(min(len(x), len(y)), 1), 2), dtype=np.int32)
+        tb, tq = C.c_double(), C.c_double()
+        f = self.L.vo32_match_kdtree
+        f.restype = C.c_int
+        n = f(self._p(x), C.c_int(len(x)), self._p(y), C.c_int(len(y)), C.c_float(radius), C.c_int(max_leaf),
+              self._p(out), C.byref(tb), C.byref(tq))
+        res = out[:n].copy()
+        return (res, tb.value, tq.value) if timing else res
 
     def join(self, img_pairs, world_pairs, linear=False):
         a = self._pairs(img_pairs)

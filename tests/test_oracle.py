@@ -61,6 +61,22 @@ def test_matcher_equals_ground_truth_and_numpy(o32, vo):
     assert any(a > b for a, b in sizes) or any(a < b for a, b in sizes)
 
 
+def test_reference_kdtree_equals_exact_search(o32, vo):
+    """The reference's PCA kd-tree + bestMatchFull (restated in oracle/vo_kdtree.c) returns exactly the
+    nearest neighbour within the radius, i.e. the definition the oracle and the kernels implement."""
+    for n, seed, kw in ((60, 1, dict(drop=0.2, distractors=5)), (900, 2, dict(drop=0.1, distractors=60)),
+                        (5000, 3, dict(drop=0.05, distractors=300))):
+        fp = vo.synth.frame_pair(n, seed=seed, **kw)
+        for a, b in ((fp["ref_app"], fp["cur_app"]), (fp["cur_app"], fp["ref_app"])):
+            assert np.array_equal(o32.match_kdtree(a, b), o32.match(a, b))
+    rng = np.random.default_rng(4)                      # noisy near-duplicates: several candidates inside the radius
+    base = rng.uniform(-1, 1, (400, 10)).astype(np.float32)
+    tree = np.concatenate([base + rng.normal(0, 0.01, base.shape).astype(np.float32) for _ in range(4)])
+    assert np.array_equal(o32.match_kdtree(tree, base), o32.match(tree, base))
+    same = np.zeros((50, 10), np.float32)               # would recurse forever in the reference (SURVEY A18)
+    assert len(o32.match_kdtree(same, same[:3])) == 3
+
+
 def test_matcher_radius_strict_and_ties(o32):
     base = np.zeros((3, 10), dtype=np.float32)
     base[1, 0] = 5.0
