@@ -16,7 +16,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvo_hip.so")
+# VO_HIP_LIB selects another build of the same library (e.g. the stamped diagnostic build)
+LIB_PATH = os.environ.get("VO_HIP_LIB") or os.path.join(_HERE, "libvo_hip.so")
 
 VO_OK = 0
 

@@ -560,6 +560,17 @@ int vo_picp_get_stats(vo_picp* s, float* chi_in, float* chi_out, int* n_in) {
   return r;
 }
 
+#ifdef VO_STAMPS
+// diagnostic build only: copies the s_memtime stamps of the last solve (128 rounds x 8 stamps)
+int vo_debug_get_stamps(vo_picp* s, unsigned long long* out) {
+  PicpState h;
+  VO_HIP_CHECK(hipMemcpyAsync(&h, s->d_state, sizeof(PicpState), hipMemcpyDeviceToHost, s->ctx->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));
+  memcpy(out, h.stamps, sizeof(h.stamps));
+  return VO_OK;
+}
+#endif
+
 int vo_picp_get_system(vo_picp* s, float H[36], float b[6]) {
   VO_REQUIRE(s, "null argument");
   if (int r = set_device(s->ctx)) return r;

@@ -64,6 +64,43 @@ __device__ __forceinline__ float block_reduce_acc(float acc[NACC], float* s_red)
   return out;
 }
 
+// Workgroup reduction of the round kernel (256 threads) through LDS only: on
+// the critical path (one wave per SIMD, ~5 cycles per issued instruction) the
+// instruction count matters more than LDS bandwidth.  Every thread stores its
+// 30 accumulators as eight 16-B writes (row stride 36 floats: conflict-free),
+// thread (slot = tid%32, part = tid/32) adds up the 32 rows of its part
+// (conflict-free 4-B reads), a second 8-row stage finishes: ~90 instructions
+// instead of ~180 for DPP + LDS.   s_acc: 256*36 floats, s_part: 8*32 floats.
+// Returns the sum of slot tid in threads 0..31 (fixed order).
+constexpr int ACC_STRIDE = 36;
+__device__ __forceinline__ float block_reduce_lds256(const float acc[NACC], float* s_acc, float* s_part) {
+  const int tid = threadIdx.x;
+  float4* row = reinterpret_cast<float4*>(s_acc + tid * ACC_STRIDE);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    float4 v;
+    v.x = acc[4 * q + 0];
+    v.y = acc[4 * q + 1];
+    v.z = (4 * q + 2 < NACC) ? acc[(4 * q + 2) < NACC ? 4 * q + 2 : 0] : 0.f;
+    v.w = (4 * q + 3 < NACC) ? acc[(4 * q + 3) < NACC ? 4 * q + 3 : 0] : 0.f;
+    row[q] = v;
+  }
+  __syncthreads();
+  const int slot = tid & 31, part = tid >> 5;
+  const float* src = s_acc + (part * 32) * ACC_STRIDE + slot;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) s += src[j * ACC_STRIDE];
+  s_part[part * 32 + slot] = s;
+  __syncthreads();
+  float out = 0.f;
+  if (tid < 32) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) out += s_part[g * 32 + tid];
+  }
+  return out;
+}
+
 __device__ __forceinline__ Pose load_pose12(const float* p) {
   Pose P;
 #pragma unroll
@@ -158,6 +195,19 @@ __global__ __launch_bounds__(256) void picp_pack_kernel(const int32_t* __restric
   }
 }
 
+#ifdef VO_STAMPS
+#define VO_STAMP(k)                                                                       \
+  do {                                                                                    \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && it < 128) {                                \
+      unsigned long long _t;                                                              \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");         \
+      S->stamps[it][k] = _t;                                                              \
+    }                                                                                     \
+  } while (0)
+#else
+#define VO_STAMP(k) do {} while (0)
+#endif
+
 // ---- one Gauss-Newton round ---------------------------------------------------
 // PRE:    first derive this round's pose from the partials of launch it-1.
 // FINISH: only derive the pose (single workgroup), publish the statistics.
@@ -165,14 +215,35 @@ template <bool PRE, bool FINISH, bool PINHOLE, bool KEEP>
 __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams* __restrict__ P,
                                                                 PicpState* S, PackedCorr pk,
                                                                 float* partials, int it, int nb) {
-  __shared__ float s_red[16 * 32];
-  __shared__ float s_tot[32];
-  __shared__ float s_sys[48];
-  __shared__ float s_pose[12];
+  __shared__ __attribute__((aligned(16))) float s_acc[PICP_BLOCK * ACC_STRIDE];   // also the staging of the partial rows
+  __shared__ float s_part[8 * 32];
+  __shared__ float s_sys[PICP_BLOCK / 64][48];
+  __shared__ float s_stat[4];
   const int tid = threadIdx.x;
-  const int n = P->n_corr;
+  VO_STAMP(0);
 
-  // issue the first correspondence's loads before the (latency-bound) solve
+  // (1) The previous launch's workgroup partials (nb rows of 32 floats, zero-padded to
+  // a multiple of 256 rows) depend on kernel arguments only: their loads go out first,
+  // before anything that waits on a parameter load.  Thread (g = tid/8, q = tid%8) owns
+  // the 16-B quad q of rows g + 32j: eight independent 16-B loads per pass (the rows were
+  // written by workgroups on all eight XCDs: Infinity-Cache/HBM round trips that must
+  // overlap, not chain).
+  float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (PRE) {
+    const int nb_pad = (nb + 255) & ~255;
+    const float* prev = partials + (size_t)((it - 1) & 1) * nb_pad * PICP_PSTRIDE;
+    const float4* src = reinterpret_cast<const float4*>(prev + (size_t)(tid >> 3) * PICP_PSTRIDE) + (tid & 7);
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+      float4 r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = src[(size_t)(b0 + 32 * j) * (PICP_PSTRIDE / 4)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { psum.x += r[j].x; psum.y += r[j].y; psum.z += r[j].z; psum.w += r[j].w; }
+    }
+  }
+
+  // (2) this thread's first correspondence (coalesced SoA loads), in flight during the solve
+  const int n = P->n_corr;
   int i = blockIdx.x * PICP_BLOCK + tid;
   bool have = !FINISH && i < n;
   float x = 0.f, y = 0.f, z = 0.f, u = 0.f, v = 0.f;
@@ -180,56 +251,72 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams
 
   Pose T;
   if (PRE) {
-    // Sum the previous launch's workgroup partials (nb rows of 32 floats).
-    // Thread t owns slot t%32 of rows t/32 + 8j: all of a thread's loads are
-    // issued before the first add (the rows come from all eight XCDs, i.e.
-    // Infinity-Cache/HBM round trips that must overlap, not chain), 32 lanes
-    // read one 128-B row.  Fixed order => every workgroup gets the same bits.
-    // The partial buffers are padded to a multiple of 256 rows and the padding
-    // rows stay zero, so neither the loads nor the adds need a bound check.
-    const int nb_pad = (nb + 255) & ~255;
-    const float* prev = partials + (size_t)((it - 1) & 1) * nb_pad * PICP_PSTRIDE;
-    const int slot = tid & 31, grp = tid >> 5;
-    constexpr int RPT = 32;                    // rows per thread per pass (8*32 = 256 rows per pass)
-    const float* src = prev + (size_t)grp * PICP_PSTRIDE + slot;
-    float sum = 0.f;
-    for (int b0 = 0; b0 < nb; b0 += 256) {
-      float r[RPT];
-#pragma unroll
-      for (int j = 0; j < RPT; ++j) r[j] = src[(size_t)(b0 + 8 * j) * PICP_PSTRIDE];
-#pragma unroll
-      for (int j = 0; j < RPT; ++j) sum += r[j];
+    VO_STAMP(1);
+    // (3) stage the 32 group sums transposed: s_acc[slot*36 + group], so that one slot's 32
+    // values are eight conflict-free 16-B reads.
+    {
+      const int g32 = tid >> 3, q4 = (tid & 7) * 4;
+      s_acc[(q4 + 0) * ACC_STRIDE + g32] = psum.x;
+      s_acc[(q4 + 1) * ACC_STRIDE + g32] = psum.y;
+      s_acc[(q4 + 2) * ACC_STRIDE + g32] = psum.z;
+      s_acc[(q4 + 3) * ACC_STRIDE + g32] = psum.w;
     }
-    s_red[grp * 32 + slot] = sum;
     __syncthreads();
-    if (tid < 32) {
+    // (4) Every wave finishes the sums it needs and runs the (uniform) 6x6 solve on its own:
+    // the four waves sit on four SIMDs, so the redundancy is free and spares three
+    // workgroup barriers plus the LDS broadcast of the pose.  Lane l < 36 builds H(r,c)
+    // (+damping on the diagonal, picp_solver.cpp:102), lanes 36..41 -b, lanes 42..44 the
+    // statistics.  Fixed order => every wave of every workgroup gets the same bits.
+    const int wave = tid >> 6, lane = tid & 63;
+    float* sys = s_sys[wave];
+    if (lane < 45) {
+      int slot;
+      bool diag = false;
+      if (lane < 36) {
+        const int r = lane / 6, c = lane - 6 * r;
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        slot = (13 * lo - lo * lo) / 2 + (hi - lo);          // row-major upper triangle
+        diag = r == c;
+      } else {
+        slot = 21 + (lane - 36);                             // 21..26 b, 27..29 chi_in, chi_out, n_in
+      }
+      const float4* row = reinterpret_cast<const float4*>(s_acc + slot * ACC_STRIDE);
       float tsum = 0.f;
 #pragma unroll
-      for (int g = 0; g < PICP_BLOCK / 32; ++g) tsum += s_red[g * 32 + tid];
-      s_tot[tid] = tsum;
-    }
-    __syncthreads();
-    picp_tail_expand(s_tot, s_sys, P->damping, (FINISH && blockIdx.x == 0) ? S->H : nullptr,
-                     (FINISH && blockIdx.x == 0) ? S->b : nullptr);
-    __syncthreads();
-    if (tid < 64) {
-      const Pose Told = uniform_pose(load_pose12(S->pose[(it - 1) & 1]));
-      const Pose Tn = picp_tail_wave(s_sys, Told);
-      if (tid == 0) {
-        store_pose12(s_pose, Tn);
-        if (blockIdx.x == 0) {
-          store_pose12(S->pose[FINISH ? 0 : (it & 1)], Tn);
-          if (FINISH) {
-            S->chi_in = s_tot[27];
-            S->chi_out = s_tot[28];
-            S->n_in = (int)(s_tot[29] + 0.5f);
-          }
-        }
+      for (int k = 0; k < 8; ++k) { const float4 t4 = row[k]; tsum += t4.x; tsum += t4.y; tsum += t4.z; tsum += t4.w; }
+      if (lane < 36) {
+        const float hv = diag ? tsum + 1.f * P->damping : tsum;
+        sys[lane] = hv;
+        if (FINISH && blockIdx.x == 0 && wave == 0) S->H[(lane % 6) * 6 + lane / 6] = hv;    // col-major
+      } else if (lane < 42) {
+        sys[lane] = -tsum;                                   // picp_solver.cpp:109 solve(-b)
+        if (FINISH && blockIdx.x == 0 && wave == 0) S->b[lane - 36] = tsum;
+      } else if (wave == 0) {
+        s_stat[lane - 42] = tsum;
       }
     }
+    // the tail below reads what other lanes of THIS wave just wrote: LDS operations of a wave
+    // execute in order, the fence/wave_barrier only pin the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    VO_STAMP(2);
+    {
+      const Pose Told = uniform_pose(load_pose12(S->pose[(it - 1) & 1]));
+      const Pose Tn = picp_tail_wave(sys, Told);
+      if (tid == 0 && blockIdx.x == 0) {
+        store_pose12(S->pose[FINISH ? 0 : (it & 1)], Tn);
+        if (FINISH) {
+          S->chi_in = s_stat[0];
+          S->chi_out = s_stat[1];
+          S->n_in = (int)(s_stat[2] + 0.5f);
+        }
+      }
+      T = uniform_pose(Tn);
+    }
+    VO_STAMP(3);
     if (FINISH) return;
-    __syncthreads();
-    T = uniform_pose(load_pose12(s_pose));
+    __syncthreads();   // every wave is done with the staged rows: s_acc is reused by the reduction
   } else {
     T = uniform_pose(load_pose12(S->pose[0]));
   }
@@ -247,12 +334,15 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams
     if (have) { x = pk.arr(0)[i]; y = pk.arr(1)[i]; z = pk.arr(2)[i]; u = pk.arr(3)[i]; v = pk.arr(4)[i]; }
     picp_accumulate_t<PINHOLE, KEEP>(cam, T, thr, cx, cy, cz, cu, cv, acc);
   }
-  const float tot = block_reduce_acc<PICP_BLOCK / 64>(acc, s_red);
+  VO_STAMP(4);
+  const float tot = block_reduce_lds256(acc, s_acc, s_part);
+  VO_STAMP(5);
   if (tid < PICP_PSTRIDE) {
     float o = tot;   // slot 29 (inlier count) is an exact integer in float: < 2^24 correspondences
     if (tid >= NACC) o = 0.f;
     partials[((size_t)(it & 1) * ((nb + 255) & ~255) + blockIdx.x) * PICP_PSTRIDE + tid] = o;
   }
+  VO_STAMP(6);
 }
 
 int picp_grid_for(int n_corr, int n_cu) {

@@ -33,6 +33,11 @@ struct PicpState {
   float chi_in, chi_out;
   int n_in;
   int n_bad;           // correspondences whose indices were out of range (dropped)
+#ifdef VO_STAMPS
+  // diagnostic build only (make STAMPS=1 -> libvo_hip_stamps.so, tools/stamp_rounds.py):
+  // s_memtime at phase boundaries of workgroup 0, per round
+  unsigned long long stamps[128][8];
+#endif
 };
 
 // packed correspondences: five SoA arrays of `cap` floats each (x,y,z,u,v)
