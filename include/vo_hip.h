@@ -98,7 +98,8 @@ int vo_picp_set_points(vo_picp *s, const float *world_xyz, int n_world, const fl
 int vo_picp_set_points_dev(vo_picp *s, const float *d_world_xyz, int n_world,
                            const float *d_meas_uv, int n_meas);
 int vo_picp_set_pose(vo_picp *s, const float T[16]);            /* camera.h:50 */
-/* same from a 4x4 in device memory, enqueued on the stream (no host sync) */
+/* same from a 4x4 in device memory: takes effect at the next one_round/solve call, on
+ * the stream, with no host sync (d_T16 must stay valid until then) */
 int vo_picp_set_pose_dev(vo_picp *s, const float *d_T16);
 int vo_picp_set_kernel_threshold(vo_picp *s, float thr);        /* picp_solver.h:35 */
 int vo_picp_get_kernel_threshold(vo_picp *s, float *thr);       /* picp_solver.h:33 */
@@ -118,6 +119,9 @@ int vo_picp_solve_dev(vo_picp *s, const int32_t *d_pairs, int n_pairs, const int
                       int keep_outliers, int n_iters);
 int vo_picp_get_pose(vo_picp *s, float T[16]);                  /* camera(), picp_solver.h:41 */
 int vo_picp_get_pose_dev(vo_picp *s, float *d_T16);             /* async copy on the stream */
+/* device address of the solver's own 4x4 pose (column-major), valid for the life of the
+ * handle and rewritten by every solve: lets a consumer kernel read the result in place */
+int vo_picp_pose_dev_ptr(vo_picp *s, const float **d_T16);
 int vo_picp_get_stats(vo_picp *s, float *chi_inliers, float *chi_outliers, int *num_inliers); /* :44-50 */
 /* H (6x6 col-major, damping included, as _H after oneRound) and b of the last round */
 int vo_picp_get_system(vo_picp *s, float H[36], float b[6]);

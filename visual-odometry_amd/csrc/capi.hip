@@ -97,6 +97,7 @@ struct vo_picp {
   bool key_dev = false;
   bool packed_valid = false;
   int grid = 1;
+  const float* pending_T0 = nullptr;   // device 4x4 to load as the pose by the next pack launch
   int zeroed_for_grid = -1;   // grid the (zero-padded) partial buffers were last cleared for
   int use_graph = 1;
   std::map<std::tuple<int, int, const void*, size_t, const void*, int>, hipGraphExec_t> graphs;
@@ -319,6 +320,7 @@ int vo_picp_set_pose(vo_picp* s, const float T[16]) {
   float pose[12];
   for (int i = 0; i < 9; ++i) pose[i] = P.R[i];
   for (int i = 0; i < 3; ++i) pose[9 + i] = P.t[i];
+  s->pending_T0 = nullptr;
   VO_HIP_CHECK(hipMemcpyAsync(s->d_state->pose[0], pose, sizeof(pose), hipMemcpyHostToDevice,
                               s->ctx->stream));
   VO_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));   // `pose` is a stack buffer
@@ -370,6 +372,12 @@ int vo_picp_set_points(vo_picp* s, const float* world, int n_world, const float*
 
 }  // extern "C"
 
+__global__ void T16_to_pose12_kernel(const float* T, float* p) {
+  const int k = threadIdx.x;
+  if (k < 9) p[k] = T[(k % 3) + 4 * (k / 3)];
+  else if (k < 12) p[k] = T[12 + (k - 9)];
+}
+
 static uint64_t sample_hash(const int32_t* pairs, int n) {
   // cheap content fingerprint: <= 64 pairs spread over the array
   uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
@@ -412,8 +420,14 @@ static int picp_prepare(vo_picp* s, const int32_t* d_pairs, int n_pairs, const i
     }
     PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
     VO_HIP_CHECK(launch_picp_pack(c->stream, d_pairs, d_n, n_pairs, s->d_world, s->n_world, s->d_meas,
-                                  s->n_meas, pk, s->d_params, s->d_state));
+                                  s->n_meas, pk, s->d_params, s->d_state, s->pending_T0));
+    s->pending_T0 = nullptr;
     s->packed_valid = true;
+  }
+  if (s->pending_T0) {   // correspondences were cached: the pose reset needs its own (tiny) launch
+    hipLaunchKernelGGL(T16_to_pose12_kernel, dim3(1), dim3(64), 0, c->stream, s->pending_T0, s->d_state->pose[0]);
+    VO_HIP_CHECK(hipGetLastError());
+    s->pending_T0 = nullptr;
   }
   return VO_OK;
 }
@@ -515,17 +529,16 @@ int vo_picp_get_pose(vo_picp* s, float T[16]) {
   return r;
 }
 
-__global__ void T16_to_pose12_kernel(const float* T, float* p) {
-  const int k = threadIdx.x;
-  if (k < 9) p[k] = T[(k % 3) + 4 * (k / 3)];
-  else if (k < 12) p[k] = T[12 + (k - 9)];
-}
-
 int vo_picp_set_pose_dev(vo_picp* s, const float* d_T16) {
   VO_REQUIRE(s && d_T16, "null argument");
-  if (int r = set_device(s->ctx)) return r;
-  hipLaunchKernelGGL(T16_to_pose12_kernel, dim3(1), dim3(64), 0, s->ctx->stream, d_T16, s->d_state->pose[0]);
-  VO_HIP_CHECK(hipGetLastError());
+  // consumed by the next solve: folded into its gather launch (or a 12-thread launch of its own)
+  s->pending_T0 = d_T16;
+  return VO_OK;
+}
+
+int vo_picp_pose_dev_ptr(vo_picp* s, const float** d_T16) {
+  VO_REQUIRE(s && d_T16, "null argument");
+  *d_T16 = s->d_state->T16;
   return VO_OK;
 }
 

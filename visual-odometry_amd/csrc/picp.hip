@@ -176,10 +176,15 @@ __global__ __launch_bounds__(256) void picp_pack_kernel(const int32_t* __restric
                                                         const int* __restrict__ d_n, int n_max,
                                                         const float* __restrict__ world, int n_world,
                                                         const float* __restrict__ meas, int n_meas,
-                                                        PackedCorr pk, PicpParams* P, PicpState* S) {
+                                                        PackedCorr pk, PicpParams* P, PicpState* S,
+                                                        const float* __restrict__ T0) {
   int n = n_max;
   if (d_n) { const int m = *d_n; n = m < n_max ? (m < 0 ? 0 : m) : n_max; }
   if (blockIdx.x == 0 && threadIdx.x == 0) P->n_corr = n;
+  if (T0 && blockIdx.x == 0 && threadIdx.x < 12) {          // pending pose reset rides along
+    const int k = threadIdx.x;
+    S->pose[0][k] = k < 9 ? T0[(k % 3) + 4 * (k / 3)] : T0[12 + (k - 9)];
+  }
   const float qnan = __int_as_float(0x7fc00000);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int m = pairs[2 * i];       // .first  -> measurement (picp_solver.cpp:66)
@@ -307,6 +312,10 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams
       if (tid == 0 && blockIdx.x == 0) {
         store_pose12(S->pose[FINISH ? 0 : (it & 1)], Tn);
         if (FINISH) {
+          float T16[16];
+          pose_to_T16(Tn, T16);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) S->T16[k] = T16[k];
           S->chi_in = s_stat[0];
           S->chi_out = s_stat[1];
           S->n_in = (int)(s_stat[2] + 0.5f);
@@ -359,14 +368,14 @@ int picp_grid_for(int n_corr, int n_cu) {
 
 hipError_t launch_picp_pack(hipStream_t st, const int32_t* d_pairs, const int* d_n, int n_max,
                             const float* d_world, int n_world, const float* d_meas, int n_meas,
-                            PackedCorr pk, PicpParams* d_params, PicpState* d_state) {
+                            PackedCorr pk, PicpParams* d_params, PicpState* d_state, const float* d_T0) {
   hipError_t e = hipMemsetAsync(&d_state->n_bad, 0, sizeof(int), st);
   if (e != hipSuccess) return e;
   int grid = (n_max + 255) / 256;
   if (grid < 1) grid = 1;
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(picp_pack_kernel, dim3(grid), dim3(256), 0, st, d_pairs, d_n, n_max, d_world,
-                     n_world, d_meas, n_meas, pk, d_params, d_state);
+                     n_world, d_meas, n_meas, pk, d_params, d_state, d_T0);
   return hipGetLastError();
 }
 

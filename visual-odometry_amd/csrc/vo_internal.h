@@ -33,6 +33,7 @@ struct PicpState {
   float chi_in, chi_out;
   int n_in;
   int n_bad;           // correspondences whose indices were out of range (dropped)
+  float T16[16];       // pose after the last solve as a column-major 4x4 (written by the finish launch)
 #ifdef VO_STAMPS
   // diagnostic build only (make STAMPS=1 -> libvo_hip_stamps.so, tools/stamp_rounds.py):
   // s_memtime at phase boundaries of workgroup 0, per round
@@ -48,9 +49,10 @@ struct PackedCorr {
   __host__ __device__ float* arr(int k) { return base + (size_t)k * cap; }
 };
 
+// d_T0 (may be null): column-major 4x4 in device memory that becomes the solver's pose
 hipError_t launch_picp_pack(hipStream_t st, const int32_t* d_pairs, const int* d_n, int n_max,
                             const float* d_world, int n_world, const float* d_meas, int n_meas,
-                            PackedCorr pk, PicpParams* d_params, PicpState* d_state);
+                            PackedCorr pk, PicpParams* d_params, PicpState* d_state, const float* d_T0);
 
 // Enqueue n_iters Gauss-Newton rounds (n_iters+1 launches).  d_partials holds
 // 2 * round_up(grid,256) * PICP_PSTRIDE floats, zero-initialised.

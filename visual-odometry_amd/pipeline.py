@@ -39,7 +39,6 @@ class FramePipeline:
         self.d_tri_pairs = a(max(self.nq, 1) * 8)
         self.d_tri_app = a(max(self.nq, 1) * 40)
         self.d_counts = a(64)                       # [0]=n_match [1]=n_join [2]=n_tri
-        self.d_pose = a(64)
         self.d_ident = up(np.eye(4, dtype=np.float32))
         self.X_prev = _colmajor(np.eye(4), 4)       # pose of the previous frame (vo_complete.cpp:159)
         h = C.c_void_p()
@@ -49,6 +48,9 @@ class FramePipeline:
         _chk(self.lib.vo_picp_set_kernel_threshold(h, C.c_float(kernel_threshold)))
         _chk(self.lib.vo_picp_set_points_dev(h, C.c_void_p(self.d_model_t), C.c_int(self.n_model),
                                              C.c_void_p(self.d_cur_pts), C.c_int(self.n_cur)))
+        p = C.c_void_p()
+        _chk(self.lib.vo_picp_pose_dev_ptr(h, C.byref(p)))
+        self.d_pose = p.value                       # the solver's own 4x4, read in place by triangulate
 
     def _cnt(self, i):
         return C.c_void_p(self.d_counts + 4 * i)
@@ -73,7 +75,6 @@ class FramePipeline:
         _chk(self.lib.vo_picp_set_pose_dev(self.solver, C.c_void_p(self.d_ident)))
         _chk(self.lib.vo_picp_solve_dev(self.solver, C.c_void_p(self.d_j), C.c_int(self.nq), self._cnt(1),
                                         C.c_int(0), C.c_int(self.n_iters)))
-        _chk(self.lib.vo_picp_get_pose_dev(self.solver, C.c_void_p(self.d_pose)))
 
     def triangulate(self):
         _chk(self.lib.vo_triangulate_dev(self.ctx.h, _ptr(self.K), None, C.c_void_p(self.d_pose),
@@ -118,5 +119,5 @@ class FramePipeline:
             self.solver = None
         for d in (self.d_ref_app, self.d_cur_app, self.d_ref_pts, self.d_cur_pts, self.d_model, self.d_model_pairs,
                   self.d_m, self.d_j, self.d_model_t, self.d_tri_xyz, self.d_tri_pairs, self.d_tri_app,
-                  self.d_counts, self.d_pose, self.d_ident):
+                  self.d_counts, self.d_ident):
             self.ctx.free(d)
