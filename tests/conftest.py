@@ -19,7 +19,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def vo():
     import __graft_entry__ as g
-    return g.load_package()
+    pkg = g.load_package()
+    if not os.path.exists(pkg.LIB_PATH):     # fresh checkout: compile the library first (hipcc cross-compiles without a GPU)
+        g.build()
+    return pkg
 
 
 @pytest.fixture(scope="session")
