@@ -233,8 +233,20 @@ def frame_leg(torch, ctx, stream, pipe, fp, args):
 
 
 def batched_leg(torch, vo, ctx, stream, args):
-    """config 4's per-GPU share: P independent 50k problems, all rounds in one launch."""
-    P, n, iters = args.batch_pairs, args.points, args.iters
+    """config 4's per-GPU share (200 problems), plus the same kernel with the chip full (256, 512
+    problems: one workgroup per problem, 256 CUs) to show where it saturates."""
+    out = _batched_run(torch, vo, ctx, stream, args, args.batch_pairs)
+    if args.batch_pairs == 200:
+        out["chip_full"] = []
+        for P in (256, 512):
+            r = _batched_run(torch, vo, ctx, stream, args, P)
+            out["chip_full"].append({"pairs": P, "kernel_ms": r["kernel_ms"], "iters_per_sec": r["iters_per_sec"],
+                                     "achieved_GBs": r["roofline"]["achieved"], "frac": r["roofline"]["frac"]})
+    return out
+
+
+def _batched_run(torch, vo, ctx, stream, args, P):
+    n, iters = args.points, args.iters
     lib = ctx.lib
     distinct = min(P, 4)
     fps = [vo.synth.frame_pair(n, seed=4000 + p) for p in range(distinct)]

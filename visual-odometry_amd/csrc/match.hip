@@ -207,24 +207,52 @@ __global__ void match_params_kernel(const unsigned* __restrict__ mm, float radiu
   *out = bp;
 }
 
-// counts[0..NB) tree, counts[NB..2NB) queries
-__global__ __launch_bounds__(256) void match_bucket_count_kernel(const float* __restrict__ tree, int nt,
-                                                                 const float* __restrict__ qry, int nq,
-                                                                 const BucketParams* __restrict__ bpp, int* counts) {
-  const BucketParams bp = *bpp;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nt + nq; i += gridDim.x * blockDim.x) {
-    const bool is_t = i < nt;
-    const float x = is_t ? tree[10 * (size_t)i + bp.dim] : qry[10 * (size_t)(i - nt) + bp.dim];
-    atomicAdd(&counts[(is_t ? 0 : NBUCKET) + bucket_of(x, bp)], 1);
-  }
+// Counting sort of both sets by bucket without global atomics: SORT_BLOCKS
+// workgroups each take a contiguous slice of the combined index space
+// [0,nt) tree, [nt,nt+nq) queries.
+//   hist    : LDS histogram of the slice -> block_hist[blk][2*NBUCKET]
+//   offsets : per bin, exclusive scan over the workgroups and over the bins
+//             -> starts[2][NBUCKET+1], block_hist becomes per-(blk,bin) offsets
+//   place   : every workgroup ranks its points inside a bin with LDS atomics
+//             and writes 48-B records (10 components, original index, bucket)
+// The order inside a bucket is arbitrary; nothing downstream depends on it.
+constexpr int SORT_BLOCKS = 32;
+
+__device__ __forceinline__ void sort_slice(int nt, int nq, int& lo, int& hi) {
+  const int total = nt + nq;
+  const int per = (total + SORT_BLOCKS - 1) / SORT_BLOCKS;
+  lo = blockIdx.x * per;
+  hi = lo + per < total ? lo + per : total;
 }
 
-// two workgroups: exclusive scan of each half; starts has 2*(NB+1) entries, cursor 2*NB
-__global__ __launch_bounds__(NBUCKET) void match_bucket_scan_kernel(const int* __restrict__ counts, int* starts,
-                                                                    int* cursor) {
+__global__ __launch_bounds__(256) void match_bucket_hist_kernel(const float* __restrict__ tree, int nt,
+                                                                const float* __restrict__ qry, int nq,
+                                                                const BucketParams* __restrict__ bpp, int* block_hist) {
+  __shared__ int s_h[2 * NBUCKET];
+  for (int k = threadIdx.x; k < 2 * NBUCKET; k += 256) s_h[k] = 0;
+  __syncthreads();
+  const BucketParams bp = *bpp;
+  int lo, hi;
+  sort_slice(nt, nq, lo, hi);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const bool is_t = i < nt;
+    const float x = is_t ? tree[10 * (size_t)i + bp.dim] : qry[10 * (size_t)(i - nt) + bp.dim];
+    atomicAdd(&s_h[(is_t ? 0 : NBUCKET) + bucket_of(x, bp)], 1);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * NBUCKET; k += 256) block_hist[(size_t)blockIdx.x * 2 * NBUCKET + k] = s_h[k];
+}
+
+// grid 2 (tree half, query half) x NBUCKET threads (one bin each)
+__global__ __launch_bounds__(NBUCKET) void match_bucket_offsets_kernel(int* block_hist, int* starts) {
   __shared__ int s_w[NBUCKET / 64];
   const int half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int v = counts[half * NBUCKET + tid];
+  int h[SORT_BLOCKS];
+#pragma unroll
+  for (int b = 0; b < SORT_BLOCKS; ++b) h[b] = block_hist[(size_t)b * 2 * NBUCKET + half * NBUCKET + tid];
+  int v = 0;
+#pragma unroll
+  for (int b = 0; b < SORT_BLOCKS; ++b) v += h[b];
   int incl = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
@@ -233,29 +261,39 @@ __global__ __launch_bounds__(NBUCKET) void match_bucket_scan_kernel(const int* _
   int woff = 0, tot = 0;
 #pragma unroll
   for (int w = 0; w < NBUCKET / 64; ++w) { const int c = s_w[w]; if (w < wave) woff += c; tot += c; }
-  const int excl = woff + incl - v;
-  starts[half * (NBUCKET + 1) + tid] = excl;
-  cursor[half * NBUCKET + tid] = excl;
+  int run = woff + incl - v;
+  starts[half * (NBUCKET + 1) + tid] = run;
   if (tid == 0) starts[half * (NBUCKET + 1) + NBUCKET] = tot;
+#pragma unroll
+  for (int b = 0; b < SORT_BLOCKS; ++b) {
+    block_hist[(size_t)b * 2 * NBUCKET + half * NBUCKET + tid] = run;
+    run += h[b];
+  }
 }
 
-// 12-float records: 10 appearance components, original index (int bits), bucket (int bits)
-__global__ __launch_bounds__(256) void match_bucket_scatter_kernel(const float* __restrict__ tree, int nt,
-                                                                   const float* __restrict__ qry, int nq,
-                                                                   const BucketParams* __restrict__ bpp, int* cursor,
-                                                                   float* tree_rec, float* qry_rec,
-                                                                   unsigned long long* best, float r2) {
+__global__ __launch_bounds__(256) void match_bucket_place_kernel(const float* __restrict__ tree, int nt,
+                                                                 const float* __restrict__ qry, int nq,
+                                                                 const BucketParams* __restrict__ bpp,
+                                                                 const int* __restrict__ block_off, float* tree_rec,
+                                                                 float* qry_rec, unsigned long long* best, float r2) {
+  __shared__ int s_off[2 * NBUCKET];
+  for (int k = threadIdx.x; k < 2 * NBUCKET; k += 256) s_off[k] = block_off[(size_t)blockIdx.x * 2 * NBUCKET + k];
+  __syncthreads();
   const BucketParams bp = *bpp;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nt + nq; i += gridDim.x * blockDim.x) {
+  int lo, hi;
+  sort_slice(nt, nq, lo, hi);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
     const bool is_t = i < nt;
     const int idx = is_t ? i : i - nt;
     const float2* src = reinterpret_cast<const float2*>((is_t ? tree : qry) + 10 * (size_t)idx);
     float2 v[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) v[k] = src[k];
-    const float x = (bp.dim & 1) ? v[bp.dim >> 1].y : v[bp.dim >> 1].x;
+    float x = v[0].x;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { if (bp.dim == 2 * k) x = v[k].x; if (bp.dim == 2 * k + 1) x = v[k].y; }
     const int b = bucket_of(x, bp);
-    const int pos = atomicAdd(&cursor[(is_t ? 0 : NBUCKET) + b], 1);
+    const int pos = atomicAdd(&s_off[(is_t ? 0 : NBUCKET) + b], 1);
     float4* dst = reinterpret_cast<float4*>((is_t ? tree_rec : qry_rec) + 12 * (size_t)pos);
     dst[0] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
     dst[1] = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
@@ -353,7 +391,7 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
 }
 
 size_t match_pruned_workspace_bytes(int nt, int nq) {
-  return sizeof(float) * 12 * ((size_t)nt + (size_t)nq) + sizeof(int) * (2 * NBUCKET + 2 * (NBUCKET + 1) + 2 * NBUCKET) +
+  return sizeof(float) * 12 * ((size_t)nt + (size_t)nq) + sizeof(int) * ((size_t)SORT_BLOCKS * 2 * NBUCKET + 2 * (NBUCKET + 1) + 8) +
          sizeof(BucketParams) + 20 * sizeof(unsigned) + 512;
 }
 
@@ -363,23 +401,20 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
   char* p = static_cast<char*>(ws);
   float* tree_rec = reinterpret_cast<float*>(p); p += sizeof(float) * 12 * (size_t)nt;
   float* qry_rec = reinterpret_cast<float*>(p); p += sizeof(float) * 12 * (size_t)nq;
-  int* counts = reinterpret_cast<int*>(p); p += sizeof(int) * 2 * NBUCKET;
-  int* cursor = reinterpret_cast<int*>(p); p += sizeof(int) * 2 * NBUCKET;
-  int* starts = reinterpret_cast<int*>(p); p += sizeof(int) * (2 * (NBUCKET + 1) + 2);
+  int* block_hist = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)SORT_BLOCKS * 2 * NBUCKET;
+  int* starts = reinterpret_cast<int*>(p); p += sizeof(int) * (2 * (NBUCKET + 1) + 6);
   BucketParams* bp = reinterpret_cast<BucketParams*>(p); p += 64;
   unsigned* mm = reinterpret_cast<unsigned*>(p);
-  hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * 2 * NBUCKET, st);
-  if (e == hipSuccess) e = hipMemsetAsync(mm, 0xff, 10 * sizeof(unsigned), st);
+  hipError_t e = hipMemsetAsync(mm, 0xff, 10 * sizeof(unsigned), st);
   if (e == hipSuccess) e = hipMemsetAsync(mm + 10, 0x00, 10 * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
   int g = (nt + nq + 255) / 256;
-  if (g > 1024) g = 1024;
   hipLaunchKernelGGL(match_minmax_kernel, dim3(g > 256 ? 256 : g), dim3(256), 0, st, tree, nt, qry, nq, mm);
   hipLaunchKernelGGL(match_params_kernel, dim3(1), dim3(64), 0, st, mm, radius, bp);
-  hipLaunchKernelGGL(match_bucket_count_kernel, dim3(g), dim3(256), 0, st, tree, nt, qry, nq, bp, counts);
-  hipLaunchKernelGGL(match_bucket_scan_kernel, dim3(2), dim3(NBUCKET), 0, st, counts, starts, cursor);
-  hipLaunchKernelGGL(match_bucket_scatter_kernel, dim3(g), dim3(256), 0, st, tree, nt, qry, nq, bp, cursor, tree_rec,
-                     qry_rec, d_best, r2);
+  hipLaunchKernelGGL(match_bucket_hist_kernel, dim3(SORT_BLOCKS), dim3(256), 0, st, tree, nt, qry, nq, bp, block_hist);
+  hipLaunchKernelGGL(match_bucket_offsets_kernel, dim3(2), dim3(NBUCKET), 0, st, block_hist, starts);
+  hipLaunchKernelGGL(match_bucket_place_kernel, dim3(SORT_BLOCKS), dim3(256), 0, st, tree, nt, qry, nq, bp, block_hist,
+                     tree_rec, qry_rec, d_best, r2);
   const int qblocks = (nq + MB * QPT - 1) / (MB * QPT);
   int nchunks = (6 * (n_cu > 0 ? n_cu : 256) + qblocks - 1) / qblocks;
   if (nchunks < 1) nchunks = 1;
