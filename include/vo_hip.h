@@ -66,6 +66,19 @@ int vo_ctx_device(vo_ctx *ctx);
 /* name of the device ("gfx950...") and number of compute units */
 int vo_ctx_device_info(vo_ctx *ctx, char *name, int name_len, int *n_cu);
 
+/* ---- hipGraph capture of a sequence of *_dev calls -------------------------------- */
+/* Everything enqueued on the context's stream between begin and end (only *_dev entry
+ * points: no host copies, no synchronisation, and every buffer the sequence needs must
+ * already have been sized by a previous identical call) becomes one replayable graph:
+ * a whole frame (match, join, transform, n rounds, triangulate = ~80 launches) then
+ * costs one launch on the host.  Device pointers and counts are baked in; data and
+ * device-side counts may change between replays. */
+typedef struct vo_graph vo_graph;
+int vo_ctx_begin_capture(vo_ctx *ctx);
+int vo_ctx_end_capture(vo_ctx *ctx, vo_graph **out);
+int vo_graph_launch(vo_graph *g);          /* on the stream of the context it was captured on */
+int vo_graph_destroy(vo_graph *g);
+
 /* device memory helpers for callers without a HIP runtime of their own */
 int vo_dev_alloc(vo_ctx *ctx, size_t bytes, void **dptr);
 int vo_dev_free(vo_ctx *ctx, void *dptr);

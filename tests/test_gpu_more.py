@@ -122,3 +122,29 @@ def test_frame_pipeline_device_resident(vo, ctx, o32):
     assert np.array_equal(pairs, po) and np.array_equal(app, ao)
     assert np.all(np.abs(xyz - xo) <= 1e-4 * np.maximum(1, np.abs(xo)))
     pipe.close()
+
+
+def test_whole_frame_graph_replay(vo, ctx, o32):
+    """vo_ctx_begin_capture/end_capture: a captured frame replays to the same bits as plain launches,
+    and follows new data in the same device buffers (counts live in device memory)."""
+    fp = vo.synth.frame_pair(3000, seed=304, drop=0.1, distractors=40, model_drop=0.1)
+    c2 = vo.Context(0)
+    pipe = vo.FramePipeline(c2, fp, n_iters=8, kernel_threshold=10000.0)
+    pipe.frame()
+    ref = (pipe.pose().tobytes(), pipe.fetch("match").tobytes(), pipe.fetch("join").tobytes(), pipe.fetch("tri_xyz").tobytes())
+    pipe.capture_frame()
+    for _ in range(3):
+        pipe.frame_graph()
+    got = (pipe.pose().tobytes(), pipe.fetch("match").tobytes(), pipe.fetch("join").tobytes(), pipe.fetch("tri_xyz").tobytes())
+    assert got == ref
+    # new measurements in the same buffers: drop the appearance of 100 current points -> fewer matches
+    cur_app = fp["cur_app"].copy()
+    cur_app[:100] = 9.0
+    c2.h2d(pipe.d_cur_app, cur_app)
+    pipe.frame_graph()
+    m_o = o32.match(fp["ref_app"], cur_app)
+    assert np.array_equal(pipe.fetch("match"), m_o) and len(m_o) < len(np.frombuffer(ref[1], np.int32)) // 2
+    j_o = o32.join(m_o, fp["model_pairs"])
+    r = o32.picp_solve(OCam(480, 640, 0, 10, fp["K"], np.eye(4)), fp["model"], fp["cur_pts"], j_o, 8, 10000.0, False, trace=False)
+    assert np.abs(pipe.pose() - r["T"]).max() < 1e-4 and pipe.stats()[2] == r["num_inliers"]
+    pipe.close(); c2.close()

@@ -77,6 +77,12 @@ struct vo_ctx {
   DevBuf batch_pack;  // packed correspondences of the batched solver
   DevBuf prune_ws;    // bucket-sorted copies of the matcher
   int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan
+  bool capturing = false;
+};
+
+struct vo_graph {
+  vo_ctx* ctx = nullptr;
+  hipGraphExec_t exec = nullptr;
 };
 
 struct vo_picp {
@@ -169,6 +175,48 @@ int vo_ctx_device_info(vo_ctx* c, char* name, int name_len, int* n_cu) {
   VO_REQUIRE(c, "ctx is null");
   if (name && name_len > 0) { strncpy(name, c->name, (size_t)name_len - 1); name[name_len - 1] = 0; }
   if (n_cu) *n_cu = c->n_cu;
+  return VO_OK;
+}
+
+int vo_ctx_begin_capture(vo_ctx* c) {
+  VO_REQUIRE(c, "ctx is null");
+  VO_REQUIRE(!c->capturing, "already capturing");
+  if (int r = set_device(c)) return r;
+  VO_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  c->capturing = true;
+  return VO_OK;
+}
+
+int vo_ctx_end_capture(vo_ctx* c, vo_graph** out) {
+  VO_REQUIRE(c && out, "null argument");
+  VO_REQUIRE(c->capturing, "not capturing");
+  *out = nullptr;
+  c->capturing = false;
+  hipGraph_t graph = nullptr;
+  VO_HIP_CHECK(hipStreamEndCapture(c->stream, &graph));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return fail(VO_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  vo_graph* g = new vo_graph();
+  g->ctx = c;
+  g->exec = exec;
+  *out = g;
+  return VO_OK;
+}
+
+int vo_graph_launch(vo_graph* g) {
+  VO_REQUIRE(g && g->exec, "null graph");
+  if (int r = set_device(g->ctx)) return r;
+  VO_HIP_CHECK(hipGraphLaunch(g->exec, g->ctx->stream));
+  return VO_OK;
+}
+
+int vo_graph_destroy(vo_graph* g) {
+  if (!g) return VO_OK;
+  (void)hipStreamSynchronize(g->ctx->stream);
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  delete g;
   return VO_OK;
 }
 
@@ -397,6 +445,8 @@ static int picp_prepare(vo_picp* s, const int32_t* d_pairs, int n_pairs, const i
   vo_ctx* c = s->ctx;
   if (!s->have_points) return fail(VO_ERR_NOT_READY, "vo_picp: set_points has not been called");
   if (s->hp.keep_outliers != (keep_outliers ? 1 : 0)) { s->hp.keep_outliers = keep_outliers ? 1 : 0; s->params_dirty = true; }
+  if (s->params_dirty && c->capturing)
+    return fail(VO_ERR_NOT_READY, "vo_picp: parameters changed inside a graph capture (run the sequence once before capturing)");
   if (s->params_dirty) {
     // n_corr is owned by the pack kernel: keep the device value
     VO_HIP_CHECK(hipMemcpyAsync(s->d_params, &s->hp, offsetof(PicpParams, n_corr), hipMemcpyHostToDevice,
@@ -437,7 +487,7 @@ static int picp_enqueue(vo_picp* s, int n_iters) {
   PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
   float* partials = s->partials.as<float>();
   const bool pinhole = is_pinhole(s->hp.cam.K), keep = s->hp.keep_outliers != 0;
-  if (s->use_graph && n_iters >= 2) {
+  if (s->use_graph && n_iters >= 2 && !c->capturing) {
     auto key = std::make_tuple(n_iters, s->grid, (const void*)pk.base, pk.cap, (const void*)partials,
                                (pinhole ? 1 : 0) | (keep ? 2 : 0));
     auto it = s->graphs.find(key);

@@ -87,6 +87,22 @@ class FramePipeline:
     def frame(self):
         self.match(); self.join(); self.transform(); self.picp(); self.triangulate()
 
+    def capture_frame(self):
+        """Capture one whole frame into a hipGraph (after at least one plain frame(), which sizes
+        every internal buffer); frame_graph() then replays it with a single launch."""
+        self.frame()
+        self.ctx.synchronize()
+        g = C.c_void_p()
+        _chk(self.lib.vo_ctx_begin_capture(self.ctx.h))
+        try:
+            self.frame()
+        finally:
+            _chk(self.lib.vo_ctx_end_capture(self.ctx.h, C.byref(g)))
+        self.graph = g
+
+    def frame_graph(self):
+        _chk(self.lib.vo_graph_launch(self.graph))
+
     # -- results (synchronise) -------------------------------------------------
     def counts(self):
         c = np.zeros(3, np.int32)
@@ -114,6 +130,9 @@ class FramePipeline:
         return ci.value, co.value, ni.value
 
     def close(self):
+        if getattr(self, "graph", None):
+            self.lib.vo_graph_destroy(self.graph)
+            self.graph = None
         if self.solver:
             self.lib.vo_picp_destroy(self.solver)
             self.solver = None
