@@ -116,30 +116,41 @@ __global__ __launch_bounds__(MB) void match_kernel(const float* __restrict__ tre
 }
 
 // ---- pruned variant ---------------------------------------------------------------
-// For large sets the same exact scan runs over a pruned candidate set: both
-// sets are counting-sorted into 1024 buckets along the appearance dimension
-// with the largest spread, and a workgroup of (bucket-sorted) queries scans only
-// the tree buckets within +-W of its own bucket range, W = ceil(R*scale)+1,
-// R = 1.001*radius.  A tree point outside that window differs from every query
-// of the workgroup by more than the radius in one coordinate, so that single
-// term of the (non-negative, monotonically accumulated) sum already reaches
-// radius^2 and the point can never pass the strict "d2 < best" test: pruning
-// changes no decision.  Inside the window the scan is the one above (4-term
-// bit-exact prefix, then the remaining terms in the reference's order).  Worst
-// case (no spread in any dimension) it degenerates to the full scan.
+// For large sets the same exact scan runs over a pruned candidate set.  Both
+// sets are counting-sorted by a two-level key: NA coarse cells along the
+// appearance component A of largest spread, NB fine buckets along the component
+// B of second-largest spread (NA*NB = 1024 bins).  A workgroup takes queries of
+// ONE cell of A (bucket-sorted in B) and scans, for every A-cell that some query
+// could reach, only the B-buckets some query could reach:
+//     cells   [min cellA(qA - R), max cellA(qA + R)]
+//     buckets [min bktB (qB - R), max bktB (qB + R)]       R = 1.001 * radius
+// the minima/maxima taken over the workgroup's queries with the same monotone
+// bucket functions the sort used.  A tree point outside that rectangle differs
+// from every query of the workgroup by more than the radius in A or in B; that
+// single non-negative term of the monotonically accumulated sum already reaches
+// radius^2, so the point can never pass the strict "d2 < best" test: pruning
+// changes no decision.  Inside the rectangle the scan is the exact one above
+// (4-term bit-exact prefix, then the remaining terms in the reference's order).
+// With no spread in A and B it degenerates to the full scan.
 constexpr int NBUCKET = 1024;
+constexpr int NA = 16;               // coarse cells
+constexpr int NB = NBUCKET / NA;     // fine buckets per cell
 
 struct BucketParams {
-  int dim;       // appearance component used for bucketing
-  float lo;      // minimum of that component over both sets
-  float scale;   // NBUCKET / (hi - lo), 0 when hi == lo
-  int W;         // half window in buckets
+  int dimA, dimB;            // appearance components
+  float loA, scaleA;         // cell   = clamp((x - loA) * scaleA, 0, NA-1), scaleA = NA / spreadA (0 if none)
+  float loB, scaleB;         // bucket = clamp((x - loB) * scaleB, 0, NB-1)
+  float R;                   // search margin, slightly above the radius
 };
 
-__device__ __forceinline__ int bucket_of(float x, const BucketParams& bp) {
-  float v = (x - bp.lo) * bp.scale;                      // monotone non-decreasing in x
-  v = fminf(fmaxf(v, 0.f), (float)(NBUCKET - 1));        // NaN -> 0, +-inf clamp
+__device__ __forceinline__ int cell_of(float x, float lo, float scale, int n) {
+  float v = (x - lo) * scale;                            // monotone non-decreasing in x
+  v = fminf(fmaxf(v, 0.f), (float)(n - 1));              // NaN -> 0, +-inf clamp
   return (int)v;
+}
+
+__device__ __forceinline__ int bucket_of(float xa, float xb, const BucketParams& bp) {
+  return cell_of(xa, bp.loA, bp.scaleA, NA) * NB + cell_of(xb, bp.loB, bp.scaleB, NB);
 }
 
 // per-component min/max over both sets: workgroup partials merged with atomic
@@ -188,22 +199,22 @@ __global__ __launch_bounds__(256) void match_minmax_kernel(const float* __restri
   }
 }
 
-// choice of the bucketing dimension (largest finite spread) and of the window
+// choice of the two bucketing components: largest and second-largest finite spread
 __global__ void match_params_kernel(const unsigned* __restrict__ mm, float radius, BucketParams* out) {
   if (threadIdx.x != 0) return;
-  int best = 0;
-  float best_span = -1.f, blo = 0.f;
+  int a = 0, b = 1;
+  float sa = -1.f, sb = -1.f, la = 0.f, lb = 0.f;
   for (int k = 0; k < 10; ++k) {
     const float l = ord2f(mm[k]), h = ord2f(mm[10 + k]);
     const float span = h - l;
-    if (span > best_span && span < INFINITY) { best_span = span; best = k; blo = l; }
+    if (!(span < INFINITY)) continue;                  // empty / infinite / NaN ranges are skipped
+    if (span > sa) { sb = sa; b = a; lb = la; sa = span; a = k; la = l; }
+    else if (span > sb) { sb = span; b = k; lb = l; }
   }
   BucketParams bp;
-  bp.dim = best;
-  bp.lo = blo;
-  bp.scale = best_span > 0.f ? (float)NBUCKET / best_span : 0.f;
-  const float w = ceilf(radius * 1.001f * bp.scale) + 1.f;
-  bp.W = w < (float)NBUCKET ? (int)w : NBUCKET;
+  bp.dimA = a; bp.loA = la; bp.scaleA = sa > 0.f ? (float)NA / sa : 0.f;
+  bp.dimB = b; bp.loB = lb; bp.scaleB = sb > 0.f ? (float)NB / sb : 0.f;
+  bp.R = radius * 1.001f;
   *out = bp;
 }
 
@@ -236,8 +247,8 @@ __global__ __launch_bounds__(256) void match_bucket_hist_kernel(const float* __r
   sort_slice(nt, nq, lo, hi);
   for (int i = lo + threadIdx.x; i < hi; i += 256) {
     const bool is_t = i < nt;
-    const float x = is_t ? tree[10 * (size_t)i + bp.dim] : qry[10 * (size_t)(i - nt) + bp.dim];
-    atomicAdd(&s_h[(is_t ? 0 : NBUCKET) + bucket_of(x, bp)], 1);
+    const float* pt = is_t ? tree + 10 * (size_t)i : qry + 10 * (size_t)(i - nt);
+    atomicAdd(&s_h[(is_t ? 0 : NBUCKET) + bucket_of(pt[bp.dimA], pt[bp.dimB], bp)], 1);
   }
   __syncthreads();
   for (int k = threadIdx.x; k < 2 * NBUCKET; k += 256) block_hist[(size_t)blockIdx.x * 2 * NBUCKET + k] = s_h[k];
@@ -289,10 +300,15 @@ __global__ __launch_bounds__(256) void match_bucket_place_kernel(const float* __
     float2 v[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) v[k] = src[k];
-    float x = v[0].x;
+    float xa = v[0].x, xb = v[0].x;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { if (bp.dim == 2 * k) x = v[k].x; if (bp.dim == 2 * k + 1) x = v[k].y; }
-    const int b = bucket_of(x, bp);
+    for (int k = 0; k < 5; ++k) {
+      if (bp.dimA == 2 * k) xa = v[k].x;
+      if (bp.dimA == 2 * k + 1) xa = v[k].y;
+      if (bp.dimB == 2 * k) xb = v[k].x;
+      if (bp.dimB == 2 * k + 1) xb = v[k].y;
+    }
+    const int b = bucket_of(xa, xb, bp);
     const int pos = atomicAdd(&s_off[(is_t ? 0 : NBUCKET) + b], 1);
     float4* dst = reinterpret_cast<float4*>((is_t ? tree_rec : qry_rec) + 12 * (size_t)pos);
     dst[0] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
@@ -308,15 +324,33 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
                                                           const BucketParams* __restrict__ bpp, int nchunks, float r2,
                                                           unsigned long long* __restrict__ best) {
   __shared__ __attribute__((aligned(16))) float s_t[TILE * TP];
+  __shared__ int s_rng[4][MB / 64];
   const int tid = threadIdx.x;
-  const int qbase = blockIdx.x * MB * QPT;
-  const int q0 = qbase + tid * QPT;
+  const int* starts_t = starts;                       // [NBUCKET+1]
+  const int* starts_q = starts + (NBUCKET + 1);
+  // which A-cell of queries does this workgroup serve?  (workgroups never straddle cells)
+  int row = -1, qs = 0, qe = 0;
+  {
+    int wg = blockIdx.x;
+#pragma unroll 1
+    for (int r = 0; r < NA; ++r) {
+      const int b0 = starts_q[r * NB], b1 = starts_q[(r + 1) * NB];
+      const int nblk = (b1 - b0 + MB * QPT - 1) / (MB * QPT);
+      if (wg < nblk) { row = r; qs = b0 + wg * MB * QPT; qe = qs + MB * QPT < b1 ? qs + MB * QPT : b1; break; }
+      wg -= nblk;
+    }
+  }
+  if (row < 0) return;                                // surplus workgroup (grid is an upper bound)
+  const BucketParams bp = *bpp;
+  const int q0 = qs + tid * QPT;
   float q[QPT][10];
   float bd[QPT];
   int bi[QPT], qorig[QPT];
+  int aLo = NA, aHi = -1, bLo = NB, bHi = -1;
 #pragma unroll
   for (int j = 0; j < QPT; ++j) {
-    const int qi = q0 + j < nq ? q0 + j : nq - 1;          // clamp: result discarded
+    const bool live = q0 + j < qe;
+    const int qi = live ? q0 + j : qe - 1;             // clamp: result discarded
     const float4* src = reinterpret_cast<const float4*>(qry_rec + 12 * (size_t)qi);
     const float4 a = src[0], b = src[1], c = src[2];
     q[j][0] = a.x; q[j][1] = a.y; q[j][2] = a.z; q[j][3] = a.w;
@@ -325,64 +359,89 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
     qorig[j] = __float_as_int(c.z);
     bd[j] = r2;
     bi[j] = -1;
-  }
-  // bucket range of this workgroup's queries (sorted by bucket) widened by W
-  const int W = bpp->W;
-  const int q_last = qbase + MB * QPT - 1 < nq ? qbase + MB * QPT - 1 : nq - 1;
-  int b_lo = __float_as_int(qry_rec[12 * (size_t)qbase + 11]) - W;
-  int b_hi = __float_as_int(qry_rec[12 * (size_t)q_last + 11]) + W;
-  b_lo = b_lo < 0 ? 0 : b_lo;
-  b_hi = b_hi > NBUCKET - 1 ? NBUCKET - 1 : b_hi;
-  const int r_begin = starts[b_lo], r_end = starts[b_hi + 1];
-  const int span = r_end - r_begin;
-  const int per = ((span + nchunks - 1) / nchunks + TILE - 1) / TILE * TILE;   // whole tiles per chunk
-  const int t_begin = r_begin + blockIdx.y * per;
-  const int t_end = t_begin + per < r_end ? t_begin + per : r_end;
-  for (int tb = t_begin; tb < t_end; tb += TILE) {
-    const int cnt = t_end - tb < TILE ? t_end - tb : TILE;
-    __syncthreads();
-    const float4* src = reinterpret_cast<const float4*>(tree_rec + 12 * (size_t)tb);
-    float4* dst = reinterpret_cast<float4*>(s_t);
-    for (int f = tid; f < cnt * 3; f += MB) dst[f] = src[f];
-    __syncthreads();
-#pragma unroll 4
-    for (int p = 0; p < cnt; ++p) {
-      const float4 ta = *reinterpret_cast<const float4*>(&s_t[p * TP]);
-      float pre[QPT];
-      bool any = false;
+    float xa = q[j][0], xb = q[j][0];
 #pragma unroll
-      for (int j = 0; j < QPT; ++j) {
-        const float d0 = ta.x - q[j][0], d1 = ta.y - q[j][1], d2 = ta.z - q[j][2], d3 = ta.w - q[j][3];
-        float s = d0 * d0;
-        s += d1 * d1;
-        s += d2 * d2;
-        s += d3 * d3;
-        pre[j] = s;
-        any = any || (s <= bd[j]);   // <=: an exact tie with a lower original index must still be seen
-      }
-      if (__builtin_expect(any, 0)) {
-        const float4 tb4 = *reinterpret_cast<const float4*>(&s_t[p * TP + 4]);
-        const float4 tc = *reinterpret_cast<const float4*>(&s_t[p * TP + 8]);
+    for (int k = 0; k < 10; ++k) { if (bp.dimA == k) xa = q[j][k]; if (bp.dimB == k) xb = q[j][k]; }
+    if (live) {
+      const int a0 = cell_of(xa - bp.R, bp.loA, bp.scaleA, NA), a1 = cell_of(xa + bp.R, bp.loA, bp.scaleA, NA);
+      const int b0 = cell_of(xb - bp.R, bp.loB, bp.scaleB, NB), b1 = cell_of(xb + bp.R, bp.loB, bp.scaleB, NB);
+      aLo = a0 < aLo ? a0 : aLo; aHi = a1 > aHi ? a1 : aHi;
+      bLo = b0 < bLo ? b0 : bLo; bHi = b1 > bHi ? b1 : bHi;
+    }
+  }
+  // rectangle of the workgroup: min/max over its queries
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int t0 = __shfl_xor(aLo, d), t1 = __shfl_xor(aHi, d), t2 = __shfl_xor(bLo, d), t3 = __shfl_xor(bHi, d);
+    aLo = t0 < aLo ? t0 : aLo; aHi = t1 > aHi ? t1 : aHi;
+    bLo = t2 < bLo ? t2 : bLo; bHi = t3 > bHi ? t3 : bHi;
+  }
+  if ((tid & 63) == 0) { s_rng[0][tid >> 6] = aLo; s_rng[1][tid >> 6] = aHi; s_rng[2][tid >> 6] = bLo; s_rng[3][tid >> 6] = bHi; }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < MB / 64; ++w) {
+    aLo = s_rng[0][w] < aLo ? s_rng[0][w] : aLo; aHi = s_rng[1][w] > aHi ? s_rng[1][w] : aHi;
+    bLo = s_rng[2][w] < bLo ? s_rng[2][w] : bLo; bHi = s_rng[3][w] > bHi ? s_rng[3][w] : bHi;
+  }
+  // total candidate count over the cells, split into nchunks slices of whole tiles
+  int span = 0;
+  for (int r = aLo; r <= aHi; ++r) span += starts_t[r * NB + bHi + 1] - starts_t[r * NB + bLo];
+  const int per = ((span + nchunks - 1) / nchunks + TILE - 1) / TILE * TILE;
+  const int v_begin = blockIdx.y * per;                // slice of the virtual concatenation of the ranges
+  const int v_end = v_begin + per < span ? v_begin + per : span;
+  int v0 = 0;                                          // virtual offset of the current range
+  for (int r = aLo; r <= aHi; ++r) {
+    const int r_begin = starts_t[r * NB + bLo], r_len = starts_t[r * NB + bHi + 1] - r_begin;
+    const int lo = v_begin > v0 ? v_begin - v0 : 0;
+    const int hi = v_end - v0 < r_len ? v_end - v0 : r_len;
+    v0 += r_len;
+    for (int off = lo; off < hi; off += TILE) {
+      const int tb = r_begin + off;
+      const int cnt = hi - off < TILE ? hi - off : TILE;
+      __syncthreads();
+      const float4* src = reinterpret_cast<const float4*>(tree_rec + 12 * (size_t)tb);
+      float4* dst = reinterpret_cast<float4*>(s_t);
+      for (int f = tid; f < cnt * 3; f += MB) dst[f] = src[f];
+      __syncthreads();
+#pragma unroll 4
+      for (int p = 0; p < cnt; ++p) {
+        const float4 ta = *reinterpret_cast<const float4*>(&s_t[p * TP]);
+        float pre[QPT];
+        bool any = false;
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
-          float s = pre[j];
-          float d;
-          d = tb4.x - q[j][4]; s += d * d;
-          d = tb4.y - q[j][5]; s += d * d;
-          d = tb4.z - q[j][6]; s += d * d;
-          d = tb4.w - q[j][7]; s += d * d;
-          d = tc.x - q[j][8]; s += d * d;
-          d = tc.y - q[j][9]; s += d * d;
-          // ties: lowest ORIGINAL index (the sorted order is arbitrary inside a bucket)
-          const int ti = __float_as_int(tc.z);
-          if (s < bd[j] || (s == bd[j] && bi[j] >= 0 && ti < bi[j])) { bd[j] = s; bi[j] = ti; }
+          const float d0 = ta.x - q[j][0], d1 = ta.y - q[j][1], d2 = ta.z - q[j][2], d3 = ta.w - q[j][3];
+          float s = d0 * d0;
+          s += d1 * d1;
+          s += d2 * d2;
+          s += d3 * d3;
+          pre[j] = s;
+          any = any || (s <= bd[j]);   // <=: an exact tie with a lower original index must still be seen
+        }
+        if (__builtin_expect(any, 0)) {
+          const float4 tb4 = *reinterpret_cast<const float4*>(&s_t[p * TP + 4]);
+          const float4 tc = *reinterpret_cast<const float4*>(&s_t[p * TP + 8]);
+#pragma unroll
+          for (int j = 0; j < QPT; ++j) {
+            float s = pre[j];
+            float d;
+            d = tb4.x - q[j][4]; s += d * d;
+            d = tb4.y - q[j][5]; s += d * d;
+            d = tb4.z - q[j][6]; s += d * d;
+            d = tb4.w - q[j][7]; s += d * d;
+            d = tc.x - q[j][8]; s += d * d;
+            d = tc.y - q[j][9]; s += d * d;
+            // ties: lowest ORIGINAL index (the sorted order is arbitrary inside a bucket)
+            const int ti = __float_as_int(tc.z);
+            if (s < bd[j] || (s == bd[j] && bi[j] >= 0 && ti < bi[j])) { bd[j] = s; bi[j] = ti; }
+          }
         }
       }
     }
   }
 #pragma unroll
   for (int j = 0; j < QPT; ++j) {
-    if (bi[j] >= 0 && q0 + j < nq) {
+    if (bi[j] >= 0 && q0 + j < qe) {
       const unsigned long long key =
           ((unsigned long long)__float_as_uint(bd[j]) << 32) | (unsigned long long)(unsigned)bi[j];
       atomicMin(&best[qorig[j]], key);
@@ -415,7 +474,7 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
   hipLaunchKernelGGL(match_bucket_offsets_kernel, dim3(2), dim3(NBUCKET), 0, st, block_hist, starts);
   hipLaunchKernelGGL(match_bucket_place_kernel, dim3(SORT_BLOCKS), dim3(256), 0, st, tree, nt, qry, nq, bp, block_hist,
                      tree_rec, qry_rec, d_best, r2);
-  const int qblocks = (nq + MB * QPT - 1) / (MB * QPT);
+  const int qblocks = (nq + MB * QPT - 1) / (MB * QPT) + NA;   // upper bound: workgroups are aligned to A-cells
   int nchunks = (6 * (n_cu > 0 ? n_cu : 256) + qblocks - 1) / qblocks;
   if (nchunks < 1) nchunks = 1;
   if (nchunks > 64) nchunks = 64;
