@@ -24,6 +24,8 @@
 // is (query blocks) x (tree chunks); chunks merge through one 64-bit
 // atomicMin per hit on key = (bits(d2) << 32) | tree index, which is
 // order-independent, hence deterministic.
+#include <stdlib.h>
+
 #include "vo_internal.h"
 
 namespace vo {
@@ -33,7 +35,7 @@ hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best
 
 constexpr int MB = 256;       // threads per workgroup
 constexpr int QPT = 2;        // queries per thread
-constexpr int TILE = 512;     // tree points per LDS tile (24 KiB)
+constexpr int TILE = 128;     // tree points per LDS tile (6 KiB)
 constexpr int TP = 12;        // padded floats per tree point in LDS
 
 __global__ __launch_bounds__(256) void match_init_kernel(unsigned long long* best, int nq, float r2) {
@@ -163,7 +165,7 @@ __device__ __forceinline__ float ord2f(unsigned o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
-// mm[0..9] = min (init 0xffffffff), mm[10..19] = max (init 0)
+// mm[0..9] = ord(min), mm[10..19] = ~ord(max): both merge with atomicMin, one 0xff memset initialises all
 __global__ __launch_bounds__(256) void match_minmax_kernel(const float* __restrict__ a, int na,
                                                            const float* __restrict__ b, int nb, unsigned* mm) {
   __shared__ float s_lo[4][10], s_hi[4][10];
@@ -195,27 +197,36 @@ __global__ __launch_bounds__(256) void match_minmax_kernel(const float* __restri
     float l = INFINITY, h = -INFINITY;
     for (int w = 0; w < 4; ++w) { l = fminf(l, s_lo[w][k]); h = fmaxf(h, s_hi[w][k]); }
     atomicMin(&mm[k], f2ord(l));
-    atomicMax(&mm[10 + k], f2ord(h));
+    atomicMin(&mm[10 + k], ~f2ord(h));
   }
 }
 
-// choice of the two bucketing components: largest and second-largest finite spread
-__global__ void match_params_kernel(const unsigned* __restrict__ mm, float radius, BucketParams* out) {
-  if (threadIdx.x != 0) return;
-  int a = 0, b = 1;
-  float sa = -1.f, sb = -1.f, la = 0.f, lb = 0.f;
-  for (int k = 0; k < 10; ++k) {
-    const float l = ord2f(mm[k]), h = ord2f(mm[10 + k]);
+// Choice of the two bucketing components.  Components 0..3 form the bit-exact early-exit
+// prefix of the scan; a component the rectangle has already narrowed makes a poor filter
+// term, so A and B are taken from components 4..9 (largest, second-largest finite spread)
+// unless those are much flatter (< half the spread) than the best of all ten.
+__device__ void top2(const unsigned* mm, int k0, int k1, int& a, int& b, float& sa, float& sb, float& la, float& lb) {
+  a = k0; b = k0 + 1; sa = -1.f; sb = -1.f; la = 0.f; lb = 0.f;
+  for (int k = k0; k < k1; ++k) {
+    const float l = ord2f(mm[k]), h = ord2f(~mm[10 + k]);
     const float span = h - l;
     if (!(span < INFINITY)) continue;                  // empty / infinite / NaN ranges are skipped
     if (span > sa) { sb = sa; b = a; lb = la; sa = span; a = k; la = l; }
     else if (span > sb) { sb = span; b = k; lb = l; }
   }
+}
+
+__device__ BucketParams make_bucket_params(const unsigned* __restrict__ mm, float radius) {
+  int a, b, a2, b2;
+  float sa, sb, la, lb, sa2, sb2, la2, lb2;
+  top2(mm, 0, 10, a, b, sa, sb, la, lb);
+  top2(mm, 4, 10, a2, b2, sa2, sb2, la2, lb2);
+  if (sa2 >= 0.5f * sa && sb2 >= 0.5f * sb) { a = a2; b = b2; sa = sa2; sb = sb2; la = la2; lb = lb2; }
   BucketParams bp;
   bp.dimA = a; bp.loA = la; bp.scaleA = sa > 0.f ? (float)NA / sa : 0.f;
   bp.dimB = b; bp.loB = lb; bp.scaleB = sb > 0.f ? (float)NB / sb : 0.f;
   bp.R = radius * 1.001f;
-  *out = bp;
+  return bp;
 }
 
 // Counting sort of both sets by bucket without global atomics: SORT_BLOCKS
@@ -238,11 +249,17 @@ __device__ __forceinline__ void sort_slice(int nt, int nq, int& lo, int& hi) {
 
 __global__ __launch_bounds__(256) void match_bucket_hist_kernel(const float* __restrict__ tree, int nt,
                                                                 const float* __restrict__ qry, int nq,
-                                                                const BucketParams* __restrict__ bpp, int* block_hist) {
+                                                                const unsigned* __restrict__ mm, float radius,
+                                                                BucketParams* bp_out, int* block_hist) {
   __shared__ int s_h[2 * NBUCKET];
+  __shared__ BucketParams s_bp;
   for (int k = threadIdx.x; k < 2 * NBUCKET; k += 256) s_h[k] = 0;
+  if (threadIdx.x == 0) {                        // every workgroup derives the same parameters from the min/max words
+    s_bp = make_bucket_params(mm, radius);
+    if (blockIdx.x == 0) *bp_out = s_bp;         // published for the later launches
+  }
   __syncthreads();
-  const BucketParams bp = *bpp;
+  const BucketParams bp = s_bp;
   int lo, hi;
   sort_slice(nt, nq, lo, hi);
   for (int i = lo + threadIdx.x; i < hi; i += 256) {
@@ -331,13 +348,19 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
   // which A-cell of queries does this workgroup serve?  (workgroups never straddle cells)
   int row = -1, qs = 0, qe = 0;
   {
+    int edge[NA + 1];                                  // all cell boundaries at once: independent loads
+#pragma unroll
+    for (int r = 0; r <= NA; ++r) edge[r] = starts_q[r * NB];
     int wg = blockIdx.x;
-#pragma unroll 1
+#pragma unroll
     for (int r = 0; r < NA; ++r) {
-      const int b0 = starts_q[r * NB], b1 = starts_q[(r + 1) * NB];
-      const int nblk = (b1 - b0 + MB * QPT - 1) / (MB * QPT);
-      if (wg < nblk) { row = r; qs = b0 + wg * MB * QPT; qe = qs + MB * QPT < b1 ? qs + MB * QPT : b1; break; }
-      wg -= nblk;
+      const int nblk = (edge[r + 1] - edge[r] + MB * QPT - 1) / (MB * QPT);
+      if (row < 0 && wg < nblk) {
+        row = r;
+        qs = edge[r] + wg * MB * QPT;
+        qe = qs + MB * QPT < edge[r + 1] ? qs + MB * QPT : edge[r + 1];
+      }
+      if (row < 0) wg -= nblk;
     }
   }
   if (row < 0) return;                                // surplus workgroup (grid is an upper bound)
@@ -403,9 +426,11 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
       float4* dst = reinterpret_cast<float4*>(s_t);
       for (int f = tid; f < cnt * 3; f += MB) dst[f] = src[f];
       __syncthreads();
+      float4 nxt = *reinterpret_cast<const float4*>(&s_t[0]);
 #pragma unroll 4
       for (int p = 0; p < cnt; ++p) {
-        const float4 ta = *reinterpret_cast<const float4*>(&s_t[p * TP]);
+        const float4 ta = nxt;
+        nxt = *reinterpret_cast<const float4*>(&s_t[(p + 1 < cnt ? p + 1 : p) * TP]);   // next point's prefix, in flight
         float pre[QPT];
         bool any = false;
 #pragma unroll
@@ -451,7 +476,7 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
 
 size_t match_pruned_workspace_bytes(int nt, int nq) {
   return sizeof(float) * 12 * ((size_t)nt + (size_t)nq) + sizeof(int) * ((size_t)SORT_BLOCKS * 2 * NBUCKET + 2 * (NBUCKET + 1) + 8) +
-         sizeof(BucketParams) + 20 * sizeof(unsigned) + 512;
+         sizeof(BucketParams) + 32 * sizeof(unsigned) + 512;
 }
 
 static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt, const float* qry, int nq,
@@ -464,18 +489,18 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
   int* starts = reinterpret_cast<int*>(p); p += sizeof(int) * (2 * (NBUCKET + 1) + 6);
   BucketParams* bp = reinterpret_cast<BucketParams*>(p); p += 64;
   unsigned* mm = reinterpret_cast<unsigned*>(p);
-  hipError_t e = hipMemsetAsync(mm, 0xff, 10 * sizeof(unsigned), st);
-  if (e == hipSuccess) e = hipMemsetAsync(mm + 10, 0x00, 10 * sizeof(unsigned), st);
+  hipError_t e = hipMemsetAsync(mm, 0xff, 32 * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
   int g = (nt + nq + 255) / 256;
   hipLaunchKernelGGL(match_minmax_kernel, dim3(g > 256 ? 256 : g), dim3(256), 0, st, tree, nt, qry, nq, mm);
-  hipLaunchKernelGGL(match_params_kernel, dim3(1), dim3(64), 0, st, mm, radius, bp);
-  hipLaunchKernelGGL(match_bucket_hist_kernel, dim3(SORT_BLOCKS), dim3(256), 0, st, tree, nt, qry, nq, bp, block_hist);
+  hipLaunchKernelGGL(match_bucket_hist_kernel, dim3(SORT_BLOCKS), dim3(256), 0, st, tree, nt, qry, nq, mm, radius, bp,
+                     block_hist);
   hipLaunchKernelGGL(match_bucket_offsets_kernel, dim3(2), dim3(NBUCKET), 0, st, block_hist, starts);
   hipLaunchKernelGGL(match_bucket_place_kernel, dim3(SORT_BLOCKS), dim3(256), 0, st, tree, nt, qry, nq, bp, block_hist,
                      tree_rec, qry_rec, d_best, r2);
   const int qblocks = (nq + MB * QPT - 1) / (MB * QPT) + NA;   // upper bound: workgroups are aligned to A-cells
-  int nchunks = (6 * (n_cu > 0 ? n_cu : 256) + qblocks - 1) / qblocks;
+  static const int chunk_factor = [] { const char* e = getenv("VO_MATCH_CHUNK_FACTOR"); return e ? atoi(e) : 16; }();
+  int nchunks = (chunk_factor * (n_cu > 0 ? n_cu : 256) + qblocks - 1) / qblocks;
   if (nchunks < 1) nchunks = 1;
   if (nchunks > 64) nchunks = 64;
   hipLaunchKernelGGL(match_pruned_kernel, dim3(qblocks, nchunks), dim3(MB), 0, st, tree_rec, nt, qry_rec, nq, starts,
