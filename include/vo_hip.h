@@ -204,6 +204,41 @@ int vo_triangulate_dev(vo_ctx *ctx, const float K[9], const float X[16], const f
                        const float *d_p2_uv, int n2, const float *d_app2, float *d_out_xyz,
                        int32_t *d_out_pairs, float *d_out_app, int *d_n_out);
 
+/* ---- many independent frame pairs at once (throughput form of vo_complete.cpp:156-173) ---- */
+/* For each of n_frames independent frame pairs: match -> join -> X_prev * model -> n_iters rounds
+ * from the identity -> triangulate, every stage one batched launch (frame = a grid dimension) and
+ * the solver the batched kernel of vo_picp_solve_batch_dev.  All frames share the set sizes, the
+ * camera and the solver settings; per-frame counts are produced in device memory.  All pointers
+ * are DEVICE pointers; frame f of an array lives at base + f * (items per frame).  Enqueues on
+ * the context's stream and returns. */
+typedef struct vo_frame_batch {
+  int n_frames;
+  int n_ref, n_cur;              /* points in every reference / current image */
+  int n_model, n_model_pairs;    /* model points and (ref index, model index) pairs per frame */
+  const float *ref_app, *cur_app;   /* [n_frames][n_ref|n_cur][10] */
+  const float *ref_pts, *cur_pts;   /* [n_frames][n_ref|n_cur][2] */
+  const float *model;               /* [n_frames][n_model][3] */
+  const int32_t *model_pairs;       /* [n_frames][n_model_pairs][2] */
+  const float *X_prev;              /* [n_frames][16] column-major, or NULL for identity */
+  int rows, cols, z_near, z_far;
+  float K[9];
+  float kernel_threshold;
+  int keep_outliers;
+  int n_iters;
+  float radius;                     /* appearance radius (0.1 in the reference) */
+  /* outputs; q = min(n_ref, n_cur) items of room per frame */
+  int32_t *matches;                 /* [n_frames][q][2]  (ref index, cur index) */
+  int32_t *joined;                  /* [n_frames][q][2]  (cur index, model index) */
+  float *model_moved;               /* [n_frames][n_model][3]  X_prev * model (also the solver's world points) */
+  float *poses;                     /* [n_frames][16] */
+  float *stats;                     /* [n_frames][4]: chi_inliers, chi_outliers, num_inliers, 0 (may be NULL) */
+  float *tri_xyz;                   /* [n_frames][q][3] */
+  int32_t *tri_pairs;               /* [n_frames][q][2]  (cur index, slot) */
+  float *tri_app;                   /* [n_frames][q][10] or NULL */
+  int *counts;                      /* [3][n_frames]: matches, joined pairs, triangulated points */
+} vo_frame_batch;
+int vo_frames_batch_dev(vo_ctx *ctx, const vo_frame_batch *batch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,3 +148,30 @@ def test_whole_frame_graph_replay(vo, ctx, o32):
     r = o32.picp_solve(OCam(480, 640, 0, 10, fp["K"], np.eye(4)), fp["model"], fp["cur_pts"], j_o, 8, 10000.0, False, trace=False)
     assert np.abs(pipe.pose() - r["T"]).max() < 1e-4 and pipe.stats()[2] == r["num_inliers"]
     pipe.close(); c2.close()
+
+
+@pytest.mark.parametrize("n,F", [(700, 5), (6000, 3)])     # full-scan matcher / bucket-pruned matcher
+def test_batched_frames_equal_single_frames(vo, o32, n, F):
+    """vo_frames_batch_dev: every frame of the batch gets exactly the matches / joined pairs / survivors of the
+    per-frame path and of the oracle, and its pose within the reduction-order tolerance."""
+    c = vo.Context(0)
+    fps = []
+    for i in range(F):                                   # same sizes, different content
+        f = vo.synth.frame_pair(n, seed=7000 + 31 * i + n)
+        keep = np.random.default_rng(i).permutation(n)[: n - n // 10]
+        f["model_pairs"] = np.ascontiguousarray(f["model_pairs"][np.sort(keep)])     # some points without model
+        fps.append(f)
+    bp = vo.BatchPipeline(c, fps, n_iters=9, kernel_threshold=10000.0)
+    for _ in range(2):
+        bp.run()
+    poses, stats, counts = bp.poses(), bp.stats(), bp.counts()
+    for i, f in enumerate(fps):
+        m_o = o32.match(f["ref_app"], f["cur_app"]); j_o = o32.join(m_o, f["model_pairs"])
+        assert np.array_equal(bp.fetch("match", i), m_o) and np.array_equal(bp.fetch("join", i), j_o)
+        assert counts[0, i] == len(m_o) and counts[1, i] == len(j_o)
+        r = o32.picp_solve(OCam(480, 640, 0, 10, f["K"], np.eye(4)), f["model"], f["cur_pts"], j_o, 9, 10000.0, False, trace=False)
+        assert np.abs(poses[i] - r["T"]).max() < 1e-4 and int(stats[i, 2]) == r["num_inliers"]
+        xo, po, ao = o32.triangulate(f["K"], poses[i], m_o, f["ref_pts"], f["cur_pts"], f["cur_app"])
+        assert np.array_equal(bp.fetch("tri_pairs", i), po) and np.array_equal(bp.fetch("tri_app", i), ao)
+        assert np.all(np.abs(bp.fetch("tri_xyz", i) - xo) <= 1e-4 * np.maximum(1, np.abs(xo)))
+    bp.close(); c.close()

@@ -695,7 +695,7 @@ int vo_match_appearances_dev(vo_ctx* c, const float* d_a1, int n1, const float* 
   const bool prune = c->match_mode == 2 || (c->match_mode == 0 && (double)nt * (double)nq >= 4.0e6);
   void* ws = nullptr;
   if (prune && nq > 0) {
-    VO_HIP_CHECK(c->prune_ws.ensure(match_pruned_workspace_bytes(nt, nq), c->stream));
+    VO_HIP_CHECK(c->prune_ws.ensure(match_pruned_workspace_bytes(nt, nq, 1), c->stream));
     ws = c->prune_ws.p;
   }
   VO_HIP_CHECK(launch_match(c->stream, d_a1, n1, d_a2, n2, radius, d_out_pairs, d_n_out,
@@ -722,6 +722,56 @@ int vo_match_appearances(vo_ctx* c, const float* a1, int n1, const float* a2, in
   VO_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (h > 0) VO_HIP_CHECK(hipMemcpy(out_pairs, c->out[0].p, sizeof(int32_t) * 2 * (size_t)h, hipMemcpyDeviceToHost));
   *n_out = h;
+  return VO_OK;
+}
+
+// ---- batched frames -----------------------------------------------------------------------
+int vo_frames_batch_dev(vo_ctx* c, const vo_frame_batch* b) {
+  VO_REQUIRE(c && b, "null argument");
+  const int F = b->n_frames;
+  VO_REQUIRE(F >= 0 && b->n_ref >= 0 && b->n_cur >= 0 && b->n_model >= 0 && b->n_model_pairs >= 0 && b->n_iters >= 0,
+             "negative count");
+  if (F == 0) return VO_OK;
+  const int q = b->n_ref < b->n_cur ? b->n_ref : b->n_cur;
+  VO_REQUIRE(q > 0 && b->n_model > 0, "empty frames");
+  VO_REQUIRE(b->ref_app && b->cur_app && b->ref_pts && b->cur_pts && b->model && b->model_pairs, "null input array");
+  VO_REQUIRE(b->matches && b->joined && b->model_moved && b->poses && b->tri_xyz && b->tri_pairs && b->counts,
+             "null output array");
+  if (int r = set_device(c)) return r;
+  const int nt = b->n_ref > b->n_cur ? b->n_ref : b->n_cur;
+  const size_t cs = compaction_scratch_ints(q);
+  VO_HIP_CHECK(c->scratch.ensure(sizeof(int) * cs * (size_t)F, c->stream));
+  VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)q * (size_t)F, c->stream));
+  VO_HIP_CHECK(c->table.ensure(sizeof(int) * (size_t)(b->n_ref ? b->n_ref : 1) * (size_t)F, c->stream));
+  const bool prune = c->match_mode == 2 || (c->match_mode == 0 && (double)nt * (double)q >= 4.0e6);
+  void* ws = nullptr;
+  if (prune) {
+    VO_HIP_CHECK(c->prune_ws.ensure(match_pruned_workspace_bytes(nt, q, F), c->stream));
+    ws = c->prune_ws.p;
+  }
+  int* n_match = b->counts;
+  int* n_join = b->counts + F;
+  int* n_tri = b->counts + 2 * (size_t)F;
+  // compute_correspondences_images, all frames                                  vo_complete.cpp:156
+  VO_HIP_CHECK(launch_match_batch(c->stream, b->ref_app, b->n_ref, 10 * (size_t)b->n_ref, b->cur_app, b->n_cur,
+                                  10 * (size_t)b->n_cur, b->radius, b->matches, (size_t)q, n_match,
+                                  c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, F));
+  // extract_correspondences_world                                               vo_complete.cpp:157
+  VO_HIP_CHECK(launch_join_batch(c->stream, b->matches, q, n_match, b->model_pairs, b->n_model_pairs, nullptr, b->n_ref,
+                                 b->joined, n_join, c->table.as<int>(), c->scratch.as<int>(), F, (size_t)q,
+                                 (size_t)b->n_model_pairs, (size_t)q));
+  // X_curr * triangulated_pc                                                    vo_complete.cpp:159
+  VO_HIP_CHECK(launch_transform_batch(c->stream, b->X_prev, b->model, b->n_model, (size_t)b->n_model, b->model_moved, F));
+  // solver.init(identity) + n rounds                                            vo_complete.cpp:161-164
+  if (int r = vo_picp_solve_batch_dev(c, F, b->rows, b->cols, b->z_near, b->z_far, b->K, b->kernel_threshold,
+                                      b->keep_outliers, b->model_moved, (size_t)b->n_model, b->cur_pts, (size_t)b->n_cur,
+                                      b->joined, (size_t)q, n_join, nullptr, b->n_iters, b->poses, b->stats))
+    return r;
+  // triangulate_points with the new pose                                        vo_complete.cpp:172-173
+  VO_HIP_CHECK(launch_triangulate_batch(c->stream, b->K, nullptr, b->poses, b->matches, q, n_match, b->ref_pts, b->n_ref,
+                                        b->cur_pts, b->n_cur, b->tri_app ? b->cur_app : nullptr, b->tri_xyz, b->tri_pairs,
+                                        b->tri_app, n_tri, c->scratch.as<int>(), F, (size_t)q, (size_t)b->n_ref,
+                                        (size_t)b->n_cur, (size_t)q));
   return VO_OK;
 }
 

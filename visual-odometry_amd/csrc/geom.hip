@@ -47,9 +47,12 @@ __device__ __forceinline__ int clamp_count(const int* d_n, int n_max) {
   return n;
 }
 
-// One workgroup: offsets[b] = sum(counts[0..b-1]) in place, *total = sum.
+// One workgroup per frame (blockIdx.x): offsets[b] = sum(counts[0..b-1]) in place, *total = sum.
 __global__ __launch_bounds__(1024) void scan_counts_kernel(int* counts, int nb, int* total,
-                                                           int* total2) {
+                                                           int* total2, size_t counts_stride) {
+  counts += blockIdx.x * counts_stride;
+  total += blockIdx.x;
+  if (total2) total2 += blockIdx.x;
   __shared__ int s_w[16];
   __shared__ int s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,8 +88,9 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(int* counts, int nb, 
   }
 }
 
-static hipError_t launch_scan(hipStream_t st, int* counts, int nb, int* total, int* total2 = nullptr) {
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, counts, nb, total, total2);
+static hipError_t launch_scan(hipStream_t st, int* counts, int nb, int* total, int* total2 = nullptr, int n_frames = 1,
+                              size_t counts_stride = 0) {
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(n_frames), dim3(1024), 0, st, counts, nb, total, total2, counts_stride);
   return hipGetLastError();
 }
 
@@ -171,6 +175,41 @@ __global__ __launch_bounds__(256) void transform_kernel(Pose T, const float* __r
   }
 }
 
+// batched: frame f = blockIdx.y reads T16[f] (column-major 4x4; null: identity) and in/out + f*stride points
+__global__ __launch_bounds__(256) void transform_batch_kernel(const float* __restrict__ T16, const float* __restrict__ in,
+                                                              int n, size_t stride, float* __restrict__ out) {
+  const int f = blockIdx.y;
+  Pose T;
+  if (T16) {
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = T16[16 * (size_t)f + k];
+    T = pose_from_T16(t);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) T.R[k] = (k % 4 == 0) ? 1.f : 0.f;
+    T.t[0] = T.t[1] = T.t[2] = 0.f;
+  }
+  in += 3 * f * stride;
+  out += 3 * f * stride;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float* p = in + 3 * (size_t)i;
+    float ox, oy, oz;
+    pose_apply(T, p[0], p[1], p[2], ox, oy, oz);
+    float* o = out + 3 * (size_t)i;
+    o[0] = ox; o[1] = oy; o[2] = oz;
+  }
+}
+
+hipError_t launch_transform_batch(hipStream_t st, const float* d_T16, const float* d_in, int n, size_t stride,
+                                  float* d_out, int n_frames) {
+  if (n <= 0 || n_frames <= 0) return hipSuccess;
+  int grid = (n + 255) / 256;
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(transform_batch_kernel, dim3(grid, n_frames), dim3(256), 0, st, d_T16, d_in, n, stride, d_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_transform_points(hipStream_t st, const Pose& T, const float* d_in, int n,
                                    const int* d_n, float* d_out) {
   if (n <= 0) return hipSuccess;
@@ -195,7 +234,25 @@ struct TriArgs {
   int32_t* out_pairs;
   float* out_app;
   int* counts;
+  // batched use: frame f = blockIdx.y; strides in pairs / points (0 for a single frame)
+  size_t pairs_stride, p1_stride, p2_stride, out_stride, counts_stride;
 };
+
+// shifts every per-frame pointer of `a` to frame blockIdx.y
+__device__ __forceinline__ TriArgs tri_frame(TriArgs a) {
+  const size_t f = blockIdx.y;
+  if (a.d_X16) a.d_X16 += 16 * f;
+  a.pairs += 2 * f * a.pairs_stride;
+  if (a.d_n) a.d_n += f;
+  a.p1 += 2 * f * a.p1_stride;
+  a.p2 += 2 * f * a.p2_stride;
+  if (a.app2) a.app2 += 10 * f * a.p2_stride;
+  a.out_xyz += 3 * f * a.out_stride;
+  if (a.out_pairs) a.out_pairs += 2 * f * a.out_stride;
+  if (a.out_app) a.out_app += 10 * f * a.out_stride;
+  a.counts += f * a.counts_stride;
+  return a;
+}
 
 __device__ __forceinline__ void tri_setup(const TriArgs& a, TriConst* s_c) {
   if (threadIdx.x == 0) {
@@ -225,7 +282,8 @@ __device__ __forceinline__ bool tri_eval(const TriArgs& a, const TriConst& c, in
   return triangulate_point(d1, d2, c.t, p);
 }
 
-__global__ __launch_bounds__(CB) void tri_count_kernel(TriArgs a) {
+__global__ __launch_bounds__(CB) void tri_count_kernel(TriArgs a0) {
+  const TriArgs a = tri_frame(a0);
   __shared__ TriConst s_c;
   __shared__ int s_wave[CB / 64];
   tri_setup(a, &s_c);
@@ -238,7 +296,8 @@ __global__ __launch_bounds__(CB) void tri_count_kernel(TriArgs a) {
   if (threadIdx.x == 0) a.counts[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a) {
+__global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a0) {
+  const TriArgs a = tri_frame(a0);
   __shared__ TriConst s_c;
   __shared__ int s_wave[CB / 64];
   tri_setup(a, &s_c);
@@ -263,11 +322,13 @@ __global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a) {
   }
 }
 
-hipError_t launch_triangulate(hipStream_t st, const float K[9], const Pose* X_host,
-                              const float* d_X16, const int32_t* d_pairs, int n, const int* d_n,
-                              const float* d_p1, int n1, const float* d_p2, int n2,
-                              const float* d_app2, float* d_out_xyz, int32_t* d_out_pairs,
-                              float* d_out_app, int* d_n_out, int* d_scratch) {
+// n_frames > 1: frame f uses d_X16 + 16f, pairs + f*pairs_stride, d_n[f], p1/p2/app2 + f*stride, writes
+// out_* + f*out_stride and d_n_out[f]; d_scratch holds n_frames * compaction_scratch_ints(n) ints.
+hipError_t launch_triangulate_batch(hipStream_t st, const float K[9], const Pose* X_host, const float* d_X16,
+                                    const int32_t* d_pairs, int n, const int* d_n, const float* d_p1, int n1,
+                                    const float* d_p2, int n2, const float* d_app2, float* d_out_xyz,
+                                    int32_t* d_out_pairs, float* d_out_app, int* d_n_out, int* d_scratch, int n_frames,
+                                    size_t pairs_stride, size_t p1_stride, size_t p2_stride, size_t out_stride) {
   TriArgs a;
   for (int k = 0; k < 9; ++k) a.K[k] = K[k];
   if (X_host) a.X = *X_host;
@@ -277,12 +338,25 @@ hipError_t launch_triangulate(hipStream_t st, const float K[9], const Pose* X_ho
   a.p1 = d_p1; a.n1 = n1; a.p2 = d_p2; a.n2 = n2; a.app2 = d_app2;
   a.out_xyz = d_out_xyz; a.out_pairs = d_out_pairs; a.out_app = d_out_app;
   a.counts = d_scratch;
+  const bool batched = n_frames > 1;
+  a.pairs_stride = batched ? pairs_stride : 0; a.p1_stride = batched ? p1_stride : 0;
+  a.p2_stride = batched ? p2_stride : 0; a.out_stride = batched ? out_stride : 0;
+  a.counts_stride = batched ? compaction_scratch_ints(n) : 0;
   const int nb = (n + CB - 1) / CB;
-  if (nb > 0) hipLaunchKernelGGL(tri_count_kernel, dim3(nb), dim3(CB), 0, st, a);
-  hipError_t e = launch_scan(st, d_scratch, nb, d_n_out);
+  if (nb > 0) hipLaunchKernelGGL(tri_count_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);
+  hipError_t e = launch_scan(st, d_scratch, nb, d_n_out, nullptr, n_frames, a.counts_stride);
   if (e != hipSuccess) return e;
-  if (nb > 0) hipLaunchKernelGGL(tri_scatter_kernel, dim3(nb), dim3(CB), 0, st, a);
+  if (nb > 0) hipLaunchKernelGGL(tri_scatter_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);
   return hipGetLastError();
+}
+
+hipError_t launch_triangulate(hipStream_t st, const float K[9], const Pose* X_host,
+                              const float* d_X16, const int32_t* d_pairs, int n, const int* d_n,
+                              const float* d_p1, int n1, const float* d_p2, int n2,
+                              const float* d_app2, float* d_out_xyz, int32_t* d_out_pairs,
+                              float* d_out_app, int* d_n_out, int* d_scratch) {
+  return launch_triangulate_batch(st, K, X_host, d_X16, d_pairs, n, d_n, d_p1, n1, d_p2, n2, d_app2, d_out_xyz,
+                                  d_out_pairs, d_out_app, d_n_out, d_scratch, 1, 0, 0, 0, 0);
 }
 
 // ---- join ---------------------------------------------------------------------------
@@ -292,7 +366,10 @@ constexpr int JOIN_EMPTY = 0x7f7f7f7f;   // byte pattern of the memset
 
 __global__ __launch_bounds__(256) void join_build_kernel(const int32_t* __restrict__ world, int n_max,
                                                          const int* __restrict__ d_n, int n_ref,
-                                                         int* table) {
+                                                         int* table, size_t world_stride) {
+  world += 2 * blockIdx.y * world_stride;            // frame = blockIdx.y
+  table += (size_t)blockIdx.y * n_ref;
+  if (d_n) d_n += blockIdx.y;
   const int n = clamp_count(d_n, n_max);
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const int ref = world[2 * (size_t)j];
@@ -307,7 +384,19 @@ struct JoinArgs {
   const int* table;
   int32_t* out;
   int* counts;
+  size_t img_stride, world_stride, out_stride, counts_stride;   // per frame (blockIdx.y), in pairs / ints
 };
+
+__device__ __forceinline__ JoinArgs join_frame(JoinArgs a) {
+  const size_t f = blockIdx.y;
+  a.img += 2 * f * a.img_stride;
+  if (a.d_n) a.d_n += f;
+  a.world += 2 * f * a.world_stride;
+  a.table += f * (size_t)a.n_ref;
+  a.out += 2 * f * a.out_stride;
+  a.counts += f * a.counts_stride;
+  return a;
+}
 
 __device__ __forceinline__ bool join_eval(const JoinArgs& a, int i, int& cur, int& w) {
   const int ref = a.img[2 * (size_t)i];
@@ -319,7 +408,8 @@ __device__ __forceinline__ bool join_eval(const JoinArgs& a, int i, int& cur, in
   return true;
 }
 
-__global__ __launch_bounds__(CB) void join_count_kernel(JoinArgs a) {
+__global__ __launch_bounds__(CB) void join_count_kernel(JoinArgs a0) {
+  const JoinArgs a = join_frame(a0);
   __shared__ int s_wave[CB / 64];
   const int n = clamp_count(a.d_n, a.n_max);
   const int i = blockIdx.x * CB + threadIdx.x;
@@ -330,7 +420,8 @@ __global__ __launch_bounds__(CB) void join_count_kernel(JoinArgs a) {
   if (threadIdx.x == 0) a.counts[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(CB) void join_scatter_kernel(JoinArgs a) {
+__global__ __launch_bounds__(CB) void join_scatter_kernel(JoinArgs a0) {
+  const JoinArgs a = join_frame(a0);
   __shared__ int s_wave[CB / 64];
   const int n = clamp_count(a.d_n, a.n_max);
   const int i = blockIdx.x * CB + threadIdx.x;
@@ -346,27 +437,41 @@ __global__ __launch_bounds__(CB) void join_scatter_kernel(JoinArgs a) {
   }
 }
 
-hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const int* d_n_img,
-                       const int32_t* d_world, int n_world, const int* d_n_world, int n_ref,
-                       int32_t* d_out, int* d_n_out, int* d_table, int* d_scratch) {
+// n_frames > 1: frame f joins d_img + f*img_stride (d_n_img[f] pairs) with d_world + f*world_stride
+// (d_n_world[f] pairs, or n_world when null) into d_out + f*out_stride, count in d_n_out[f];
+// d_table: n_frames*n_ref ints, d_scratch: n_frames*compaction_scratch_ints(n_img) ints.
+hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, const int* d_n_img,
+                             const int32_t* d_world, int n_world, const int* d_n_world, int n_ref, int32_t* d_out,
+                             int* d_n_out, int* d_table, int* d_scratch, int n_frames, size_t img_stride,
+                             size_t world_stride, size_t out_stride) {
+  const bool batched = n_frames > 1;
   hipError_t e = hipSuccess;
   if (n_ref > 0) {
-    e = hipMemsetAsync(d_table, 0x7f, sizeof(int) * (size_t)n_ref, st);
+    e = hipMemsetAsync(d_table, 0x7f, sizeof(int) * (size_t)n_ref * (size_t)n_frames, st);
     if (e != hipSuccess) return e;
   }
   if (n_world > 0 && n_ref > 0) {
     int grid = (n_world + 255) / 256;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(join_build_kernel, dim3(grid), dim3(256), 0, st, d_world, n_world, d_n_world,
-                       n_ref, d_table);
+    hipLaunchKernelGGL(join_build_kernel, dim3(grid, n_frames), dim3(256), 0, st, d_world, n_world, d_n_world, n_ref,
+                       d_table, batched ? world_stride : 0);
   }
-  JoinArgs a{d_img, n_img, d_n_img, d_world, n_ref, d_table, d_out, d_scratch};
+  JoinArgs a{d_img, n_img, d_n_img, d_world, n_ref, d_table, d_out, d_scratch,
+             batched ? img_stride : 0, batched ? world_stride : 0, batched ? out_stride : 0,
+             batched ? compaction_scratch_ints(n_img) : 0};
   const int nb = (n_img + CB - 1) / CB;
-  if (nb > 0) hipLaunchKernelGGL(join_count_kernel, dim3(nb), dim3(CB), 0, st, a);
-  e = launch_scan(st, d_scratch, nb, d_n_out);
+  if (nb > 0) hipLaunchKernelGGL(join_count_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);
+  e = launch_scan(st, d_scratch, nb, d_n_out, nullptr, n_frames, a.counts_stride);
   if (e != hipSuccess) return e;
-  if (nb > 0) hipLaunchKernelGGL(join_scatter_kernel, dim3(nb), dim3(CB), 0, st, a);
+  if (nb > 0) hipLaunchKernelGGL(join_scatter_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);
   return hipGetLastError();
+}
+
+hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const int* d_n_img,
+                       const int32_t* d_world, int n_world, const int* d_n_world, int n_ref,
+                       int32_t* d_out, int* d_n_out, int* d_table, int* d_scratch) {
+  return launch_join_batch(st, d_img, n_img, d_n_img, d_world, n_world, d_n_world, n_ref, d_out, d_n_out, d_table,
+                           d_scratch, 1, 0, 0, 0);
 }
 
 // ---- matcher output compaction (used by match.hip) -------------------------------
@@ -377,40 +482,46 @@ struct MatchOutArgs {
   int tree_is_1;    // pairs are (a1 index, a2 index): vo_complete.cpp:40-43
   int32_t* out;
   int* counts;
+  size_t best_stride, out_stride, counts_stride;   // per frame (blockIdx.y)
 };
 
 __global__ __launch_bounds__(CB) void match_count_kernel(MatchOutArgs a) {
   __shared__ int s_wave[CB / 64];
+  const unsigned long long* best = a.best + blockIdx.y * a.best_stride;
   const int q = blockIdx.x * CB + threadIdx.x;
-  const bool ok = q < a.nq && (unsigned)(a.best[q] & 0xffffffffull) != 0xffffffffu;
+  const bool ok = q < a.nq && (unsigned)(best[q] & 0xffffffffull) != 0xffffffffu;
   int total;
   block_rank(ok, s_wave, total);
-  if (threadIdx.x == 0) a.counts[blockIdx.x] = total;
+  if (threadIdx.x == 0) a.counts[blockIdx.y * a.counts_stride + blockIdx.x] = total;
 }
 
 __global__ __launch_bounds__(CB) void match_scatter_kernel(MatchOutArgs a) {
   __shared__ int s_wave[CB / 64];
+  const unsigned long long* best = a.best + blockIdx.y * a.best_stride;
+  int32_t* out = a.out + 2 * blockIdx.y * a.out_stride;
   const int q = blockIdx.x * CB + threadIdx.x;
   unsigned idx = 0xffffffffu;
-  if (q < a.nq) idx = (unsigned)(a.best[q] & 0xffffffffull);
+  if (q < a.nq) idx = (unsigned)(best[q] & 0xffffffffull);
   const bool ok = idx != 0xffffffffu;
   int total;
   const int r = block_rank(ok, s_wave, total);
   if (ok) {
-    const size_t dst = (size_t)a.counts[blockIdx.x] + r;
-    a.out[2 * dst] = a.tree_is_1 ? (int)idx : q;
-    a.out[2 * dst + 1] = a.tree_is_1 ? q : (int)idx;
+    const size_t dst = (size_t)a.counts[blockIdx.y * a.counts_stride + blockIdx.x] + r;
+    out[2 * dst] = a.tree_is_1 ? (int)idx : q;
+    out[2 * dst + 1] = a.tree_is_1 ? q : (int)idx;
   }
 }
 
 hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best, int nq, int tree_is_1,
-                                int32_t* d_out, int* d_n_out, int* d_scratch) {
-  MatchOutArgs a{d_best, nq, tree_is_1, d_out, d_scratch};
+                                int32_t* d_out, int* d_n_out, int* d_scratch, int n_frames, size_t best_stride,
+                                size_t out_stride) {
   const int nb = (nq + CB - 1) / CB;
-  if (nb > 0) hipLaunchKernelGGL(match_count_kernel, dim3(nb), dim3(CB), 0, st, a);
-  hipError_t e = launch_scan(st, d_scratch, nb, d_n_out);
+  const size_t cs = n_frames > 1 ? compaction_scratch_ints(nq) : 0;
+  MatchOutArgs a{d_best, nq, tree_is_1, d_out, d_scratch, best_stride, n_frames > 1 ? out_stride : 0, cs};
+  if (nb > 0) hipLaunchKernelGGL(match_count_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);
+  hipError_t e = launch_scan(st, d_scratch, nb, d_n_out, nullptr, n_frames, cs);
   if (e != hipSuccess) return e;
-  if (nb > 0) hipLaunchKernelGGL(match_scatter_kernel, dim3(nb), dim3(CB), 0, st, a);
+  if (nb > 0) hipLaunchKernelGGL(match_scatter_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);
   return hipGetLastError();
 }
 

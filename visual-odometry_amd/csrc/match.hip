@@ -26,19 +26,23 @@
 // order-independent, hence deterministic.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "vo_internal.h"
 
 namespace vo {
 
 hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best, int nq, int tree_is_1,
-                                int32_t* d_out, int* d_n_out, int* d_scratch);
+                                int32_t* d_out, int* d_n_out, int* d_scratch, int n_frames, size_t best_stride,
+                                size_t out_stride);
 
 constexpr int MB = 256;       // threads per workgroup
 constexpr int QPT = 2;        // queries per thread
 constexpr int TILE = 128;     // tree points per LDS tile (6 KiB)
 constexpr int TP = 12;        // padded floats per tree point in LDS
 
-__global__ __launch_bounds__(256) void match_init_kernel(unsigned long long* best, int nq, float r2) {
+__global__ __launch_bounds__(256) void match_init_kernel(unsigned long long* best, int nq, float r2, size_t best_stride) {
+  best += blockIdx.z * best_stride;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < nq) best[q] = ((unsigned long long)__float_as_uint(r2) << 32) | 0xffffffffull;
 }
@@ -46,7 +50,9 @@ __global__ __launch_bounds__(256) void match_init_kernel(unsigned long long* bes
 __global__ __launch_bounds__(MB) void match_kernel(const float* __restrict__ tree, int nt,
                                                    const float* __restrict__ qry, int nq,
                                                    int chunk, float r2,
-                                                   unsigned long long* __restrict__ best) {
+                                                   unsigned long long* __restrict__ best, size_t tree_stride,
+                                                   size_t qry_stride, size_t best_stride) {
+  tree += blockIdx.z * tree_stride; qry += blockIdx.z * qry_stride; best += blockIdx.z * best_stride;
   __shared__ __attribute__((aligned(16))) float s_t[TILE * TP];
   const int tid = threadIdx.x;
   const int q0 = (blockIdx.x * MB + tid) * QPT;
@@ -134,6 +140,19 @@ __global__ __launch_bounds__(MB) void match_kernel(const float* __restrict__ tre
 // changes no decision.  Inside the rectangle the scan is the exact one above
 // (4-term bit-exact prefix, then the remaining terms in the reference's order).
 // With no spread in A and B it degenerates to the full scan.
+// Batched use: blockIdx.z = frame.  Every per-frame array is base + frame * stride; the single-frame
+// entry points launch with gridDim.z = 1 and all strides 0.
+struct MatchStrides {
+  size_t tree, qry;     // floats between consecutive frames of the two input sets
+  size_t ws;            // bytes between consecutive frames' workspaces (identical internal layout)
+  size_t best;          // keys between consecutive frames
+  size_t mm;            // bytes between consecutive frames' min/max words (kept contiguous: one memset)
+};
+template <class T>
+__device__ __forceinline__ T* frame_ptr(T* p, size_t bytes) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + bytes);
+}
+
 constexpr int NBUCKET = 1024;
 constexpr int NA = 16;               // coarse cells
 constexpr int NB = NBUCKET / NA;     // fine buckets per cell
@@ -167,7 +186,9 @@ __device__ __forceinline__ float ord2f(unsigned o) {
 
 // mm[0..9] = ord(min), mm[10..19] = ~ord(max): both merge with atomicMin, one 0xff memset initialises all
 __global__ __launch_bounds__(256) void match_minmax_kernel(const float* __restrict__ a, int na,
-                                                           const float* __restrict__ b, int nb, unsigned* mm) {
+                                                           const float* __restrict__ b, int nb, unsigned* mm,
+                                                           MatchStrides ms) {
+  a += blockIdx.z * ms.tree; b += blockIdx.z * ms.qry; mm = frame_ptr(mm, blockIdx.z * ms.mm);
   __shared__ float s_lo[4][10], s_hi[4][10];
   float lo[10], hi[10];
 #pragma unroll
@@ -250,7 +271,10 @@ __device__ __forceinline__ void sort_slice(int nt, int nq, int& lo, int& hi) {
 __global__ __launch_bounds__(256) void match_bucket_hist_kernel(const float* __restrict__ tree, int nt,
                                                                 const float* __restrict__ qry, int nq,
                                                                 const unsigned* __restrict__ mm, float radius,
-                                                                BucketParams* bp_out, int* block_hist) {
+                                                                BucketParams* bp_out, int* block_hist, MatchStrides ms) {
+  tree += blockIdx.z * ms.tree; qry += blockIdx.z * ms.qry;
+  mm = frame_ptr(mm, blockIdx.z * ms.mm); bp_out = frame_ptr(bp_out, blockIdx.z * ms.ws);
+  block_hist = frame_ptr(block_hist, blockIdx.z * ms.ws);
   __shared__ int s_h[2 * NBUCKET];
   __shared__ BucketParams s_bp;
   for (int k = threadIdx.x; k < 2 * NBUCKET; k += 256) s_h[k] = 0;
@@ -272,7 +296,8 @@ __global__ __launch_bounds__(256) void match_bucket_hist_kernel(const float* __r
 }
 
 // grid 2 (tree half, query half) x NBUCKET threads (one bin each)
-__global__ __launch_bounds__(NBUCKET) void match_bucket_offsets_kernel(int* block_hist, int* starts) {
+__global__ __launch_bounds__(NBUCKET) void match_bucket_offsets_kernel(int* block_hist, int* starts, MatchStrides ms) {
+  block_hist = frame_ptr(block_hist, blockIdx.z * ms.ws); starts = frame_ptr(starts, blockIdx.z * ms.ws);
   __shared__ int s_w[NBUCKET / 64];
   const int half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int h[SORT_BLOCKS];
@@ -303,7 +328,11 @@ __global__ __launch_bounds__(256) void match_bucket_place_kernel(const float* __
                                                                  const float* __restrict__ qry, int nq,
                                                                  const BucketParams* __restrict__ bpp,
                                                                  const int* __restrict__ block_off, float* tree_rec,
-                                                                 float* qry_rec, unsigned long long* best, float r2) {
+                                                                 float* qry_rec, unsigned long long* best, float r2,
+                                                                 MatchStrides ms) {
+  tree += blockIdx.z * ms.tree; qry += blockIdx.z * ms.qry; best += blockIdx.z * ms.best;
+  bpp = frame_ptr(bpp, blockIdx.z * ms.ws); block_off = frame_ptr(block_off, blockIdx.z * ms.ws);
+  tree_rec = frame_ptr(tree_rec, blockIdx.z * ms.ws); qry_rec = frame_ptr(qry_rec, blockIdx.z * ms.ws);
   __shared__ int s_off[2 * NBUCKET];
   for (int k = threadIdx.x; k < 2 * NBUCKET; k += 256) s_off[k] = block_off[(size_t)blockIdx.x * 2 * NBUCKET + k];
   __syncthreads();
@@ -339,7 +368,10 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
                                                           const float* __restrict__ qry_rec, int nq,
                                                           const int* __restrict__ starts,
                                                           const BucketParams* __restrict__ bpp, int nchunks, float r2,
-                                                          unsigned long long* __restrict__ best) {
+                                                          unsigned long long* __restrict__ best, MatchStrides ms) {
+  tree_rec = frame_ptr(tree_rec, blockIdx.z * ms.ws); qry_rec = frame_ptr(qry_rec, blockIdx.z * ms.ws);
+  starts = frame_ptr(starts, blockIdx.z * ms.ws); bpp = frame_ptr(bpp, blockIdx.z * ms.ws);
+  best += blockIdx.z * ms.best;
   __shared__ __attribute__((aligned(16))) float s_t[TILE * TP];
   __shared__ int s_rng[4][MB / 64];
   const int tid = threadIdx.x;
@@ -474,70 +506,98 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
   }
 }
 
-size_t match_pruned_workspace_bytes(int nt, int nq) {
-  return sizeof(float) * 12 * ((size_t)nt + (size_t)nq) + sizeof(int) * ((size_t)SORT_BLOCKS * 2 * NBUCKET + 2 * (NBUCKET + 1) + 8) +
-         sizeof(BucketParams) + 32 * sizeof(unsigned) + 512;
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// per-frame block (sorted records, histograms, bucket starts, parameters)
+static size_t match_frame_ws_bytes(int nt, int nq) {
+  return align256(sizeof(float) * 12 * ((size_t)nt + (size_t)nq) +
+                  sizeof(int) * ((size_t)SORT_BLOCKS * 2 * NBUCKET + 2 * (NBUCKET + 1) + 8) + sizeof(BucketParams) + 512);
+}
+// whole workspace: the min/max words of all frames first (128 B each), then the per-frame blocks
+size_t match_pruned_workspace_bytes(int nt, int nq, int n_frames) {
+  return align256(128 * (size_t)n_frames) + (size_t)n_frames * match_frame_ws_bytes(nt, nq);
 }
 
 static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt, const float* qry, int nq,
-                                      float radius, float r2, unsigned long long* d_best, void* ws, int n_cu) {
-  // workspace carve (all offsets multiples of 16 bytes)
-  char* p = static_cast<char*>(ws);
+                                      float radius, float r2, unsigned long long* d_best, void* ws, int n_cu,
+                                      int n_frames, size_t tree_stride, size_t qry_stride, size_t best_stride) {
+  // workspace carve of frame 0 (all offsets multiples of 16 bytes); frame f lives ws_stride bytes further
+  unsigned* mm = static_cast<unsigned*>(ws);
+  char* p = static_cast<char*>(ws) + align256(128 * (size_t)n_frames);
   float* tree_rec = reinterpret_cast<float*>(p); p += sizeof(float) * 12 * (size_t)nt;
   float* qry_rec = reinterpret_cast<float*>(p); p += sizeof(float) * 12 * (size_t)nq;
   int* block_hist = reinterpret_cast<int*>(p); p += sizeof(int) * (size_t)SORT_BLOCKS * 2 * NBUCKET;
   int* starts = reinterpret_cast<int*>(p); p += sizeof(int) * (2 * (NBUCKET + 1) + 6);
-  BucketParams* bp = reinterpret_cast<BucketParams*>(p); p += 64;
-  unsigned* mm = reinterpret_cast<unsigned*>(p);
-  hipError_t e = hipMemsetAsync(mm, 0xff, 32 * sizeof(unsigned), st);
+  BucketParams* bp = reinterpret_cast<BucketParams*>(p);
+  MatchStrides ms;
+  ms.tree = tree_stride; ms.qry = qry_stride; ms.best = best_stride;
+  ms.ws = n_frames > 1 ? match_frame_ws_bytes(nt, nq) : 0;
+  ms.mm = 128;
+  const unsigned Z = (unsigned)n_frames;
+  hipError_t e = hipMemsetAsync(mm, 0xff, 128 * (size_t)n_frames, st);
   if (e != hipSuccess) return e;
   int g = (nt + nq + 255) / 256;
-  hipLaunchKernelGGL(match_minmax_kernel, dim3(g > 256 ? 256 : g), dim3(256), 0, st, tree, nt, qry, nq, mm);
-  hipLaunchKernelGGL(match_bucket_hist_kernel, dim3(SORT_BLOCKS), dim3(256), 0, st, tree, nt, qry, nq, mm, radius, bp,
-                     block_hist);
-  hipLaunchKernelGGL(match_bucket_offsets_kernel, dim3(2), dim3(NBUCKET), 0, st, block_hist, starts);
-  hipLaunchKernelGGL(match_bucket_place_kernel, dim3(SORT_BLOCKS), dim3(256), 0, st, tree, nt, qry, nq, bp, block_hist,
-                     tree_rec, qry_rec, d_best, r2);
+  hipLaunchKernelGGL(match_minmax_kernel, dim3(g > 256 ? 256 : g, 1, Z), dim3(256), 0, st, tree, nt, qry, nq, mm, ms);
+  hipLaunchKernelGGL(match_bucket_hist_kernel, dim3(SORT_BLOCKS, 1, Z), dim3(256), 0, st, tree, nt, qry, nq, mm, radius,
+                     bp, block_hist, ms);
+  hipLaunchKernelGGL(match_bucket_offsets_kernel, dim3(2, 1, Z), dim3(NBUCKET), 0, st, block_hist, starts, ms);
+  hipLaunchKernelGGL(match_bucket_place_kernel, dim3(SORT_BLOCKS, 1, Z), dim3(256), 0, st, tree, nt, qry, nq, bp,
+                     block_hist, tree_rec, qry_rec, d_best, r2, ms);
   const int qblocks = (nq + MB * QPT - 1) / (MB * QPT) + NA;   // upper bound: workgroups are aligned to A-cells
   static const int chunk_factor = [] { const char* e = getenv("VO_MATCH_CHUNK_FACTOR"); return e ? atoi(e) : 16; }();
-  int nchunks = (chunk_factor * (n_cu > 0 ? n_cu : 256) + qblocks - 1) / qblocks;
+  int nchunks = (chunk_factor * (n_cu > 0 ? n_cu : 256) + qblocks * n_frames - 1) / (qblocks * n_frames);
   if (nchunks < 1) nchunks = 1;
   if (nchunks > 64) nchunks = 64;
-  hipLaunchKernelGGL(match_pruned_kernel, dim3(qblocks, nchunks), dim3(MB), 0, st, tree_rec, nt, qry_rec, nq, starts,
-                     bp, nchunks, r2, d_best);
+  hipLaunchKernelGGL(match_pruned_kernel, dim3(qblocks, nchunks, Z), dim3(MB), 0, st, tree_rec, nt, qry_rec, nq, starts,
+                     bp, nchunks, r2, d_best, ms);
   return hipGetLastError();
 }
 
-hipError_t launch_match(hipStream_t st, const float* d_a1, int n1, const float* d_a2, int n2,
-                        float radius, int32_t* d_out_pairs, int* d_n_out,
-                        unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws) {
+// n_frames frames with identical set sizes; frame f reads a1 + f*a1_stride etc.  d_prune_ws holds
+// match_pruned_workspace_bytes(nt, nq, n_frames) bytes (or is null: full scan).
+hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t a1_stride, const float* d_a2, int n2,
+                              size_t a2_stride, float radius, int32_t* d_out_pairs, size_t out_stride, int* d_n_out,
+                              unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws, int n_frames) {
   const int tree_is_1 = n1 >= n2;                 // vo_complete.cpp:15-20 (ties: a1 is the tree)
   const float* tree = tree_is_1 ? d_a1 : d_a2;
   const float* qry = tree_is_1 ? d_a2 : d_a1;
+  const size_t ts = tree_is_1 ? a1_stride : a2_stride, qs = tree_is_1 ? a2_stride : a1_stride;
   const int nt = tree_is_1 ? n1 : n2, nq = tree_is_1 ? n2 : n1;
   const float r2 = radius * radius;
+  const size_t best_stride = n_frames > 1 ? (size_t)nq : 0;
+  const unsigned Z = (unsigned)n_frames;
   if (nq > 0 && nt > 0 && d_prune_ws) {
-    hipError_t ep = launch_match_pruned(st, tree, nt, qry, nq, radius, r2, d_best, d_prune_ws, n_cu);
+    hipError_t ep = launch_match_pruned(st, tree, nt, qry, nq, radius, r2, d_best, d_prune_ws, n_cu, n_frames, ts, qs,
+                                        best_stride);
     if (ep != hipSuccess) return ep;
   } else if (nq > 0) {
-    hipLaunchKernelGGL(match_init_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, d_best, nq, r2);
+    hipLaunchKernelGGL(match_init_kernel, dim3((nq + 255) / 256, 1, Z), dim3(256), 0, st, d_best, nq, r2, best_stride);
     if (nt > 0) {
       const int qblocks = (nq + MB * QPT - 1) / (MB * QPT);
       // enough tree chunks to put ~8 workgroups on every CU, whole tiles each
-      int want = (8 * (n_cu > 0 ? n_cu : 256) + qblocks - 1) / qblocks;
+      int want = (8 * (n_cu > 0 ? n_cu : 256) + qblocks * n_frames - 1) / (qblocks * n_frames);
       const int tiles = (nt + TILE - 1) / TILE;
       if (want > tiles) want = tiles;
       if (want < 1) want = 1;
       const int tiles_per_chunk = (tiles + want - 1) / want;
       const int chunk = tiles_per_chunk * TILE;
       const int nchunks = (nt + chunk - 1) / chunk;
-      hipLaunchKernelGGL(match_kernel, dim3(qblocks, nchunks), dim3(MB), 0, st, tree, nt, qry, nq,
-                         chunk, r2, d_best);
+      hipLaunchKernelGGL(match_kernel, dim3(qblocks, nchunks, Z), dim3(MB), 0, st, tree, nt, qry, nq, chunk, r2, d_best,
+                         n_frames > 1 ? ts : 0, n_frames > 1 ? qs : 0, best_stride);
     }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return launch_match_compact(st, d_best, nq, tree_is_1, d_out_pairs, d_n_out, d_scratch);
+  return launch_match_compact(st, d_best, nq, tree_is_1, d_out_pairs, d_n_out, d_scratch, n_frames, best_stride,
+                              out_stride);
+}
+
+hipError_t launch_match(hipStream_t st, const float* d_a1, int n1, const float* d_a2, int n2,
+                        float radius, int32_t* d_out_pairs, int* d_n_out,
+                        unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws) {
+  return launch_match_batch(st, d_a1, n1, 0, d_a2, n2, 0, radius, d_out_pairs, 0, d_n_out, d_best, d_scratch, n_cu,
+                            d_prune_ws, 1);
 }
 
 }  // namespace vo

@@ -104,8 +104,25 @@ hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const in
                        int32_t* d_out, int* d_n_out, int* d_table /* n_ref ints */,
                        int* d_scratch);
 
-// d_prune_ws: null -> full scan; else match_pruned_workspace_bytes(nt, nq) bytes -> bucket-pruned scan
-size_t match_pruned_workspace_bytes(int nt, int nq);
+// d_prune_ws: null -> full scan; else match_pruned_workspace_bytes(nt, nq, n_frames) bytes -> bucket-pruned scan
+size_t match_pruned_workspace_bytes(int nt, int nq, int n_frames);
+// n_frames frames of identical set sizes, frame f at base + f*stride (strides in floats / pairs);
+// d_best: n_frames*min(n1,n2) keys; d_scratch: n_frames * compaction_scratch_ints(min(n1,n2)) ints; d_n_out[n_frames]
+hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t a1_stride, const float* d_a2, int n2,
+                              size_t a2_stride, float radius, int32_t* d_out_pairs, size_t out_stride, int* d_n_out,
+                              unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws, int n_frames);
+hipError_t launch_transform_batch(hipStream_t st, const float* d_T16, const float* d_in, int n, size_t stride,
+                                  float* d_out, int n_frames);
+hipError_t launch_triangulate_batch(hipStream_t st, const float K[9], const Pose* X_host, const float* d_X16,
+                                    const int32_t* d_pairs, int n, const int* d_n, const float* d_p1, int n1,
+                                    const float* d_p2, int n2, const float* d_app2, float* d_out_xyz,
+                                    int32_t* d_out_pairs, float* d_out_app, int* d_n_out, int* d_scratch, int n_frames,
+                                    size_t pairs_stride, size_t p1_stride, size_t p2_stride, size_t out_stride);
+hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, const int* d_n_img,
+                             const int32_t* d_world, int n_world, const int* d_n_world, int n_ref, int32_t* d_out,
+                             int* d_n_out, int* d_table, int* d_scratch, int n_frames, size_t img_stride,
+                             size_t world_stride, size_t out_stride);
+
 hipError_t launch_match(hipStream_t st, const float* d_a1, int n1, const float* d_a2, int n2,
                         float radius, int32_t* d_out_pairs, int* d_n_out,
                         unsigned long long* d_best /* min(n1,n2) u64 */, int* d_scratch, int n_cu,

@@ -140,3 +140,87 @@ class FramePipeline:
                   self.d_m, self.d_j, self.d_model_t, self.d_tri_xyz, self.d_tri_pairs, self.d_tri_app,
                   self.d_counts, self.d_ident):
             self.ctx.free(d)
+
+
+class _FrameBatch(C.Structure):
+    """vo_frame_batch of include/vo_hip.h"""
+    _fields_ = [("n_frames", C.c_int), ("n_ref", C.c_int), ("n_cur", C.c_int), ("n_model", C.c_int),
+                ("n_model_pairs", C.c_int),
+                ("ref_app", C.c_void_p), ("cur_app", C.c_void_p), ("ref_pts", C.c_void_p), ("cur_pts", C.c_void_p),
+                ("model", C.c_void_p), ("model_pairs", C.c_void_p), ("X_prev", C.c_void_p),
+                ("rows", C.c_int), ("cols", C.c_int), ("z_near", C.c_int), ("z_far", C.c_int),
+                ("K", C.c_float * 9), ("kernel_threshold", C.c_float), ("keep_outliers", C.c_int),
+                ("n_iters", C.c_int), ("radius", C.c_float),
+                ("matches", C.c_void_p), ("joined", C.c_void_p), ("model_moved", C.c_void_p), ("poses", C.c_void_p),
+                ("stats", C.c_void_p), ("tri_xyz", C.c_void_p), ("tri_pairs", C.c_void_p), ("tri_app", C.c_void_p),
+                ("counts", C.c_void_p)]
+
+
+class BatchPipeline:
+    """n_frames independent frame pairs per call (vo_frames_batch_dev): every stage is one batched launch,
+    the solver is the batched kernel.  All frames must have the same set sizes."""
+
+    def __init__(self, ctx: Context, fps: list, n_iters: int = 50, kernel_threshold: float = 10000.0,
+                 with_appearance: bool = True):
+        self.ctx, self.lib = ctx, ctx.lib
+        F = self.F = len(fps)
+        f0 = fps[0]
+        self.n_ref, self.n_cur = len(f0["ref_app"]), len(f0["cur_app"])
+        self.n_model, self.n_mp = len(f0["model"]), len(f0["model_pairs"])
+        for f in fps:
+            assert (len(f["ref_app"]), len(f["cur_app"]), len(f["model"]), len(f["model_pairs"])) == \
+                (self.n_ref, self.n_cur, self.n_model, self.n_mp), "frames of a batch must have identical sizes"
+        self.q = min(self.n_ref, self.n_cur)
+        stack = lambda k, dt: np.ascontiguousarray(np.stack([np.asarray(f[k], dt) for f in fps]))
+        up = ctx.to_device
+        self._in = [up(stack("ref_app", np.float32)), up(stack("cur_app", np.float32)), up(stack("ref_pts", np.float32)),
+                    up(stack("cur_pts", np.float32)), up(stack("model", np.float32)), up(stack("model_pairs", np.int32))]
+        a = ctx.alloc
+        q = self.q
+        self.d_matches, self.d_joined = a(F * q * 8), a(F * q * 8)
+        self.d_moved, self.d_poses, self.d_stats = a(F * self.n_model * 12), a(F * 64), a(F * 16)
+        self.d_tri_xyz, self.d_tri_pairs = a(F * q * 12), a(F * q * 8)
+        self.d_tri_app = a(F * q * 40) if with_appearance else 0
+        self.d_counts = a(3 * F * 4)
+        b = self.b = _FrameBatch()
+        b.n_frames, b.n_ref, b.n_cur, b.n_model, b.n_model_pairs = F, self.n_ref, self.n_cur, self.n_model, self.n_mp
+        (b.ref_app, b.cur_app, b.ref_pts, b.cur_pts, b.model, b.model_pairs) = self._in
+        b.X_prev = None
+        b.rows, b.cols, b.z_near, b.z_far = int(f0["rows"]), int(f0["cols"]), int(f0["z_near"]), int(f0["z_far"])
+        b.K[:] = _colmajor(f0["K"], 3).tolist()
+        b.kernel_threshold, b.keep_outliers, b.n_iters, b.radius = kernel_threshold, 0, n_iters, 0.1
+        b.matches, b.joined, b.model_moved, b.poses, b.stats = self.d_matches, self.d_joined, self.d_moved, self.d_poses, self.d_stats
+        b.tri_xyz, b.tri_pairs, b.tri_app, b.counts = self.d_tri_xyz, self.d_tri_pairs, self.d_tri_app or None, self.d_counts
+
+    def run(self):
+        _chk(self.lib.vo_frames_batch_dev(self.ctx.h, C.byref(self.b)))
+
+    def counts(self):
+        c = np.zeros((3, self.F), np.int32)
+        self.ctx.d2h(c, self.d_counts)
+        return c
+
+    def poses(self):
+        T = np.zeros((self.F, 16), np.float32)
+        self.ctx.d2h(T, self.d_poses)
+        return np.ascontiguousarray(T.reshape(self.F, 4, 4).transpose(0, 2, 1))
+
+    def stats(self):
+        s = np.zeros((self.F, 4), np.float32)
+        self.ctx.d2h(s, self.d_stats)
+        return s
+
+    def fetch(self, what, f):
+        c = self.counts()
+        spec = {"match": (self.d_matches, c[0, f], 2, np.int32), "join": (self.d_joined, c[1, f], 2, np.int32),
+                "tri_xyz": (self.d_tri_xyz, c[2, f], 3, np.float32), "tri_pairs": (self.d_tri_pairs, c[2, f], 2, np.int32),
+                "tri_app": (self.d_tri_app, c[2, f], 10, np.float32)}[what]
+        out = np.zeros((int(spec[1]), spec[2]), spec[3])
+        if len(out):
+            self.ctx.d2h(out, spec[0] + f * self.q * spec[2] * 4)
+        return out
+
+    def close(self):
+        for d in self._in + [self.d_matches, self.d_joined, self.d_moved, self.d_poses, self.d_stats, self.d_tri_xyz,
+                             self.d_tri_pairs, self.d_counts] + ([self.d_tri_app] if self.d_tri_app else []):
+            self.ctx.free(d)
