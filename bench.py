@@ -186,31 +186,30 @@ def _chk(lib, rc):
         raise RuntimeError(lib.vo_last_error().decode())
 
 
-def frame_throughput(vo, args, streams=8, frames=30):
-    """Independent frame pairs in flight on `streams` HIP streams of this GPU, each replaying a
-    whole-frame hipGraph (config 4's mode of operation: independent pairs, no exchange)."""
-    ctxs = [vo.Context(0 if "LOCAL_RANK" not in os.environ else int(os.environ["LOCAL_RANK"])) for _ in range(streams)]
-    fps_in = [vo.synth.frame_pair(args.points, seed=6000 + i) for i in range(min(streams, 4))]
-    pipes = [vo.FramePipeline(c, fps_in[i % len(fps_in)], n_iters=args.iters) for i, c in enumerate(ctxs)]
-    for p in pipes:
-        p.capture_frame()
-    for c in ctxs:
-        c.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(frames):
-        for p in pipes:
-            p.frame_graph()
-    for c in ctxs:
-        c.synchronize()
-    dt = time.perf_counter() - t0
-    err = max(float(np.abs(p.pose() - fps_in[i % len(fps_in)]["X_gt"]).max()) for i, p in enumerate(pipes))
-    assert err < 1e-3, err
-    for p in pipes:
-        p.close()
-    for c in ctxs:
-        c.close()
-    return {"streams": streams, "frames_per_sec": streams * frames / dt, "pose_err_vs_gt": err,
-            "note": "one whole-frame hipGraph replay per frame and stream; kernels of different pairs overlap on the GPU"}
+def frame_throughput(vo, torch, ctx, stream, args, frames=200):
+    """BASELINE configs[3]'s per-GPU share: `frames` independent frame pairs resident in HBM, processed by
+    vo_frames_batch_dev (every stage one batched launch, frame = a grid dimension; batched solver)."""
+    distinct = [vo.synth.frame_pair(args.points, seed=6000 + i) for i in range(4)]
+    fps_in = [distinct[i % 4] for i in range(frames)]      # distinct copies in HBM; values repeat every 4 frames
+    bp = vo.BatchPipeline(ctx, fps_in, n_iters=args.iters)
+    bp.run()
+    ctx.synchronize()
+    reps = 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        bp.run()
+    e1.record(stream)
+    ctx.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    P = bp.poses()
+    err = max(float(np.abs(P[i] - fps_in[i]["X_gt"]).max()) for i in range(frames))
+    c = bp.counts()
+    assert err < 1e-3 and int(c[1].min()) == args.points, (err, c[:, :4])
+    bp.close()
+    return {"frames": frames, "ms_per_batch": ms, "frames_per_sec": frames / (ms * 1e-3), "us_per_frame": ms * 1e3 / frames,
+            "pose_err_vs_gt": err,
+            "note": "match + join + transform + 50 rounds + triangulate for every frame; one vo_frames_batch_dev call"}
 
 
 def frame_leg(torch, ctx, stream, pipe, fp, args, vo_mod=None):
@@ -249,10 +248,10 @@ def frame_leg(torch, ctx, stream, pipe, fp, args, vo_mod=None):
     ctx.synchronize()
     dt = time.perf_counter() - t0
     c = pipe.counts().tolist()
-    thr = frame_throughput(vo_mod, args) if vo_mod is not None else None
+    thr = frame_throughput(vo_mod, torch, ctx, stream, args) if vo_mod is not None else None
     n1, n2 = pipe.n_ref, pipe.n_cur
     match_flops = 30.0 * n1 * n2                     # 30 flop per (tree, query) pair
-    return {"frames_per_sec": args.frame_steps / dt, "ms_per_frame": dt * 1e3 / args.frame_steps, "throughput_mode": thr,
+    return {"frames_per_sec": args.frame_steps / dt, "ms_per_frame": dt * 1e3 / args.frame_steps, "batched_frames": thr,
             "counts": {"matches": c[0], "joined": c[1], "triangulated": c[2]}, **stages,
             "match_full_scan_equiv_tflops": match_flops / (stages["match_full_scan_ms"] * 1e-3) / 1e12,
             "match_note": "match_ms: default (bucket-pruned exact scan); match_full_scan_ms: every pair visited, "
