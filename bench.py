@@ -139,8 +139,8 @@ def main():
         "pose_err_vs_gt": pose_err, "num_inliers": n_in,
         "roofline": {"bound": "hbm", "kernel": "picp_round_kernel<true,false,true,false>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": _pmc_traffic("vo::picp_round_kernel<true, false, true, false>")[0],
-                     "traffic_note": _pmc_traffic("vo::picp_round_kernel<true, false, true, false>")[1],
+                     "traffic": _pmc_traffic("vo::picp_round_kernel<true, false, true, false>", 256 * ((args.points + 255) // 256))[0],
+                     "traffic_note": _pmc_traffic("vo::picp_round_kernel<true, false, true, false>", 256 * ((args.points + 255) // 256))[1],
                      "algorithmic_bytes_per_launch": alg_bytes, "launch_us": per_round_us,
                      "note": "one launch = one Gauss-Newton round over one 50k pair (1.0 MB, L2-resident): "
                              "latency-bound by the serial solve->linearize dependency, not by HBM; launch_us is "
@@ -165,16 +165,17 @@ def main():
         dist.destroy_process_group()
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch from the committed PMC summary (profiles/r01_pmc_fetch_write_v2.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very script).  Returns
-    (bytes, note) or (None, reason)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_v2.json")
+def _pmc_traffic(kernel, grid_threads):
+    """HBM bytes per launch from the committed PMC summary (profiles/r01_pmc_fetch_write_v3.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very script), for the launch
+    geometry `grid_threads`.  Returns (bytes, note) or (None, reason)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_v3.json")
     try:
         k = json.load(open(path))["kernels"][kernel]
-        fetch_kb, write_kb = k["FETCH_SIZE_KB_mean"], k["WRITE_SIZE_KB_mean"]
+        g = k["by_grid"][str(grid_threads)]
+        fetch_kb, write_kb = g["FETCH_SIZE_KB_max"], g["WRITE_SIZE_KB_max"]
     except (OSError, KeyError, ValueError):
-        return None, "no committed PMC summary for this kernel"
+        return None, "no committed PMC summary for this kernel and launch geometry"
     wide = k.get("wide_16B_loads", False)
     b = (2.0 * fetch_kb if wide else fetch_kb) * 1024.0 + write_kb * 1024.0
     return b, ("FETCH_SIZE x2 (gfx950 counts half of 16-B/lane coalesced reads) + WRITE_SIZE" if wide else
@@ -324,8 +325,8 @@ def _batched_run(torch, vo, ctx, stream, args, P):
             "pair_solves_per_sec": P / (ms * 1e-3), "pose_err_vs_gt": err,
             "roofline": {"bound": "hbm", "kernel": "picp_batch_kernel<true,false>", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": _pmc_traffic("vo::picp_batch_kernel<true, false>")[0] if (P, n, iters) == (200, 50000, 50) else None,
-                         "traffic_note": _pmc_traffic("vo::picp_batch_kernel<true, false>")[1],
+                         "traffic": _pmc_traffic("vo::picp_batch_kernel<true, false>", 768 * P)[0] if (n, iters) == (50000, 50) else None,
+                         "traffic_note": _pmc_traffic("vo::picp_batch_kernel<true, false>", 768 * P)[1],
                          "algorithmic_bytes_per_launch": alg,
                          "launch_us": kernel_ms * 1e3,
                          "note": f"{P} x {n} x 20 B x {iters} rounds of algorithmic bytes over kernel_ms = ms_per_call - "

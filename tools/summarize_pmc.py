@@ -16,22 +16,23 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        agg[name].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-    for k, v in agg.items():
+        agg[(name, int(r["Grid_Size"]))].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    for (k, grid), v in agg.items():
         if not k.startswith("vo::"):
             continue
-        d = out.setdefault(k, {})
+        # one entry per (kernel, grid size in threads): the same kernel runs at several problem sizes in one bench
+        d = out.setdefault(k, {"wide_16B_loads": k.startswith(WIDE), "by_grid": {}})["by_grid"].setdefault(str(grid), {})
         d[C + "_KB_mean"] = sum(x[0] for x in v) / len(v)
+        d[C + "_KB_max"] = max(x[0] for x in v)     # bench.py also launches the batch kernel with 0 rounds (gather-pass timing)
         d["launches_" + C] = len(v)
         d["dur_us_under_pmc"] = sum(x[1] for x in v) / len(v) / 1e3
-        d["wide_16B_loads"] = k.startswith(WIDE)
 json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 5 "
                       "--warmup 1 --cpu-seconds 0 --frame-steps 3   (one pass per counter; tools/collect_profiles.sh)",
            "units": "FETCH_SIZE / WRITE_SIZE are KB.  gfx950: FETCH_SIZE counts exactly half the bytes of wide (16 B/lane) "
                     "coalesced streaming reads (MI355X_MICROARCH.md, HBM) -> doubled where wide_16B_loads is true; other "
                     "access widths are uncalibrated and reported as counted",
-           "kernels": out}, open(dst + "_pmc_fetch_write_v2.json", "w"), indent=1, sort_keys=True)
-shutil.copy(glob.glob(f"{src}/stats/*/*kernel_stats.csv")[0], dst + "_bench_kernel_stats_v2.csv")
-for k in ("vo::picp_batch_kernel<true, false>", "vo::picp_round_kernel<true, false, true, false>", "vo::match_pruned_kernel"):
+           "kernels": out}, open(dst + "_pmc_fetch_write_v3.json", "w"), indent=1, sort_keys=True)
+shutil.copy(glob.glob(f"{src}/stats/*/*kernel_stats.csv")[0], dst + "_bench_kernel_stats_v3.csv")
+for k in ("vo::picp_batch_kernel<true, false>", "vo::picp_round_kernel<true, false, true, false>"):
     if k in out:
         print(k, json.dumps(out[k]))
