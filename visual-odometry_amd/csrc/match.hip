@@ -37,7 +37,9 @@ hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best
                                 size_t out_stride);
 
 constexpr int MB = 256;       // threads per workgroup
-constexpr int QPT = 2;        // queries per thread
+constexpr int QPT = 2;        // queries per thread (full scan)
+constexpr int QPP = 1;        // queries per thread (pruned scan)
+constexpr int MBP = 64;       // threads per workgroup (pruned scan): small query groups keep the scanned rectangle tight
 constexpr int TILE = 128;     // tree points per LDS tile (6 KiB)
 constexpr int TP = 12;        // padded floats per tree point in LDS
 
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256) void match_bucket_place_kernel(const float* __
   }
 }
 
-__global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restrict__ tree_rec, int nt,
+__global__ __launch_bounds__(MBP) void match_pruned_kernel(const float* __restrict__ tree_rec, int nt,
                                                           const float* __restrict__ qry_rec, int nq,
                                                           const int* __restrict__ starts,
                                                           const BucketParams* __restrict__ bpp, int nchunks, float r2,
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
   starts = frame_ptr(starts, blockIdx.z * ms.ws); bpp = frame_ptr(bpp, blockIdx.z * ms.ws);
   best += blockIdx.z * ms.best;
   __shared__ __attribute__((aligned(16))) float s_t[TILE * TP];
-  __shared__ int s_rng[4][MB / 64];
+  __shared__ int s_rng[4][MBP / 64];
   const int tid = threadIdx.x;
   const int* starts_t = starts;                       // [NBUCKET+1]
   const int* starts_q = starts + (NBUCKET + 1);
@@ -386,24 +388,24 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
     int wg = blockIdx.x;
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
-      const int nblk = (edge[r + 1] - edge[r] + MB * QPT - 1) / (MB * QPT);
+      const int nblk = (edge[r + 1] - edge[r] + MBP * QPP - 1) / (MBP * QPP);
       if (row < 0 && wg < nblk) {
         row = r;
-        qs = edge[r] + wg * MB * QPT;
-        qe = qs + MB * QPT < edge[r + 1] ? qs + MB * QPT : edge[r + 1];
+        qs = edge[r] + wg * MBP * QPP;
+        qe = qs + MBP * QPP < edge[r + 1] ? qs + MBP * QPP : edge[r + 1];
       }
       if (row < 0) wg -= nblk;
     }
   }
   if (row < 0) return;                                // surplus workgroup (grid is an upper bound)
   const BucketParams bp = *bpp;
-  const int q0 = qs + tid * QPT;
-  float q[QPT][10];
-  float bd[QPT];
-  int bi[QPT], qorig[QPT];
+  const int q0 = qs + tid * QPP;
+  float q[QPP][10];
+  float bd[QPP];
+  int bi[QPP], qorig[QPP];
   int aLo = NA, aHi = -1, bLo = NB, bHi = -1;
 #pragma unroll
-  for (int j = 0; j < QPT; ++j) {
+  for (int j = 0; j < QPP; ++j) {
     const bool live = q0 + j < qe;
     const int qi = live ? q0 + j : qe - 1;             // clamp: result discarded
     const float4* src = reinterpret_cast<const float4*>(qry_rec + 12 * (size_t)qi);
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
   if ((tid & 63) == 0) { s_rng[0][tid >> 6] = aLo; s_rng[1][tid >> 6] = aHi; s_rng[2][tid >> 6] = bLo; s_rng[3][tid >> 6] = bHi; }
   __syncthreads();
 #pragma unroll
-  for (int w = 0; w < MB / 64; ++w) {
+  for (int w = 0; w < MBP / 64; ++w) {
     aLo = s_rng[0][w] < aLo ? s_rng[0][w] : aLo; aHi = s_rng[1][w] > aHi ? s_rng[1][w] : aHi;
     bLo = s_rng[2][w] < bLo ? s_rng[2][w] : bLo; bHi = s_rng[3][w] > bHi ? s_rng[3][w] : bHi;
   }
@@ -456,17 +458,17 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
       __syncthreads();
       const float4* src = reinterpret_cast<const float4*>(tree_rec + 12 * (size_t)tb);
       float4* dst = reinterpret_cast<float4*>(s_t);
-      for (int f = tid; f < cnt * 3; f += MB) dst[f] = src[f];
+      for (int f = tid; f < cnt * 3; f += MBP) dst[f] = src[f];
       __syncthreads();
       float4 nxt = *reinterpret_cast<const float4*>(&s_t[0]);
 #pragma unroll 4
       for (int p = 0; p < cnt; ++p) {
         const float4 ta = nxt;
         nxt = *reinterpret_cast<const float4*>(&s_t[(p + 1 < cnt ? p + 1 : p) * TP]);   // next point's prefix, in flight
-        float pre[QPT];
+        float pre[QPP];
         bool any = false;
 #pragma unroll
-        for (int j = 0; j < QPT; ++j) {
+        for (int j = 0; j < QPP; ++j) {
           const float d0 = ta.x - q[j][0], d1 = ta.y - q[j][1], d2 = ta.z - q[j][2], d3 = ta.w - q[j][3];
           float s = d0 * d0;
           s += d1 * d1;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
           const float4 tb4 = *reinterpret_cast<const float4*>(&s_t[p * TP + 4]);
           const float4 tc = *reinterpret_cast<const float4*>(&s_t[p * TP + 8]);
 #pragma unroll
-          for (int j = 0; j < QPT; ++j) {
+          for (int j = 0; j < QPP; ++j) {
             float s = pre[j];
             float d;
             d = tb4.x - q[j][4]; s += d * d;
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(MB) void match_pruned_kernel(const float* __restric
     }
   }
 #pragma unroll
-  for (int j = 0; j < QPT; ++j) {
+  for (int j = 0; j < QPP; ++j) {
     if (bi[j] >= 0 && q0 + j < qe) {
       const unsigned long long key =
           ((unsigned long long)__float_as_uint(bd[j]) << 32) | (unsigned long long)(unsigned)bi[j];
@@ -544,12 +546,12 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
   hipLaunchKernelGGL(match_bucket_offsets_kernel, dim3(2, 1, Z), dim3(NBUCKET), 0, st, block_hist, starts, ms);
   hipLaunchKernelGGL(match_bucket_place_kernel, dim3(SORT_BLOCKS, 1, Z), dim3(256), 0, st, tree, nt, qry, nq, bp,
                      block_hist, tree_rec, qry_rec, d_best, r2, ms);
-  const int qblocks = (nq + MB * QPT - 1) / (MB * QPT) + NA;   // upper bound: workgroups are aligned to A-cells
+  const int qblocks = (nq + MBP * QPP - 1) / (MBP * QPP) + NA;   // upper bound: workgroups are aligned to A-cells
   static const int chunk_factor = [] { const char* e = getenv("VO_MATCH_CHUNK_FACTOR"); return e ? atoi(e) : 16; }();
   int nchunks = (chunk_factor * (n_cu > 0 ? n_cu : 256) + qblocks * n_frames - 1) / (qblocks * n_frames);
   if (nchunks < 1) nchunks = 1;
   if (nchunks > 64) nchunks = 64;
-  hipLaunchKernelGGL(match_pruned_kernel, dim3(qblocks, nchunks, Z), dim3(MB), 0, st, tree_rec, nt, qry_rec, nq, starts,
+  hipLaunchKernelGGL(match_pruned_kernel, dim3(qblocks, nchunks, Z), dim3(MBP), 0, st, tree_rec, nt, qry_rec, nq, starts,
                      bp, nchunks, r2, d_best, ms);
   return hipGetLastError();
 }
