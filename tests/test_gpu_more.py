@@ -175,3 +175,32 @@ def test_batched_frames_equal_single_frames(vo, o32, n, F):
         assert np.array_equal(bp.fetch("tri_pairs", i), po) and np.array_equal(bp.fetch("tri_app", i), ao)
         assert np.all(np.abs(bp.fetch("tri_xyz", i) - xo) <= 1e-4 * np.maximum(1, np.abs(xo)))
     bp.close(); c.close()
+
+
+def test_device_pose_reset_and_in_place_pose(vo, ctx, o32):
+    """vo_picp_set_pose_dev takes effect at the next solve (folded into the gather launch, or a launch of
+    its own when the correspondences are cached); vo_picp_pose_dev_ptr exposes the result in place."""
+    fp = vo.synth.frame_pair(2500, seed=305)
+    corr = _corr(fp)
+    cam = vo.Camera(480, 640, 0, 10, fp["K"], np.eye(4), ctx=ctx)
+    s = vo.PICPSolver(ctx); s.setKernelThreshold(10000.0)
+    s.init(cam, fp["model"], fp["cur_pts"])
+    s.solve(corr, False, 7)
+    T1 = s.camera().worldInCameraPose().copy()
+    d_I = ctx.to_device(np.eye(4, dtype=np.float32))
+    lib = ctx.lib
+    for expect_repack in (False, True):
+        assert lib.vo_picp_set_pose_dev(s.h, C.c_void_p(d_I)) == 0
+        if expect_repack:
+            corr = corr.copy()                       # new host array: uploaded and gathered again
+        s.solve(corr, False, 7)
+        assert s.camera().worldInCameraPose().tobytes() == T1.tobytes()      # same start, same bits
+    p = C.c_void_p()
+    assert lib.vo_picp_pose_dev_ptr(s.h, C.byref(p)) == 0 and p.value
+    T = np.zeros(16, np.float32)
+    ctx.d2h(T, p.value)
+    assert T.reshape(4, 4).T.tobytes() == T1.tobytes()
+    s.solve(corr, False, 3)                          # without a reset the solve continues from the current pose
+    r = o32.picp_solve(OCam(480, 640, 0, 10, fp["K"], np.eye(4)), fp["model"], fp["cur_pts"], corr, 10, 10000.0, False, trace=False)
+    assert np.abs(s.camera().worldInCameraPose() - r["T"]).max() < 1e-4
+    ctx.free(d_I); s.close()
