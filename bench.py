@@ -148,6 +148,10 @@ def main():
     }
 
     legs = set() if args.no_extras else set(args.legs.split(","))
+    if "frame" in legs and args.frame_steps > 0:           # every rank: config 4 (sharded pairs + pose gather)
+        with torch.cuda.stream(stream):
+            cfg4 = frame_throughput(vo, torch, ctx, stream, args, dist, vdist, rank, world)
+        out["batched_frames"] = cfg4
     if rank == 0 and legs:
         with torch.cuda.stream(stream):
             if args.frame_steps > 0 and "frame" in legs:
@@ -187,30 +191,45 @@ def _chk(lib, rc):
         raise RuntimeError(lib.vo_last_error().decode())
 
 
-def frame_throughput(vo, torch, ctx, stream, args, frames=200):
-    """BASELINE configs[3]'s per-GPU share: `frames` independent frame pairs resident in HBM, processed by
-    vo_frames_batch_dev (every stage one batched launch, frame = a grid dimension; batched solver)."""
-    distinct = [vo.synth.frame_pair(args.points, seed=6000 + i) for i in range(4)]
+def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0, world=1, frames=200):
+    """BASELINE configs[3]: `frames` independent frame pairs per GPU resident in HBM, processed by
+    vo_frames_batch_dev (every stage one batched launch, frame = a grid dimension; batched solver); with
+    several ranks every rank owns its block of pairs and the job ends with ONE RCCL all-gather of the poses.
+    Called by every rank; timing bracketed by barrier + synchronize, max over ranks."""
+    distinct = [vo.synth.frame_pair(args.points, seed=6000 + 4 * rank + i) for i in range(4)]
     fps_in = [distinct[i % 4] for i in range(frames)]      # distinct copies in HBM; values repeat every 4 frames
-    bp = vo.BatchPipeline(ctx, fps_in, n_iters=args.iters)
+    poses_t = torch.zeros((frames, 16), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+    bp = vo.BatchPipeline(ctx, fps_in, n_iters=args.iters, poses_ptr=poses_t.data_ptr())
     bp.run()
     ctx.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
     reps = 3
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
+    barrier()
+    t0 = time.perf_counter()
     for _ in range(reps):
         bp.run()
-    e1.record(stream)
-    ctx.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+        if dist is not None:
+            all_poses = vdist.gather_poses(poses_t)        # (world*frames, 16), rank-major = global pair order
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dt = vdist.max_over_ranks(dt, poses_t.device)
+        assert all_poses.shape == (world * frames, 16)
+        assert torch.equal(all_poses[rank * frames:(rank + 1) * frames], poses_t)
+    ms = dt * 1e3 / reps
     P = bp.poses()
     err = max(float(np.abs(P[i] - fps_in[i]["X_gt"]).max()) for i in range(frames))
     c = bp.counts()
     assert err < 1e-3 and int(c[1].min()) == args.points, (err, c[:, :4])
     bp.close()
-    return {"frames": frames, "ms_per_batch": ms, "frames_per_sec": frames / (ms * 1e-3), "us_per_frame": ms * 1e3 / frames,
-            "pose_err_vs_gt": err,
-            "note": "match + join + transform + 50 rounds + triangulate for every frame; one vo_frames_batch_dev call"}
+    return {"frames_per_gpu": frames, "n_gpus": world, "frames_total": frames * world, "ms_per_batch": ms,
+            "frames_per_sec": frames * world / (ms * 1e-3), "us_per_frame_per_gpu": ms * 1e3 / frames, "pose_err_vs_gt": err,
+            "note": "match + join + transform + 50 rounds + triangulate for every frame, one vo_frames_batch_dev call per "
+                    "rank" + ("; + one all_gather_into_tensor of the poses per batch" if dist is not None else "")}
 
 
 def frame_leg(torch, ctx, stream, pipe, fp, args, vo_mod=None):
@@ -249,10 +268,9 @@ def frame_leg(torch, ctx, stream, pipe, fp, args, vo_mod=None):
     ctx.synchronize()
     dt = time.perf_counter() - t0
     c = pipe.counts().tolist()
-    thr = frame_throughput(vo_mod, torch, ctx, stream, args) if vo_mod is not None else None
     n1, n2 = pipe.n_ref, pipe.n_cur
     match_flops = 30.0 * n1 * n2                     # 30 flop per (tree, query) pair
-    return {"frames_per_sec": args.frame_steps / dt, "ms_per_frame": dt * 1e3 / args.frame_steps, "batched_frames": thr,
+    return {"frames_per_sec": args.frame_steps / dt, "ms_per_frame": dt * 1e3 / args.frame_steps, 
             "counts": {"matches": c[0], "joined": c[1], "triangulated": c[2]}, **stages,
             "match_full_scan_equiv_tflops": match_flops / (stages["match_full_scan_ms"] * 1e-3) / 1e12,
             "match_note": "match_ms: default (bucket-pruned exact scan); match_full_scan_ms: every pair visited, "

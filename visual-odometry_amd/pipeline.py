@@ -161,7 +161,9 @@ class BatchPipeline:
     the solver is the batched kernel.  All frames must have the same set sizes."""
 
     def __init__(self, ctx: Context, fps: list, n_iters: int = 50, kernel_threshold: float = 10000.0,
-                 with_appearance: bool = True):
+                 with_appearance: bool = True, poses_ptr: int | None = None):
+        """poses_ptr: optional device buffer (n_frames*16 floats, e.g. a torch tensor's data_ptr) that
+        receives the poses directly, so that a collective can read them without a copy."""
         self.ctx, self.lib = ctx, ctx.lib
         F = self.F = len(fps)
         f0 = fps[0]
@@ -178,7 +180,8 @@ class BatchPipeline:
         a = ctx.alloc
         q = self.q
         self.d_matches, self.d_joined = a(F * q * 8), a(F * q * 8)
-        self.d_moved, self.d_poses, self.d_stats = a(F * self.n_model * 12), a(F * 64), a(F * 16)
+        self._own_poses = poses_ptr is None
+        self.d_moved, self.d_poses, self.d_stats = a(F * self.n_model * 12), (a(F * 64) if poses_ptr is None else poses_ptr), a(F * 16)
         self.d_tri_xyz, self.d_tri_pairs = a(F * q * 12), a(F * q * 8)
         self.d_tri_app = a(F * q * 40) if with_appearance else 0
         self.d_counts = a(3 * F * 4)
@@ -221,6 +224,7 @@ class BatchPipeline:
         return out
 
     def close(self):
-        for d in self._in + [self.d_matches, self.d_joined, self.d_moved, self.d_poses, self.d_stats, self.d_tri_xyz,
-                             self.d_tri_pairs, self.d_counts] + ([self.d_tri_app] if self.d_tri_app else []):
+        for d in self._in + [self.d_matches, self.d_joined, self.d_moved, self.d_stats, self.d_tri_xyz,
+                             self.d_tri_pairs, self.d_counts] + ([self.d_tri_app] if self.d_tri_app else []) + \
+                ([self.d_poses] if self._own_poses else []):
             self.ctx.free(d)
