@@ -47,7 +47,11 @@ def parse():
     ap.add_argument("--frame-steps", type=int, default=30, help="frames of the whole-frame leg (0: skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU-baseline leg (0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="headline measurement only")
-    ap.add_argument("--legs", default="frame,batched,cpu", help="extra legs to run (comma list of frame,batched,cpu)")
+    ap.add_argument("--legs", default="frame,batched,sequence,cpu",
+                    help="extra legs to run (comma list of frame,batched,sequence,cpu)")
+    ap.add_argument("--seq-frames", type=int, default=200, help="frames of the sequence leg (config 3)")
+    ap.add_argument("--seq-points", type=int, default=50000, help="landmarks in view per frame in the sequence leg")
+    ap.add_argument("--seq-iters", type=int, default=100, help="PICP rounds per frame in the sequence leg (vo_complete.cpp:163)")
     return ap.parse_args()
 
 
@@ -158,6 +162,8 @@ def main():
                 out["frame"] = frame_leg(torch, ctx, stream, pipe, fp, args, vo)
             if args.batch_pairs > 0 and "batched" in legs:
                 out["batched"] = batched_leg(torch, vo, ctx, stream, args)
+            if args.seq_frames >= 3 and "sequence" in legs:
+                out["sequence"] = sequence_leg(vo, ctx, args)
         if args.cpu_seconds > 0 and world == 1 and "cpu" in legs:
             out["cpu_baseline"] = cpu_leg(fp, pipe, args)
     pipe.close()
@@ -276,6 +282,57 @@ def frame_leg(torch, ctx, stream, pipe, fp, args, vo_mod=None):
             "match_note": "match_ms: default (bucket-pruned exact scan); match_full_scan_ms: every pair visited, "
                           "bit-exact 3-term early exit; equiv_tflops = 30*N1*N2 flop / time (brute-force-equivalent "
                           "rate, not executed flops)"}
+
+
+def sequence_leg(vo, ctx, args):
+    """BASELINE configs[2]: a serial synthetic sequence (epipolar initialisation, then per frame
+    match -> join -> transform -> seq_iters rounds -> triangulate), everything resident in HBM."""
+    t0 = time.perf_counter()
+    seq = vo.synth.sequence(seed=3000, n_frames=args.seq_frames, n_visible=args.seq_points)
+    t_gen = time.perf_counter() - t0
+    sp = vo.SequencePipeline(ctx, seq, n_iters=args.seq_iters)
+    sp.run(); ctx.synchronize()                      # warm-up pass: sizes every workspace, builds the solver graph
+    t0 = time.perf_counter()
+    sp.initialise(); ctx.synchronize()
+    t1 = time.perf_counter()
+    for t in range(2, sp.F):
+        sp.step(t)
+    ctx.synchronize()
+    t2 = time.perf_counter()
+    traj, counts = sp.trajectory(), sp.counts()
+    sp.close()
+    m = _sequence_metrics(vo, seq, traj)
+    n = [len(f["pts"]) for f in seq["frames"]]
+    return {"frames": sp.F, "points_per_frame": {"min": int(min(n)), "max": int(max(n))}, "landmarks": len(seq["world_xyz"]),
+            "iters_per_frame": args.seq_iters, "init_ms": (t1 - t0) * 1e3,
+            "chain_ms": (t2 - t1) * 1e3, "frames_per_sec": (sp.F - 2) / (t2 - t1),
+            "ms_per_frame": (t2 - t1) * 1e3 / (sp.F - 2),
+            "picp_iters_per_sec": (sp.F - 2) * args.seq_iters / (t2 - t1),
+            "joined_per_frame": {"min": int(counts[2:, 1].min()), "max": int(counts[2:, 1].max())},
+            "accuracy_vs_ground_truth": m, "generate_s": t_gen,
+            "note": "init = match + vo_estimate_transform (host 8-point, once) + triangulate of the first pair; "
+                    "chain = frames 2.. enqueued back to back with no host synchronisation; "
+                    "accuracy: relative poses against the generator's ground truth (evaluate.cpp's measures)"}
+
+
+def _sequence_metrics(vo, seq, traj):
+    """evaluate.cpp:18-86 on relative camera poses: rotation part of X_est^-1 X_gt, translation-norm
+    ratio (its median fixes the monocular scale), position RMSE of the chained trajectory after scaling."""
+    Xgt = vo.synth.sequence_gt_relative(seq)
+    e_rot, ratio = [], []
+    for t in range(1, len(traj)):
+        Xe = traj[t].astype(np.float64)
+        e_rot.append(float(np.trace(np.eye(3) - Xe[:3, :3].T @ Xgt[t - 1][:3, :3])))
+        ratio.append(float(np.linalg.norm(Xe[:3, 3]) / np.linalg.norm(Xgt[t - 1][:3, 3])))
+    r = float(np.median(ratio))
+    We, Wg = np.eye(4), np.eye(4)
+    err = []
+    for t in range(1, len(traj)):
+        We = We @ np.linalg.inv(traj[t].astype(np.float64)); Wg = Wg @ np.linalg.inv(Xgt[t - 1])
+        err.append(np.linalg.norm(We[:3, 3] / r - Wg[:3, 3]) ** 2)
+    return {"mean_orientation_error": float(np.mean(e_rot)), "max_orientation_error": float(np.max(np.abs(e_rot))),
+            "scale_ratio_median": r, "scale_ratio_drift": float(max(ratio) / min(ratio) - 1.0),
+            "rmse_position": float(np.sqrt(np.mean(err))), "path_length": float(seq["step"] * (len(traj) - 1))}
 
 
 def batched_leg(torch, vo, ctx, stream, args):

@@ -89,9 +89,13 @@ inline IsometryPair essential2transformPair(const Matrix3f& E) {
   return IsometryPair(make(R1), make(R2));
 }
 
-//! epipolar_utils.cpp:176-213 -- pose of the first camera in the frame of the second
-inline Isometry3f estimate_transform(const Matrix3f k, const IntPairVector& correspondences,
-                                     const Vector2fVector& p1_img, const Vector2fVector& p2_img) {
+//! epipolar_utils.cpp:176-213 with the cheirality count abstracted: count_in_front(X) returns the number of
+//! correspondences that triangulate successfully under the candidate X (the reference calls
+//! triangulate_points v1 and uses its return value, :196-209).  Strict '>' keeps the first best candidate.
+template <class CountInFront>
+inline Isometry3f estimate_transform_with(const Matrix3f k, const IntPairVector& correspondences,
+                                          const Vector2fVector& p1_img, const Vector2fVector& p2_img,
+                                          CountInFront&& count_in_front) {
   const Matrix3f F = estimate_fundamental(correspondences, p1_img, p2_img);
   linalg::Mat3d kd, Fd;
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { kd.m[i][j] = k(i, j); Fd.m[i][j] = F(i, j); }
@@ -101,14 +105,22 @@ inline Isometry3f estimate_transform(const Matrix3f k, const IntPairVector& corr
   const IsometryPair X12 = essential2transformPair(E);
   int n_in_front = 0;
   Isometry3f X_best = Isometry3f::Identity();
-  Vector3fVector triang;
   for (int cand = 0; cand < 4; ++cand) {                      // :187-211
     Isometry3f X_test = cand < 2 ? X12.first : X12.second;
     if (cand & 1) { X_test(0, 3) = -X_test(0, 3); X_test(1, 3) = -X_test(1, 3); X_test(2, 3) = -X_test(2, 3); }
-    const int n_test = triangulate_points(k, X_test, correspondences, p1_img, p2_img, triang);
+    const int n_test = count_in_front(X_test);
     if (n_test > n_in_front) { n_in_front = n_test; X_best = X_test; }
   }
   return X_best;
+}
+
+//! epipolar_utils.cpp:176-213 -- pose of the first camera in the frame of the second
+inline Isometry3f estimate_transform(const Matrix3f k, const IntPairVector& correspondences,
+                                     const Vector2fVector& p1_img, const Vector2fVector& p2_img) {
+  Vector3fVector triang;
+  return estimate_transform_with(k, correspondences, p1_img, p2_img, [&](const Isometry3f& X_test) {
+    return triangulate_points(k, X_test, correspondences, p1_img, p2_img, triang);
+  });
 }
 
 }  // namespace vo

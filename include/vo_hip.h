@@ -187,8 +187,12 @@ int vo_join_correspondences_dev(vo_ctx *ctx, const int32_t *d_img_pairs, int n_i
 /* ---- Isometry3f * point set (PointCloud.h:77-82, vo_daKnown.cpp:144) --- */
 int vo_transform_points(vo_ctx *ctx, const float T[16], const float *in_xyz, int n,
                         float *out_xyz);
-int vo_transform_points_dev(vo_ctx *ctx, const float T[16], const float *d_in_xyz, int n,
-                            const int *d_n, float *d_out_xyz);
+/* device form: the isometry comes from the host (T) or, when d_T16 is non-NULL, from device
+ * memory (column-major 4x4, e.g. vo_picp_pose_dev_ptr of the previous frame's solve -- the
+ * X_curr * triangulated_pc of vo_complete.cpp:159 with no host round trip); d_n (may be NULL)
+ * points at a device count <= n. */
+int vo_transform_points_dev(vo_ctx *ctx, const float T[16], const float *d_T16,
+                            const float *d_in_xyz, int n, const int *d_n, float *d_out_xyz);
 
 /* ---- triangulate_points (utils.cpp:51-134; triangulate_point :36-49) --- */
 /* pairs = (index in p1, index in p2); X = pose of the first camera in the
@@ -203,6 +207,18 @@ int vo_triangulate_dev(vo_ctx *ctx, const float K[9], const float X[16], const f
                        const int32_t *d_pairs, int n, const int *d_n, const float *d_p1_uv, int n1,
                        const float *d_p2_uv, int n2, const float *d_app2, float *d_out_xyz,
                        int32_t *d_out_pairs, float *d_out_app, int *d_n_out);
+
+/* ---- estimate_transform (epipolar_utils.cpp:176-213) --------------------- */
+/* Relative pose of the first camera in the frame of the second from >= 8 image correspondences
+ * pairs = (index in p1, index in p2): normalised 8-point fundamental (:103-144, normalisation over
+ * ALL n1 / n2 points, :48-65), E = K^T F K, the four (R, +-t) candidates (:146-174) and the
+ * cheirality vote, which runs the triangulation kernel once per candidate and keeps the first
+ * candidate with the most survivors.  Host linear algebra in double (once per sequence).
+ * As in the reference t is read off R*E un-normalised (:163-164): |t| is the singular value
+ * of E, which is what fixes the scale of a monocular sequence.  Fewer than 8 pairs:
+ * VO_ERR_INVALID_ARG (the reference prints and exits, :105-108). */
+int vo_estimate_transform(vo_ctx *ctx, const float K[9], const int32_t *pairs, int n,
+                          const float *p1_uv, int n1, const float *p2_uv, int n2, float X_out[16]);
 
 /* ---- many independent frame pairs at once (throughput form of vo_complete.cpp:156-173) ---- */
 /* For each of n_frames independent frame pairs: match -> join -> X_prev * model -> n_iters rounds

@@ -6,7 +6,7 @@ The directory name carries a hyphen, so the package is loaded through
 `__graft_entry__.load_package()` under the module name `visual_odometry_amd`.
 """
 from . import synth  # noqa: F401  (data generation only)
-from .pipeline import BatchPipeline, FramePipeline  # noqa: F401
+from .pipeline import BatchPipeline, FramePipeline, SequencePipeline  # noqa: F401
 from .api import (  # noqa: F401
     Camera,
     Context,
@@ -14,6 +14,7 @@ from .api import (  # noqa: F401
     VoError,
     compute_correspondences_images,
     default_context,
+    estimate_transform,
     extract_correspondences_world,
     load_library,
     transform_points,

@@ -315,3 +315,16 @@ def transform_points(X, points, ctx: Context | None = None):
     out = np.zeros_like(p)
     _chk(ctx.lib.vo_transform_points(ctx.h, _ptr(_colmajor(X, 4)), _ptr(p), C.c_int(len(p)), _ptr(out)))
     return out
+
+
+def estimate_transform(k, correspondences, p1_img, p2_img, ctx: Context | None = None):
+    """epipolar_utils.cpp:176-213: relative pose (first camera in the frame of the second) from >= 8
+    image correspondences; the cheirality vote runs the GPU triangulation kernel."""
+    ctx = ctx or default_context()
+    pairs = _i32pairs(correspondences)
+    a = _f32(p1_img, (-1, 2))
+    b = _f32(p2_img, (-1, 2))
+    X = np.zeros(16, dtype=np.float32)
+    _chk(ctx.lib.vo_estimate_transform(ctx.h, _ptr(_colmajor(k, 3)), _ptr(pairs), C.c_int(len(pairs)), _ptr(a),
+                                       C.c_int(len(a)), _ptr(b), C.c_int(len(b)), _ptr(X)))
+    return X.reshape(4, 4).T.copy()

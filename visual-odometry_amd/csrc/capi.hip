@@ -12,6 +12,7 @@
 
 #include "../../include/vo_hip.h"
 #include "vo_internal.h"
+#include "../../include/vo/epipolar.hpp"   // host linear algebra of vo_estimate_transform
 
 using namespace vo;
 
@@ -816,12 +817,13 @@ int vo_join_correspondences(vo_ctx* c, const int32_t* img, int n_img, const int3
 }
 
 // ---- transform ------------------------------------------------------------------------------
-int vo_transform_points_dev(vo_ctx* c, const float T[16], const float* d_in, int n, const int* d_n,
-                            float* d_out) {
-  VO_REQUIRE(c && T, "null argument");
+int vo_transform_points_dev(vo_ctx* c, const float T[16], const float* d_T16, const float* d_in, int n,
+                            const int* d_n, float* d_out) {
+  VO_REQUIRE(c && (T || d_T16), "null argument");
   VO_REQUIRE(n >= 0 && (n == 0 || (d_in && d_out)), "bad point arrays");
   if (int r = set_device(c)) return r;
-  VO_HIP_CHECK(launch_transform_points(c->stream, pose_from_T16(T), d_in, n, d_n, d_out));
+  if (d_T16) VO_HIP_CHECK(launch_transform_points_devpose(c->stream, d_T16, d_in, n, d_n, d_out));
+  else VO_HIP_CHECK(launch_transform_points(c->stream, pose_from_T16(T), d_in, n, d_n, d_out));
   return VO_OK;
 }
 
@@ -832,7 +834,7 @@ int vo_transform_points(vo_ctx* c, const float T[16], const float* in, int n, fl
   if (int r = set_device(c)) return r;
   if (int r = upload(c, c->in[0], in, sizeof(float) * 3 * (size_t)n)) return r;
   VO_HIP_CHECK(c->out[0].ensure(sizeof(float) * 3 * (size_t)n, c->stream));
-  if (int r = vo_transform_points_dev(c, T, c->in[0].as<float>(), n, nullptr, c->out[0].as<float>())) return r;
+  if (int r = vo_transform_points_dev(c, T, nullptr, c->in[0].as<float>(), n, nullptr, c->out[0].as<float>())) return r;
   VO_HIP_CHECK(hipMemcpyAsync(out, c->out[0].p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
   VO_HIP_CHECK(hipStreamSynchronize(c->stream));
   return VO_OK;
@@ -888,6 +890,48 @@ int vo_triangulate(vo_ctx* c, const float K[9], const float X[16], const int32_t
     if (want_app) VO_HIP_CHECK(hipMemcpy(out_app, c->out[2].p, sizeof(float) * 10 * (size_t)h, hipMemcpyDeviceToHost));
   }
   *n_out = h;
+  return VO_OK;
+}
+
+// ---- epipolar initialisation (epipolar_utils.cpp:176-213) --------------------------------------
+int vo_estimate_transform(vo_ctx* c, const float K[9], const int32_t* pairs, int n, const float* p1, int n1,
+                          const float* p2, int n2, float X_out[16]) {
+  VO_REQUIRE(c && K && pairs && p1 && p2 && X_out, "null argument");
+  VO_REQUIRE(n >= 8, "fewer than 8 correspondences");
+  VO_REQUIRE(n1 > 0 && n2 > 0, "empty point set");
+  for (int i = 0; i < n; ++i)
+    if (pairs[2 * i] < 0 || pairs[2 * i] >= n1 || pairs[2 * i + 1] < 0 || pairs[2 * i + 1] >= n2)
+      return fail(VO_ERR_BAD_INDEX, "vo_estimate_transform: pair %d = (%d,%d) outside the point arrays", i,
+                  pairs[2 * i], pairs[2 * i + 1]);
+  if (int r = set_device(c)) return r;
+  // device copies once; the four candidates are scored by the triangulation kernel in count-only use
+  if (int r = upload(c, c->in[0], pairs, sizeof(int32_t) * 2 * (size_t)n)) return r;
+  if (int r = upload(c, c->in[1], p1, sizeof(float) * 2 * (size_t)n1)) return r;
+  if (int r = upload(c, c->in[2], p2, sizeof(float) * 2 * (size_t)n2)) return r;
+  VO_HIP_CHECK(c->out[0].ensure(sizeof(float) * 3 * (size_t)n, c->stream));
+  if (int r = ensure_counts(c)) return r;
+  vo::Matrix3f k;
+  for (int j = 0; j < 9; ++j) k.m[j] = K[j];
+  vo::IntPairVector corr((size_t)n);
+  for (int i = 0; i < n; ++i) corr[(size_t)i] = vo::IntPair(pairs[2 * i], pairs[2 * i + 1]);
+  vo::Vector2fVector a((size_t)n1), b((size_t)n2);
+  memcpy((void*)a.data(), p1, sizeof(float) * 2 * (size_t)n1);
+  memcpy((void*)b.data(), p2, sizeof(float) * 2 * (size_t)n2);
+  int rc = VO_OK;
+  const vo::Isometry3f X = vo::estimate_transform_with(k, corr, a, b, [&](const vo::Isometry3f& X_test) {
+    if (rc != VO_OK) return 0;
+    rc = vo_triangulate_dev(c, K, X_test.data(), nullptr, c->in[0].as<int32_t>(), n, nullptr, c->in[1].as<float>(), n1,
+                            c->in[2].as<float>(), n2, nullptr, c->out[0].as<float>(), nullptr, nullptr,
+                            c->counts.as<int>());
+    int h = 0;
+    if (rc == VO_OK && hipMemcpyAsync(&h, c->counts.p, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+      rc = fail(VO_ERR_HIP, "vo_estimate_transform: count readback failed");
+    if (rc == VO_OK && hipStreamSynchronize(c->stream) != hipSuccess)
+      rc = fail(VO_ERR_HIP, "vo_estimate_transform: stream synchronisation failed");
+    return rc == VO_OK ? h : 0;
+  });
+  if (rc != VO_OK) return rc;
+  memcpy(X_out, X.data(), sizeof(float) * 16);
   return VO_OK;
 }
 

@@ -175,6 +175,24 @@ __global__ __launch_bounds__(256) void transform_kernel(Pose T, const float* __r
   }
 }
 
+// same with the isometry read from device memory (the pose a previous solve left there)
+__global__ __launch_bounds__(256) void transform_devpose_kernel(const float* __restrict__ T16, const float* __restrict__ in,
+                                                                int n_max, const int* __restrict__ d_n,
+                                                                float* __restrict__ out) {
+  float t[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t[k] = T16[k];
+  const Pose T = pose_from_T16(t);
+  const int n = clamp_count(d_n, n_max);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float* p = in + 3 * (size_t)i;
+    float ox, oy, oz;
+    pose_apply(T, p[0], p[1], p[2], ox, oy, oz);
+    float* o = out + 3 * (size_t)i;
+    o[0] = ox; o[1] = oy; o[2] = oz;
+  }
+}
+
 // batched: frame f = blockIdx.y reads T16[f] (column-major 4x4; null: identity) and in/out + f*stride points
 __global__ __launch_bounds__(256) void transform_batch_kernel(const float* __restrict__ T16, const float* __restrict__ in,
                                                               int n, size_t stride, float* __restrict__ out) {
@@ -216,6 +234,15 @@ hipError_t launch_transform_points(hipStream_t st, const Pose& T, const float* d
   int grid = (n + 255) / 256;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(transform_kernel, dim3(grid), dim3(256), 0, st, T, d_in, n, d_n, d_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_transform_points_devpose(hipStream_t st, const float* d_T16, const float* d_in, int n,
+                                           const int* d_n, float* d_out) {
+  if (n <= 0) return hipSuccess;
+  int grid = (n + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(transform_devpose_kernel, dim3(grid), dim3(256), 0, st, d_T16, d_in, n, d_n, d_out);
   return hipGetLastError();
 }
 

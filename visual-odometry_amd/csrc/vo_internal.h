@@ -92,6 +92,8 @@ hipError_t launch_project_points(hipStream_t st, const CamK& cam, const Pose& T,
 
 hipError_t launch_transform_points(hipStream_t st, const Pose& T, const float* d_in, int n,
                                    const int* d_n, float* d_out);
+hipError_t launch_transform_points_devpose(hipStream_t st, const float* d_T16, const float* d_in, int n,
+                                           const int* d_n, float* d_out);
 
 hipError_t launch_triangulate(hipStream_t st, const float K[9], const Pose* X_host,
                               const float* d_X16, const int32_t* d_pairs, int n, const int* d_n,

@@ -67,7 +67,7 @@ class FramePipeline:
                                                   C.c_int(self.n_ref), C.c_void_p(self.d_j), self._cnt(1)))
 
     def transform(self):
-        _chk(self.lib.vo_transform_points_dev(self.ctx.h, _ptr(self.X_prev), C.c_void_p(self.d_model),
+        _chk(self.lib.vo_transform_points_dev(self.ctx.h, _ptr(self.X_prev), None, C.c_void_p(self.d_model),
                                               C.c_int(self.n_model), None, C.c_void_p(self.d_model_t)))
 
     def picp(self):
@@ -227,4 +227,145 @@ class BatchPipeline:
         for d in self._in + [self.d_matches, self.d_joined, self.d_moved, self.d_stats, self.d_tri_xyz,
                              self.d_tri_pairs, self.d_counts] + ([self.d_tri_app] if self.d_tri_app else []) + \
                 ([self.d_poses] if self._own_poses else []):
+            self.ctx.free(d)
+
+
+class SequencePipeline:
+    """A whole sequence in the manner of vo_complete.cpp:97-181 with everything resident in HBM
+    (SURVEY 8(d) config 3): all measurement files are uploaded up front; the first pair is matched,
+    initialised by vo_estimate_transform (the only host round trip) and triangulated; every later
+    frame is match -> join -> X_curr * model -> n_iters x oneRound from the identity -> triangulate,
+    chained through device-side counts and the solver's device-side pose.  Map maintenance
+    (PointCloudVector::update) is host code in the C++ application and not part of this chain."""
+
+    def __init__(self, ctx: Context, seq: dict, n_iters: int = 100, kernel_threshold: float = 10000.0,
+                 keep_appearance: bool = False):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.n_iters = n_iters
+        fr = seq["frames"]
+        self.F = len(fr)
+        assert self.F >= 2, "need at least two measurement sets"
+        self.n = [len(f["pts"]) for f in fr]
+        self.cap = max(max(self.n), 1)
+        self.off = np.concatenate([[0], np.cumsum(self.n)]).astype(np.int64)
+        self.K = _colmajor(seq["K"], 3)
+        self.cam = (int(seq["rows"]), int(seq["cols"]), int(seq["z_near"]), int(seq["z_far"]))
+        self._host_pts = [np.ascontiguousarray(f["pts"], np.float32) for f in fr[:2]]
+        up, a = ctx.to_device, ctx.alloc
+        self.d_pts = up(np.ascontiguousarray(np.concatenate([f["pts"] for f in fr]), np.float32))
+        self.d_app = up(np.ascontiguousarray(np.concatenate([f["app"] for f in fr]), np.float32))
+        cap, F = self.cap, self.F
+        self.d_m, self.d_j, self.d_model_t = a(cap * 8), a(cap * 8), a(cap * 12)
+        self.d_tri_xyz, self.d_tri_pairs = a(F * cap * 12), a(F * cap * 8)      # frame t's cloud at slice t
+        self.d_tri_app = a(F * cap * 40) if keep_appearance else 0
+        self.d_counts = a(3 * F * 4)                                            # [t] = (n_match, n_join, n_tri)
+        ctx.h2d(self.d_counts, np.zeros(3 * F, np.int32))
+        self.d_traj = a(F * 64)
+        self.d_ident = up(np.eye(4, dtype=np.float32))
+        h = C.c_void_p()
+        _chk(self.lib.vo_picp_create(ctx.h, C.byref(h)))
+        self.solver = h
+        _chk(self.lib.vo_picp_set_camera(h, *map(C.c_int, self.cam), _ptr(self.K), _ptr(_colmajor(np.eye(4), 4))))
+        _chk(self.lib.vo_picp_set_kernel_threshold(h, C.c_float(kernel_threshold)))
+        p = C.c_void_p()
+        _chk(self.lib.vo_picp_pose_dev_ptr(h, C.byref(p)))
+        self.d_pose = p.value
+        self.X0 = None
+
+    # device addresses of frame t's inputs / outputs
+    def _pts(self, t): return C.c_void_p(self.d_pts + 8 * int(self.off[t]))
+    def _app(self, t): return C.c_void_p(self.d_app + 40 * int(self.off[t]))
+    def _cnt(self, t, i): return C.c_void_p(self.d_counts + 4 * (3 * t + i))
+    def _xyz(self, t): return C.c_void_p(self.d_tri_xyz + 12 * self.cap * t)
+    def _pairs(self, t): return C.c_void_p(self.d_tri_pairs + 8 * self.cap * t)
+    def _tapp(self, t): return C.c_void_p(self.d_tri_app + 40 * self.cap * t) if self.d_tri_app else None
+
+    def _match(self, t):
+        _chk(self.lib.vo_match_appearances_dev(self.ctx.h, self._app(t - 1), C.c_int(self.n[t - 1]), self._app(t),
+                                               C.c_int(self.n[t]), C.c_float(0.1), C.c_void_p(self.d_m), self._cnt(t, 0)))
+
+    def _triangulate(self, t, X_host):
+        nq = min(self.n[t - 1], self.n[t])
+        _chk(self.lib.vo_triangulate_dev(self.ctx.h, _ptr(self.K), _ptr(X_host) if X_host is not None else None,
+                                         None if X_host is not None else C.c_void_p(self.d_pose),
+                                         C.c_void_p(self.d_m), C.c_int(nq), self._cnt(t, 0),
+                                         self._pts(t - 1), C.c_int(self.n[t - 1]), self._pts(t), C.c_int(self.n[t]),
+                                         self._app(t) if self.d_tri_app else None, self._xyz(t), self._pairs(t),
+                                         self._tapp(t), self._cnt(t, 2)))
+
+    def initialise(self):
+        """first pair: match, epipolar initialisation (host, once per sequence), triangulate (vo_complete.cpp:121-132)"""
+        self._match(1)
+        c = np.zeros(3, np.int32)
+        self.ctx.d2h(c, self.d_counts + 12)
+        pairs = np.zeros((max(int(c[0]), 1), 2), np.int32)
+        if c[0]:
+            self.ctx.d2h(pairs[: c[0]], self.d_m)
+        X = np.zeros(16, np.float32)
+        _chk(self.lib.vo_estimate_transform(self.ctx.h, _ptr(self.K), _ptr(pairs), C.c_int(int(c[0])),
+                                            _ptr(self._host_pts[0]), C.c_int(self.n[0]), _ptr(self._host_pts[1]),
+                                            C.c_int(self.n[1]), _ptr(X)))
+        self.X0 = X
+        self._triangulate(1, X)
+        self.ctx.h2d(self.d_traj, np.eye(4, dtype=np.float32))
+        self.ctx.h2d(self.d_traj + 64, X)
+
+    def step(self, t):
+        """frame t >= 2 (vo_complete.cpp:150-179); asynchronous"""
+        nq, nq_prev = min(self.n[t - 1], self.n[t]), min(self.n[t - 2], self.n[t - 1])
+        self._match(t)
+        _chk(self.lib.vo_join_correspondences_dev(self.ctx.h, C.c_void_p(self.d_m), C.c_int(nq), self._cnt(t, 0),
+                                                  self._pairs(t - 1), C.c_int(nq_prev), self._cnt(t - 1, 2),
+                                                  C.c_int(self.n[t - 1]), C.c_void_p(self.d_j), self._cnt(t, 1)))
+        _chk(self.lib.vo_transform_points_dev(self.ctx.h, _ptr(self.X0) if t == 2 else None,
+                                              None if t == 2 else C.c_void_p(self.d_pose), self._xyz(t - 1),
+                                              C.c_int(nq_prev), self._cnt(t - 1, 2), C.c_void_p(self.d_model_t)))
+        # the capacity (not the live count) is what sizes the solver's grid: the same graph serves every frame
+        _chk(self.lib.vo_picp_set_points_dev(self.solver, C.c_void_p(self.d_model_t), C.c_int(self.cap), self._pts(t),
+                                             C.c_int(self.n[t])))
+        _chk(self.lib.vo_picp_set_pose_dev(self.solver, C.c_void_p(self.d_ident)))
+        _chk(self.lib.vo_picp_solve_dev(self.solver, C.c_void_p(self.d_j), C.c_int(self.cap), self._cnt(t, 1),
+                                        C.c_int(0), C.c_int(self.n_iters)))
+        _chk(self.lib.vo_picp_get_pose_dev(self.solver, C.c_void_p(self.d_traj + 64 * t)))
+        self._triangulate(t, None)
+
+    def run(self):
+        self.initialise()
+        for t in range(2, self.F):
+            self.step(t)
+
+    # -- results (synchronise) ----------------------------------------------------------------
+    def trajectory(self):
+        T = np.zeros((self.F, 16), np.float32)
+        self.ctx.d2h(T, self.d_traj)
+        return np.ascontiguousarray(T.reshape(self.F, 4, 4).transpose(0, 2, 1))
+
+    def counts(self):
+        c = np.zeros((self.F, 3), np.int32)
+        self.ctx.d2h(c, self.d_counts)
+        return c
+
+    def cloud(self, t):
+        """triangulated points of frame t (in the frame of camera t), their (idx in frame t, k) pairs and,
+        when kept, appearances"""
+        n = int(self.counts()[t, 2])
+        xyz, pairs = np.zeros((n, 3), np.float32), np.zeros((n, 2), np.int32)
+        app = np.zeros((n, 10), np.float32) if self.d_tri_app else None
+        if n:
+            self.ctx.d2h(xyz, self._xyz(t).value); self.ctx.d2h(pairs, self._pairs(t).value)
+            if app is not None:
+                self.ctx.d2h(app, self._tapp(t).value)
+        return xyz, pairs, app
+
+    def stats(self):
+        ci, co, ni = C.c_float(), C.c_float(), C.c_int()
+        _chk(self.lib.vo_picp_get_stats(self.solver, C.byref(ci), C.byref(co), C.byref(ni)))
+        return ci.value, co.value, ni.value
+
+    def close(self):
+        if self.solver:
+            self.lib.vo_picp_destroy(self.solver)
+            self.solver = None
+        for d in (self.d_pts, self.d_app, self.d_m, self.d_j, self.d_model_t, self.d_tri_xyz, self.d_tri_pairs,
+                  self.d_counts, self.d_traj, self.d_ident) + ((self.d_tri_app,) if self.d_tri_app else ()):
             self.ctx.free(d)

@@ -156,3 +156,111 @@ def frame_pair(n, seed=2000, noise_px=0.5, drop=0.0, distractors=0, model_drop=0
                 ref_pts=ref_pts, ref_app=ref_app, cur_pts=cur_pts, cur_app=cur_app,
                 model=np.ascontiguousarray(model, dtype=np.float32), model_pairs=model_pairs,
                 gt_matches=gt_matches)
+
+
+# ---- config 3: a synthetic SEQUENCE in the reference's dataset conventions ----------------
+CAM_IN_ROBOT = np.array([[0, 0, 1, 0.2], [-1, 0, 0, 0], [0, -1, 0, 0], [0, 0, 0, 1]], dtype=np.float64)
+
+
+def planar_pose(x, y, th):
+    T = np.eye(4)
+    c, s = np.cos(th), np.sin(th)
+    T[:2, :2] = [[c, -s], [s, c]]
+    T[:2, 3] = [x, y]
+    return T
+
+
+def sequence(seed=3000, n_frames=200, n_visible=2000, step=0.2, yaw_amp=0.015, noise_px=0.0, z_vis=5.0,
+             z_lo=-1.5, z_hi=2.5):
+    """a planar robot advancing `step` per frame with a slowly varying yaw
+    (the shape of example_data's trajectory.dat), a camera mounted as in camera.dat
+    (cam_transform: optical axis along the robot's x), and landmarks spread uniformly in a slab
+    around the path at a density that puts about n_visible of them in view per frame.  Every
+    landmark carries a 10-D appearance that is copied exactly into each measurement (as in the
+    real data), each frame lists its measurements in its own random order.
+
+    The reference's Camera gate z <= z_far (camera.h:28) is applied by the solver to model
+    points in the ESTIMATED scale, which the epipolar step fixes at |t_0| = singular value of E
+    (un-normalised, epipolar_utils.cpp:163-164; about 0.3-0.4 with this camera), i.e. |t_0|/step
+    times the true one; the camera file gets z_far = ceil(z_vis/step)+1, which leaves headroom
+    for any |t_0| <= 1, while visibility is generated with the true cut-off z_vis.
+
+    Returns a dict: K, rows, cols, z_near, z_far, H (camera in robot), gt (n_frames,3: x,y,theta),
+    world_xyz (M,3), world_app (M,10), frames = [dict(ids, pts (n,2), app (n,10))]."""
+    rng = np.random.default_rng(seed)
+    F = int(n_frames)
+    th = np.zeros(F); xy = np.zeros((F, 2))
+    phase = rng.uniform(0, 2 * np.pi)
+    for t in range(1, F):
+        th[t] = th[t - 1] + yaw_amp * np.sin(2 * np.pi * t / 60.0 + phase)
+        xy[t] = xy[t - 1] + step * np.array([np.cos(th[t - 1]), np.sin(th[t - 1])])
+    gt = np.concatenate([xy, th[:, None]], axis=1)
+    K = K_REF.astype(np.float64)
+    reach = float(np.hypot(z_vis, z_vis * (COLS / 2) / K[0, 0])) + 0.5       # farthest visible point from the camera
+    lo = np.array([xy[:, 0].min() - reach, xy[:, 1].min() - reach, z_lo])
+    hi = np.array([xy[:, 0].max() + reach, xy[:, 1].max() + reach, z_hi])
+    T_cw = [np.linalg.inv(planar_pose(*gt[t]) @ CAM_IN_ROBOT) for t in range(F)]
+
+    def visible(P, t):
+        pc = P @ T_cw[t][:3, :3].T + T_cw[t][:3, 3]
+        z = pc[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = K[0, 0] * pc[:, 0] / z + K[0, 2]
+            v = K[1, 1] * pc[:, 1] / z + K[1, 2]
+        ok = (z > 1e-3) & (z <= z_vis) & (u >= 0) & (u <= COLS - 1) & (v >= 0) & (v <= ROWS - 1)
+        return ok, u, v
+
+    pilot = rng.uniform(lo, hi, (100000, 3))
+    seen = np.mean([visible(pilot, t)[0].sum() for t in range(0, F, max(F // 8, 1))])
+    M = max(int(round(100000 * n_visible / max(seen, 1.0))), 16)
+    world = rng.uniform(lo, hi, (M, 3))
+    order = np.argsort(world[:, 0], kind="stable")
+    world = np.ascontiguousarray(world[order]).astype(np.float32)               # float32 is what world.dat stores
+    w64 = world.astype(np.float64)
+    app = rng.uniform(-1, 1, (M, 10)).astype(np.float32)
+    frames = []
+    for t in range(F):
+        a, b = np.searchsorted(w64[:, 0], [xy[t, 0] - reach, xy[t, 0] + reach])
+        ok, u, v = visible(w64[a:b], t)
+        ids = a + np.nonzero(ok)[0]
+        uv = np.stack([u[ok], v[ok]], axis=1)
+        if noise_px:
+            uv = uv + rng.normal(0, noise_px, uv.shape)
+        p = rng.permutation(len(ids))
+        frames.append(dict(ids=ids[p].astype(np.int64), pts=uv[p].astype(np.float32), app=app[ids[p]]))
+    return dict(K=K_REF.copy(), rows=ROWS, cols=COLS, z_near=0, z_far=int(np.ceil(z_vis / step)) + 1,
+                H=CAM_IN_ROBOT.astype(np.float32), gt=gt, world_xyz=world, world_app=app, frames=frames, step=step)
+
+
+def sequence_gt_relative(seq):
+    """X_gt[t] (t >= 1): pose of camera t-1 in the frame of camera t, true scale (what the solver
+    estimates up to the global monocular scale)."""
+    H = seq["H"].astype(np.float64)
+    Twc = [planar_pose(*g) @ H for g in seq["gt"]]
+    return [np.linalg.inv(Twc[t]) @ Twc[t - 1] for t in range(1, len(Twc))]
+
+
+def write_sequence(seq, out_dir):
+    """Write `seq` in the reference's dataset format (files_utils.cpp:29-131): camera.dat,
+    trajectory.dat (k, odometry x y theta, ground truth x y theta), world.dat (id xyz app) and
+    meas-XXXXX.dat (3 header lines, then `point <k> <id> <col> <row> <10 appearance>`).  Floats
+    are printed with 9 significant digits, so every reader recovers the same float32."""
+    import os
+    os.makedirs(out_dir, exist_ok=True)
+    g = lambda a: " ".join("%.9g" % float(x) for x in a)
+    K, H = seq["K"], seq["H"]
+    with open(os.path.join(out_dir, "camera.dat"), "w") as f:
+        f.write("camera matrix:\n" + "".join(g(K[r]) + "\n" for r in range(3)))
+        f.write("cam_transform:\n" + "".join(g(H[r]) + "\n" for r in range(4)))
+        f.write("z_near: %d\nz_far:  %d\nwidth:  %d\nheight: %d\n" % (seq["z_near"], seq["z_far"], seq["cols"], seq["rows"]))
+    with open(os.path.join(out_dir, "trajectory.dat"), "w") as f:
+        for k, p in enumerate(seq["gt"]):
+            f.write("%d %s %s\n" % (k, g(p), g(p)))
+    with open(os.path.join(out_dir, "world.dat"), "w") as f:
+        for i, (p, a) in enumerate(zip(seq["world_xyz"], seq["world_app"])):
+            f.write("%d %s %s\n" % (i, g(p), g(a)))
+    for t, fr in enumerate(seq["frames"]):
+        with open(os.path.join(out_dir, "meas-%05d.dat" % t), "w") as f:
+            f.write("seq: %d\ngt_pose: %s\nodom_pose: %s\n" % (t, g(seq["gt"][t]), g(seq["gt"][t])))
+            for k, (i, p, a) in enumerate(zip(fr["ids"], fr["pts"], fr["app"])):
+                f.write("point %d %d %s %s\n" % (k, int(i), g(p), g(a)))
