@@ -151,6 +151,27 @@ class Oracle:
             res["T_trace"] = tT.reshape(n_iters, 4, 4).transpose(0, 2, 1).copy()
         return res
 
+    def picp_solve_mt(self, cam: Camera, world, meas, corr, n_iters: int, n_threads: int,
+                      kernel_threshold=1000.0, keep_outliers: bool = False):
+        """all-cores baseline (float32 only): per-thread partial sums, see vo_oracle.c"""
+        assert self.bits == 32
+        w = self._arr(world, (-1, 3))
+        z = self._arr(meas, (-1, 2))
+        cp = self._pairs(corr)
+        s = self.picp_t()
+        self._f("picp_ctor")(C.byref(s))
+        cs = self._cam(cam)
+        self._f("picp_init")(C.byref(s), C.byref(cs), self._p(w), self._p(z))
+        s.kernel_threshold = kernel_threshold
+        f = self.L.vo32_picp_solve_mt
+        f.restype = C.c_int
+        used = f(C.byref(s), self._p(cp), C.c_int(len(cp)), C.c_int(int(keep_outliers)), C.c_int(n_iters),
+                 C.c_int(n_threads))
+        return {"T": np.array(s.cam.T[:], dtype=self.dt).reshape(4, 4, order="F"), "threads": int(used),
+                "chi_inliers": float(s.chi_inliers), "chi_outliers": float(s.chi_outliers),
+                "num_inliers": int(s.num_inliers),
+                "H": np.array(s.H[:], dtype=self.dt).reshape(6, 6, order="F"), "b": np.array(s.b[:], dtype=self.dt)}
+
     def ldlt_solve(self, A, rhs):
         A = np.asarray(A, dtype=self.dt)
         n = A.shape[0]

@@ -72,4 +72,53 @@ int vo_join_linear(const int *img, int n_img, const int *world, int n_world, int
   return n_out;
 }
 
-int vo_oracle_abi_version(void) { return 1; }
+/* ---- all-cores CPU baseline (SURVEY 8(d) "CPU baseline timing" (ii)) ------------------------ */
+/* The reference is single-threaded; this is the "strong" baseline only: the same linearize loop
+ * (vo32_picp_linearize) over n_threads contiguous chunks with per-thread H/b/chi partials, summed
+ * in thread order (deterministic for a fixed n_threads; n_threads = 1 is bit-identical to
+ * vo32_picp_one_round), followed by the serial tail of oneRound (picp_solver.cpp:102-110).
+ * Returns the number of threads used. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int vo32_picp_solve_mt(vo32_picp *s, const int *corr, int n, int keep_outliers, int n_iters, int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+#ifndef _OPENMP
+  n_threads = 1;
+#endif
+  vo32_picp *part = (vo32_picp *)malloc(sizeof(vo32_picp) * (size_t)n_threads);
+  if (!part) return 0;
+  for (int it = 0; it < n_iters; ++it) {
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+#endif
+    for (int t = 0; t < n_threads; ++t) {
+      vo32_picp mine = *s;                       /* on the thread's own stack: no false sharing */
+      const int lo = (int)((long long)n * t / n_threads), hi = (int)((long long)n * (t + 1) / n_threads);
+      vo32_picp_linearize(&mine, corr + 2 * lo, hi - lo, keep_outliers);
+      part[t] = mine;
+    }
+    for (int i = 0; i < 36; ++i) s->H[i] = 0.f;
+    for (int i = 0; i < 6; ++i) s->b[i] = 0.f;
+    s->chi_inliers = s->chi_outliers = 0.f;
+    s->num_inliers = 0;
+    for (int t = 0; t < n_threads; ++t) {
+      for (int i = 0; i < 36; ++i) s->H[i] += part[t].H[i];
+      for (int i = 0; i < 6; ++i) s->b[i] += part[t].b[i];
+      s->chi_inliers += part[t].chi_inliers;
+      s->chi_outliers += part[t].chi_outliers;
+      s->num_inliers += part[t].num_inliers;
+    }
+    for (int i = 0; i < 6; ++i) s->H[i + 6 * i] += 1.f * s->damping;
+    if (s->num_inliers < s->min_num_inliers) continue;
+    float nb[6], dx[6], dT[16];
+    for (int i = 0; i < 6; ++i) nb[i] = -s->b[i];
+    vo32_ldlt_solve(6, s->H, nb, dx);
+    vo32_v2t_euler(dx, dT);
+    vo32_iso_mul(dT, s->cam.T, s->cam.T);
+  }
+  free(part);
+  return n_threads;
+}
+
+int vo_oracle_abi_version(void) { return 2; }

@@ -200,3 +200,18 @@ def test_v2t_and_triangulation_against_numpy(o32, o64, vo):
     ref_of_cur = {c: r for r, c in mq.tolist()}
     truth = np.array([fq["model"][model_of_ref[ref_of_cur[c]]] for c in pq[:, 0]])
     assert np.abs(xq - truth).max() < 5e-3
+
+
+def test_all_cores_baseline_is_the_same_solver(o32, vo):
+    """vo32_picp_solve_mt (bench.py's all-cores CPU baseline): one thread is bit-identical to the
+    sequential restatement; several threads only change the summation order (2e-6 abs on the pose)."""
+    fp = vo.synth.frame_pair(3000, seed=77, noise_px=0.5)
+    cam = _cam(fp)
+    corr = o32.join(o32.match(fp["ref_app"], fp["cur_app"]), fp["model_pairs"])
+    seq = o32.picp_solve(cam, fp["model"], fp["cur_pts"], corr, 8, 10000.0, False, trace=True)
+    one = o32.picp_solve_mt(cam, fp["model"], fp["cur_pts"], corr, 8, 1, 10000.0)
+    assert one["threads"] == 1 and np.array_equal(one["T"], seq["T"])
+    assert np.array_equal(one["b"], seq["b"][-1]) and one["num_inliers"] == seq["num_inliers"]
+    many = o32.picp_solve_mt(cam, fp["model"], fp["cur_pts"], corr, 8, 3, 10000.0)
+    assert many["threads"] == 3 and many["num_inliers"] == seq["num_inliers"]
+    assert np.abs(many["T"] - seq["T"]).max() < 2e-6
