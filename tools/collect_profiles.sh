@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 50 --warmup 5 --cpu-seconds 0 > $OUT/stats.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-seconds 0 --frame-steps 3 > $OUT/$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-seconds 0 --frame-steps 3 --seq-frames 6 --seq-points 5000 > $OUT/$C.log 2>&1
 done
 cd $R
 echo done; ls $OUT

@@ -27,7 +27,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
         d["launches_" + C] = len(v)
         d["dur_us_under_pmc"] = sum(x[1] for x in v) / len(v) / 1e3
 json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 5 "
-                      "--warmup 1 --cpu-seconds 0 --frame-steps 3   (one pass per counter; tools/collect_profiles.sh)",
+                      "--warmup 1 --cpu-seconds 0 --frame-steps 3 --seq-frames 6 --seq-points 5000   (one pass per counter; tools/collect_profiles.sh)",
            "units": "FETCH_SIZE / WRITE_SIZE are KB.  gfx950: FETCH_SIZE counts exactly half the bytes of wide (16 B/lane) "
                     "coalesced streaming reads (MI355X_MICROARCH.md, HBM) -> doubled where wide_16B_loads is true; other "
                     "access widths are uncalibrated and reported as counted",
