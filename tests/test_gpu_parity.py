@@ -192,6 +192,15 @@ def test_matcher_variants_agree(vo, o32):
     cases.append((const, const[:7]))                                               # zero spread in every dimension
     one_dim = base.copy(); one_dim[:, 1:] = 0
     cases.append((one_dim, one_dim[:50] + np.float32(0.05)))
+    # lattice data (multiples of 1/32): many distinct points at EXACTLY equal distance, and distances
+    # that sit exactly on and one step beside radius^2 -- the fused prefilter must not lose or add any
+    lat = (rng.integers(-3, 4, (2500, 10)) / 32.0).astype(np.float32)
+    cases.append((lat, lat[:600] + (rng.integers(-1, 2, (600, 10)) / 32.0).astype(np.float32)))
+    edge_q = np.zeros((64, 10), np.float32)
+    edge_t = np.zeros((4, 10), np.float32)
+    edge_t[0, 0] = np.float32(0.1); edge_t[1, 0] = np.nextafter(np.float32(0.1), np.float32(0))
+    edge_t[2, :4] = np.float32(0.05); edge_t[3, :4] = np.nextafter(np.float32(0.05), np.float32(0))
+    cases.append((np.concatenate([edge_t, lat[:300] + 2]), edge_q))
     for a, b in cases:
         for x, y in ((a, b), (b, a)):
             exp = o32.match(x, y)

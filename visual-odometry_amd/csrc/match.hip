@@ -9,14 +9,13 @@
 // to the lowest tree index (the reference's tie order is an artefact of its
 // PCA partition).
 //
-// Exactness: d2 is accumulated exactly like the scalar reference loop --
-// ((t0-q0)^2 + (t1-q1)^2) + ... one term after the other, no FMA -- so the
-// running sum after 3 terms is bit-identical to the reference's intermediate
-// value and, all terms being non-negative, a lower bound of the final sum.
-// A candidate whose 3-term prefix already fails "prefix < best" can never pass
-// "d2 < best": the early exit changes no decision.  On appearance data the
-// prefix test rejects all but ~5e-4 of the pairs, so the kernel issues ~10
-// instead of ~31 VALU instructions per pair.
+// Exactness: every DECISION (d2 < best, ties) is taken on d2 accumulated exactly
+// like the scalar reference loop -- ((t0-q0)^2 + (t1-q1)^2) + ... one term after
+// the other, no FMA.  The hot loop in front of it only filters: a fused partial
+// sum of the first 3-4 terms against best * (1 + 2^-19), which provably never
+// drops a point that could beat or tie the best (see PREFIX_SLACK).  On
+// appearance data the filter rejects all but ~5e-4 of the pairs, so the kernel
+// issues ~9 instead of ~31 VALU instructions per pair.
 //
 // Layout: queries live in registers (QPT per thread); tree points are staged
 // through LDS in tiles, 12 floats (48 B) per point so that one ds_read_b128
@@ -42,6 +41,13 @@ constexpr int QPP = 1;        // queries per thread (pruned scan)
 constexpr int MBP = 64;       // threads per workgroup (pruned scan): small query groups keep the scanned rectangle tight
 constexpr int TILE = 128;     // tree points per LDS tile (6 KiB)
 constexpr int TP = 12;        // padded floats per tree point in LDS
+// The hot loop only FILTERS: a fused (FMA) partial sum s' of the first 3-4 squared differences against
+// best * PREFIX_SLACK.  With eps = 2^-24 both s' and the reference's unfused partial sum s are within
+// (1 +- 4 eps) of the exact real sum, so s' > best * (1 + 2^-19) implies s > best, and the full unfused
+// sum (monotone: it only adds non-negative terms to s) is > best as well: a filtered-out point can
+// neither beat nor tie the current best.  Every survivor is re-evaluated from scratch in the
+// reference's operation order, and only that value takes part in a decision.
+constexpr float PREFIX_SLACK = 1.0f + 0x1p-19f;
 
 __global__ __launch_bounds__(256) void match_init_kernel(unsigned long long* best, int nq, float r2, size_t best_stride) {
   best += blockIdx.z * best_stride;
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(MB) void match_kernel(const float* __restrict__ tre
   const int tid = threadIdx.x;
   const int q0 = (blockIdx.x * MB + tid) * QPT;
   float q[QPT][10];
-  float bd[QPT];
+  float bd[QPT], thr[QPT];
   int bi[QPT];
 #pragma unroll
   for (int j = 0; j < QPT; ++j) {
@@ -68,6 +74,7 @@ __global__ __launch_bounds__(MB) void match_kernel(const float* __restrict__ tre
 #pragma unroll
     for (int k = 0; k < 5; ++k) { const float2 v = src[k]; q[j][2 * k] = v.x; q[j][2 * k + 1] = v.y; }
     bd[j] = r2;           // brute_force_search.h:31
+    thr[j] = r2 * PREFIX_SLACK;
     bi[j] = -1;
   }
   const int t_begin = blockIdx.y * chunk;
@@ -85,24 +92,24 @@ __global__ __launch_bounds__(MB) void match_kernel(const float* __restrict__ tre
 #pragma unroll 4
     for (int p = 0; p < cnt; ++p) {
       const float4 ta = *reinterpret_cast<const float4*>(&s_t[p * TP]);
-      float pre[QPT];
       bool any = false;
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
+        // conservative filter (fused, 3 terms): see PREFIX_SLACK
         const float d0 = ta.x - q[j][0], d1 = ta.y - q[j][1], d2 = ta.z - q[j][2];
-        float s = d0 * d0;
-        s += d1 * d1;
-        s += d2 * d2;
-        pre[j] = s;
-        any = any || (s < bd[j]);
+        const float s = __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0));
+        any = any || (s <= thr[j]);
       }
       if (__builtin_expect(any, 0)) {
         const float4 tb4 = *reinterpret_cast<const float4*>(&s_t[p * TP + 4]);
         const float2 tc = *reinterpret_cast<const float2*>(&s_t[p * TP + 8]);
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
-          float s = pre[j];
-          float d;
+          // the decision itself: the reference's unfused left-to-right sum (brute_force_search.h:34)
+          float d = ta.x - q[j][0];
+          float s = d * d;
+          d = ta.y - q[j][1]; s += d * d;
+          d = ta.z - q[j][2]; s += d * d;
           d = ta.w - q[j][3]; s += d * d;
           d = tb4.x - q[j][4]; s += d * d;
           d = tb4.y - q[j][5]; s += d * d;
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(MB) void match_kernel(const float* __restrict__ tre
           d = tb4.w - q[j][7]; s += d * d;
           d = tc.x - q[j][8]; s += d * d;
           d = tc.y - q[j][9]; s += d * d;
-          if (s < bd[j]) { bd[j] = s; bi[j] = tb + p; }   // brute_force_search.h:35-38
+          if (s < bd[j]) { bd[j] = s; thr[j] = s * PREFIX_SLACK; bi[j] = tb + p; }   // brute_force_search.h:35-38
         }
       }
     }
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(MB) void match_kernel(const float* __restrict__ tre
 // single non-negative term of the monotonically accumulated sum already reaches
 // radius^2, so the point can never pass the strict "d2 < best" test: pruning
 // changes no decision.  Inside the rectangle the scan is the exact one above
-// (4-term bit-exact prefix, then the remaining terms in the reference's order).
+// (fused 4-term filter, survivors re-evaluated in the reference's order).
 // With no spread in A and B it degenerates to the full scan.
 // Batched use: blockIdx.z = frame.  Every per-frame array is base + frame * stride; the single-frame
 // entry points launch with gridDim.z = 1 and all strides 0.
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(MBP) void match_pruned_kernel(const float* __restri
   tree_rec = frame_ptr(tree_rec, blockIdx.z * ms.ws); qry_rec = frame_ptr(qry_rec, blockIdx.z * ms.ws);
   starts = frame_ptr(starts, blockIdx.z * ms.ws); bpp = frame_ptr(bpp, blockIdx.z * ms.ws);
   best += blockIdx.z * ms.best;
-  __shared__ __attribute__((aligned(16))) float s_t[TILE * TP];
+  __shared__ __attribute__((aligned(16))) float s_t[(TILE + 12) * TP];   // +12: padding of the last trip (<= 7 records) and its look-ahead (4)
   __shared__ int s_rng[4][MBP / 64];
   const int tid = threadIdx.x;
   const int* starts_t = starts;                       // [NBUCKET+1]
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(MBP) void match_pruned_kernel(const float* __restri
   const BucketParams bp = *bpp;
   const int q0 = qs + tid * QPP;
   float q[QPP][10];
-  float bd[QPP];
+  float bd[QPP], thr[QPP];
   int bi[QPP], qorig[QPP];
   int aLo = NA, aHi = -1, bLo = NB, bHi = -1;
 #pragma unroll
@@ -415,6 +422,7 @@ __global__ __launch_bounds__(MBP) void match_pruned_kernel(const float* __restri
     q[j][8] = c.x; q[j][9] = c.y;
     qorig[j] = __float_as_int(c.z);
     bd[j] = r2;
+    thr[j] = r2 * PREFIX_SLACK;
     bi[j] = -1;
     float xa = q[j][0], xb = q[j][0];
 #pragma unroll
@@ -440,15 +448,21 @@ __global__ __launch_bounds__(MBP) void match_pruned_kernel(const float* __restri
     aLo = s_rng[0][w] < aLo ? s_rng[0][w] : aLo; aHi = s_rng[1][w] > aHi ? s_rng[1][w] : aHi;
     bLo = s_rng[2][w] < bLo ? s_rng[2][w] : bLo; bHi = s_rng[3][w] > bHi ? s_rng[3][w] : bHi;
   }
+  // the rectangle is the same in every lane: keep it (and everything derived from it) in scalar
+  // registers, so that the tile loop below runs on scalar counters and LDS addresses
+  aLo = __builtin_amdgcn_readfirstlane(aLo); aHi = __builtin_amdgcn_readfirstlane(aHi);
+  bLo = __builtin_amdgcn_readfirstlane(bLo); bHi = __builtin_amdgcn_readfirstlane(bHi);
   // total candidate count over the cells, split into nchunks slices of whole tiles
   int span = 0;
   for (int r = aLo; r <= aHi; ++r) span += starts_t[r * NB + bHi + 1] - starts_t[r * NB + bLo];
+  span = __builtin_amdgcn_readfirstlane(span);
   const int per = ((span + nchunks - 1) / nchunks + TILE - 1) / TILE * TILE;
   const int v_begin = blockIdx.y * per;                // slice of the virtual concatenation of the ranges
   const int v_end = v_begin + per < span ? v_begin + per : span;
   int v0 = 0;                                          // virtual offset of the current range
   for (int r = aLo; r <= aHi; ++r) {
-    const int r_begin = starts_t[r * NB + bLo], r_len = starts_t[r * NB + bHi + 1] - r_begin;
+    const int r_begin = __builtin_amdgcn_readfirstlane(starts_t[r * NB + bLo]);
+    const int r_len = __builtin_amdgcn_readfirstlane(starts_t[r * NB + bHi + 1]) - r_begin;
     const int lo = v_begin > v0 ? v_begin - v0 : 0;
     const int hi = v_end - v0 < r_len ? v_end - v0 : r_len;
     v0 += r_len;
@@ -459,42 +473,61 @@ __global__ __launch_bounds__(MBP) void match_pruned_kernel(const float* __restri
       const float4* src = reinterpret_cast<const float4*>(tree_rec + 12 * (size_t)tb);
       float4* dst = reinterpret_cast<float4*>(s_t);
       for (int f = tid; f < cnt * 3; f += MBP) dst[f] = src[f];
+      // the scan runs 8 points per trip with a look-ahead of 4: the records behind the last point
+      // (up to 7 are filtered, 4 more are only loaded) read as "infinitely far", so they never pass
+      if (tid < 8) s_t[(cnt + tid) * TP] = __builtin_inff();
       __syncthreads();
-      float4 nxt = *reinterpret_cast<const float4*>(&s_t[0]);
-#pragma unroll 4
-      for (int p = 0; p < cnt; ++p) {
-        const float4 ta = nxt;
-        nxt = *reinterpret_cast<const float4*>(&s_t[(p + 1 < cnt ? p + 1 : p) * TP]);   // next point's prefix, in flight
-        float pre[QPP];
-        bool any = false;
-#pragma unroll
-        for (int j = 0; j < QPP; ++j) {
-          const float d0 = ta.x - q[j][0], d1 = ta.y - q[j][1], d2 = ta.z - q[j][2], d3 = ta.w - q[j][3];
-          float s = d0 * d0;
-          s += d1 * d1;
-          s += d2 * d2;
-          s += d3 * d3;
-          pre[j] = s;
-          any = any || (s <= bd[j]);   // <=: an exact tie with a lower original index must still be seen
+      static_assert(QPP == 1, "the grouped scan below keeps one query per lane");
+      const float q0x = q[0][0], q1x = q[0][1], q2x = q[0][2], q3x = q[0][3];
+      auto filt = [&](const float4& t) {
+        // conservative filter (fused, 4 terms): see PREFIX_SLACK
+        const float d0 = t.x - q0x, d1 = t.y - q1x, d2 = t.z - q2x, d3 = t.w - q3x;
+        return __builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0)));
+      };
+      auto exact = [&](int p) {
+        // the decision itself: the reference's unfused left-to-right sum (brute_force_search.h:34)
+        const float4 ta = *reinterpret_cast<const float4*>(&s_t[p * TP]);
+        const float4 tb4 = *reinterpret_cast<const float4*>(&s_t[p * TP + 4]);
+        const float4 tc = *reinterpret_cast<const float4*>(&s_t[p * TP + 8]);
+        float d = ta.x - q[0][0];
+        float s = d * d;
+        d = ta.y - q[0][1]; s += d * d;
+        d = ta.z - q[0][2]; s += d * d;
+        d = ta.w - q[0][3]; s += d * d;
+        d = tb4.x - q[0][4]; s += d * d;
+        d = tb4.y - q[0][5]; s += d * d;
+        d = tb4.z - q[0][6]; s += d * d;
+        d = tb4.w - q[0][7]; s += d * d;
+        d = tc.x - q[0][8]; s += d * d;
+        d = tc.y - q[0][9]; s += d * d;
+        // ties: lowest ORIGINAL index (the sorted order is arbitrary inside a bucket)
+        const int ti = __float_as_int(tc.z);
+        if (s < bd[0] || (s == bd[0] && bi[0] >= 0 && ti < bi[0])) { bd[0] = s; thr[0] = s * PREFIX_SLACK; bi[0] = ti; }
+      };
+      auto ld4 = [&](int p, float4& a, float4& b, float4& c, float4& d) {
+        const float* r = &s_t[p * TP];
+        a = *reinterpret_cast<const float4*>(r); b = *reinterpret_cast<const float4*>(r + TP);
+        c = *reinterpret_cast<const float4*>(r + 2 * TP); d = *reinterpret_cast<const float4*>(r + 3 * TP);
+      };
+      auto scan4 = [&](int p, const float4& t0, const float4& t1, const float4& t2, const float4& t3) {
+        const float f0 = filt(t0), f1 = filt(t1), f2 = filt(t2), f3 = filt(t3);
+        // <=: an exact tie with a lower original index must still be seen
+        const bool pass = (f0 <= thr[0]) | (f1 <= thr[0]) | (f2 <= thr[0]) | (f3 <= thr[0]);
+        if (__builtin_expect(__ballot(pass) != 0ull, 0)) {           // wave-uniform: no exec juggling on the fast path
+          if (f0 <= thr[0]) exact(p);
+          if (f1 <= thr[0]) exact(p + 1);
+          if (f2 <= thr[0]) exact(p + 2);
+          if (f3 <= thr[0]) exact(p + 3);
         }
-        if (__builtin_expect(any, 0)) {
-          const float4 tb4 = *reinterpret_cast<const float4*>(&s_t[p * TP + 4]);
-          const float4 tc = *reinterpret_cast<const float4*>(&s_t[p * TP + 8]);
-#pragma unroll
-          for (int j = 0; j < QPP; ++j) {
-            float s = pre[j];
-            float d;
-            d = tb4.x - q[j][4]; s += d * d;
-            d = tb4.y - q[j][5]; s += d * d;
-            d = tb4.z - q[j][6]; s += d * d;
-            d = tb4.w - q[j][7]; s += d * d;
-            d = tc.x - q[j][8]; s += d * d;
-            d = tc.y - q[j][9]; s += d * d;
-            // ties: lowest ORIGINAL index (the sorted order is arbitrary inside a bucket)
-            const int ti = __float_as_int(tc.z);
-            if (s < bd[j] || (s == bd[j] && bi[j] >= 0 && ti < bi[j])) { bd[j] = s; bi[j] = ti; }
-          }
-        }
+      };
+      // 8 points per trip in two register sets: while one group of 4 is filtered the next one is in flight
+      float4 a0, a1, a2, a3, b0, b1, b2, b3;
+      ld4(0, a0, a1, a2, a3);
+      for (int p = 0; p < cnt; p += 8) {
+        ld4(p + 4, b0, b1, b2, b3);
+        scan4(p, a0, a1, a2, a3);
+        ld4(p + 8, a0, a1, a2, a3);
+        scan4(p + 4, b0, b1, b2, b3);
       }
     }
   }
