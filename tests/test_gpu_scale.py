@@ -98,3 +98,30 @@ def test_batched_solver_matches_single(vo, ctx):
         s.close()
     for d in (d_world, d_meas, d_pairs, d_n, d_T, d_stats):
         ctx.free(d)
+
+
+def test_beyond_benchmark_size_300k(vo, ctx, o32, o64):
+    """6x the benchmark size: the solver's grid is capped (4 workgroups per CU) so every thread takes
+    several correspondences, the matcher's bucket sort and the compactions run with multi-block scans."""
+    n = 300000
+    fp = vo.synth.frame_pair(n, seed=2100)
+    m = vo.compute_correspondences_images(fp["ref_app"], fp["cur_app"], ctx=ctx)
+    gt = fp["gt_matches"]
+    assert np.array_equal(m, gt[np.argsort(gt[:, 1], kind="stable")])
+    j = vo.extract_correspondences_world(m, fp["model_pairs"], ctx=ctx)
+    assert np.array_equal(j, o32.join(m, fp["model_pairs"], linear=True)) and len(j) == n
+    cam = vo.Camera(480, 640, 0, 10, fp["K"], np.eye(4), ctx=ctx)
+    s = vo.PICPSolver(ctx)
+    s.setKernelThreshold(10000.0)
+    s.init(cam, fp["model"], fp["cur_pts"])
+    s.solve(j, False, 6)
+    T = s.camera().worldInCameraPose()
+    ocam = OCam(480, 640, 0, 10, fp["K"], np.eye(4))
+    r64 = o64.picp_solve(ocam, fp["model"], fp["cur_pts"], j, 6, 10000.0, False, trace=False)
+    assert s.numInliers() == n == r64["num_inliers"]
+    assert np.abs(T - r64["T"]).max() < 1e-4
+    assert abs(s.chiInliers() - r64["chi_inliers"]) < 1e-4 * r64["chi_inliers"]
+    xyz, pairs, _ = vo.triangulate_points(fp["K"], T, m, fp["ref_pts"], fp["cur_pts"], ctx=ctx)
+    xo, po, _ = o32.triangulate(fp["K"], T, m, fp["ref_pts"], fp["cur_pts"])
+    assert np.array_equal(pairs, po) and np.all(np.abs(xyz - xo) <= 1e-4 * np.maximum(1, np.abs(xo)))
+    s.close()

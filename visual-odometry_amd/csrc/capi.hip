@@ -652,6 +652,7 @@ int vo_picp_solve_batch_dev(vo_ctx* c, int n_problems, int rows, int cols, int z
                             const float* d_T0, int n_iters, float* d_T_out, float* d_stats_out) {
   VO_REQUIRE(c && K, "null argument");
   VO_REQUIRE(n_problems >= 0 && n_iters >= 0, "negative count");
+  VO_REQUIRE(n_problems <= 65535, "more than 65535 problems per call (the problem is a grid dimension)");
   if (n_problems == 0) return VO_OK;
   VO_REQUIRE(d_world && d_meas && d_pairs && d_n_pairs && d_T_out, "null device array");
   VO_REQUIRE(world_stride > 0 && meas_stride > 0 && pairs_stride > 0, "zero stride");
@@ -733,6 +734,7 @@ int vo_frames_batch_dev(vo_ctx* c, const vo_frame_batch* b) {
   VO_REQUIRE(F >= 0 && b->n_ref >= 0 && b->n_cur >= 0 && b->n_model >= 0 && b->n_model_pairs >= 0 && b->n_iters >= 0,
              "negative count");
   if (F == 0) return VO_OK;
+  VO_REQUIRE(F <= 65535, "more than 65535 frames per call (the frame is a grid dimension)");
   const int q = b->n_ref < b->n_cur ? b->n_ref : b->n_cur;
   VO_REQUIRE(q > 0 && b->n_model > 0, "empty frames");
   VO_REQUIRE(b->ref_app && b->cur_app && b->ref_pts && b->cur_pts && b->model && b->model_pairs, "null input array");

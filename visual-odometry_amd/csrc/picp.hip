@@ -454,13 +454,38 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
   T = uniform_pose(T);
   const CamK cam = a.cam;
   const int n4 = n & ~3;
+  // The workgroup owns its CU (168 VGPRs x 768 threads), so the CU's LDS is otherwise idle: the first
+  // PICP_BATCH_LDS_TRIPS trips of every thread (its own float4 groups, written in round 0, read back by
+  // the same thread in every later round -- no barrier, conflict-free b128) never touch HBM again.
+  __shared__ float4 s_cache[PICP_BATCH_LDS_TRIPS][5][PICP_BATCH_BLOCK];
   for (int it = 0; it < a.n_iters; ++it) {
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    int i = tid * 4;
+#pragma unroll
+    for (int c = 0; c < PICP_BATCH_LDS_TRIPS; ++c) {
+      if (i < n4) {
+        float4 cx, cy, cz, cu, cv;
+        if (it == 0) {
+          cx = *reinterpret_cast<const float4*>(X + i); cy = *reinterpret_cast<const float4*>(Y + i);
+          cz = *reinterpret_cast<const float4*>(Z + i); cu = *reinterpret_cast<const float4*>(U + i);
+          cv = *reinterpret_cast<const float4*>(V + i);
+          s_cache[c][0][tid] = cx; s_cache[c][1][tid] = cy; s_cache[c][2][tid] = cz;
+          s_cache[c][3][tid] = cu; s_cache[c][4][tid] = cv;
+        } else {
+          cx = s_cache[c][0][tid]; cy = s_cache[c][1][tid]; cz = s_cache[c][2][tid];
+          cu = s_cache[c][3][tid]; cv = s_cache[c][4][tid];
+        }
+        picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, cx.x, cy.x, cz.x, cu.x, cv.x, acc);
+        picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, cx.y, cy.y, cz.y, cu.y, cv.y, acc);
+        picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, cx.z, cy.z, cz.z, cu.z, cv.z, acc);
+        picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, cx.w, cy.w, cz.w, cu.w, cv.w, acc);
+      }
+      i += PICP_BATCH_BLOCK * 4;
+    }
     // register double buffering: the next trip's five 16-B loads are in flight
     // while the current four correspondences are linearised
-    int i = tid * 4;
     bool have = i < n4;
     float4 x, y, z, u, v;
     if (have) {

@@ -14,6 +14,7 @@ constexpr int PICP_BLOCK = 256;       // threads per workgroup of the single-pro
 constexpr int PICP_PSTRIDE = 32;      // floats per workgroup partial (NACC padded)
 constexpr int PICP_MAX_BLOCKS = 2048; // grid cap (grid-stride beyond it)
 constexpr int PICP_BATCH_BLOCK = 768;   // 12 waves: 3 per SIMD, 168 VGPRs each (room for load double-buffering)
+constexpr int PICP_BATCH_LDS_TRIPS = 2;   // trips of the batched solver held in LDS across rounds (2 x 60 KiB)
 
 // Solver parameters, resident in device memory so that a captured graph of
 // iteration launches stays valid when the camera / threshold / count change.
