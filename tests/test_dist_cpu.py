@@ -33,6 +33,14 @@ WORKER = textwrap.dedent("""
         l2, h2 = vdist.shard_range(n_pairs, r, world)
         for i, p in enumerate(range(l2, h2)):
             assert torch.equal(allp[r * blk + i], torch.arange(16, dtype=torch.float32) + 100.0 * p)
+    # ragged gather (up-front matching of a sequence): item p carries p+1 pairs, blocks of 4 and 3 items
+    mine = [torch.stack([torch.arange(p + 1, dtype=torch.int32), torch.full((p + 1,), p, dtype=torch.int32)], 1)
+            for p in range(lo, hi)]
+    every = vdist.gather_ragged(mine)
+    assert len(every) == n_pairs
+    for p, it in enumerate(every):
+        assert it.shape == (p + 1, 2) and int(it[:, 1].min()) == p == int(it[:, 1].max())
+        assert torch.equal(it[:, 0], torch.arange(p + 1, dtype=torch.int32))
     t = vdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
     assert t == float(world)
     dist.barrier()

@@ -114,3 +114,22 @@ def test_cpp_vo_complete_on_synthetic_sequence(vo, seq_run, tmp_path):
     assert abs(val["ratio used for map correction"] - m["median_ratio_inv"]) < 2e-3 * m["median_ratio_inv"], (val, m)
     assert abs(val["RMSE position"] - m["rmse_position"]) < 0.05 * m["rmse_position"] + 1e-3, (val, m)
     assert abs(val["RMSE map"] - m["rmse_map"]) < 0.05 * m["rmse_map"] + 1e-3, (val, m)
+
+
+def test_upfront_sharded_matching_over_rccl(vo, tmp_path):
+    """tools/sharded_sequence.py under torch.distributed.run (one rank on this box, so the RCCL path of
+    dist.gather_ragged runs): matches computed up front + exchanged give the identical chain."""
+    import json
+    import socket
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tools", "sharded_sequence.py"), "--frames", "10", "--points", "300"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["frames"] == 10 and out["ranks"] == 1 and out["identical_to_single_gpu_chain"] is True
+    assert out["matches_total"] > 9 * 150

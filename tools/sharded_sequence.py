@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""SURVEY 8(e), second row: a real sequence is serial in its pose chain, but its matcher stage depends on
+the appearances alone.  Every rank matches its contiguous block of (t-1, t) frame pairs on its own GPU,
+the variable-length pair lists are exchanged with two RCCL all-gathers (dist.gather_ragged), and rank 0
+runs the chain (SequencePipeline) on the precomputed matches.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+      tools/sharded_sequence.py [--data DIR | --frames F --points N] [--iters K]
+
+--data DIR reads a dataset in the reference's format (parsed here with a few lines of numpy; nothing under
+oracle/ is used).  Prints one JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+
+def read_dataset(d):
+    """camera.dat / meas-*.dat of the reference's format (files_utils.cpp:29-131) -> the dict SequencePipeline takes"""
+    K = np.zeros((3, 3), np.float32); H = np.eye(4, dtype=np.float32); ints = {}
+    lines = open(os.path.join(d, "camera.dat")).read().splitlines()
+    i = 0
+    while i < len(lines):
+        w = lines[i].split()
+        if w and w[0] == "camera":
+            K[:] = [[float(x) for x in lines[i + 1 + r].split()] for r in range(3)]; i += 4; continue
+        if w and w[0] == "cam_transform:":
+            H[:] = [[float(x) for x in lines[i + 1 + r].split()] for r in range(4)]; i += 5; continue
+        if w and w[0] in ("z_near:", "z_far:", "width:", "height:"):
+            ints[w[0][:-1]] = int(w[1])
+        i += 1
+    frames = []
+    for f in sorted(x for x in os.listdir(d) if x.startswith("meas-") and x.endswith(".dat")):
+        rows = [ln.split() for ln in open(os.path.join(d, f)).read().splitlines()[3:] if ln.strip()]
+        a = np.array([[float(x) for x in r[3:15]] for r in rows], np.float32).reshape(-1, 12)
+        frames.append(dict(ids=np.array([int(r[2]) for r in rows], np.int64), pts=a[:, :2].copy(), app=a[:, 2:].copy()))
+    return dict(K=K, H=H, rows=ints["height"], cols=ints["width"], z_near=ints["z_near"], z_far=ints["z_far"], frames=frames)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--data", default=None)
+    ap.add_argument("--frames", type=int, default=60)
+    ap.add_argument("--points", type=int, default=5000)
+    ap.add_argument("--iters", type=int, default=100)
+    args = ap.parse_args()
+    import torch
+    vo = graft.load_package()
+    from importlib import import_module
+    vdist = import_module("visual_odometry_amd.dist")
+    rank, local_rank, world = vdist.env_rank_world()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = vdist.init("nccl", local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = vo.Context(local_rank, stream.cuda_stream)
+    seq = read_dataset(args.data) if args.data else vo.synth.sequence(seed=3000, n_frames=args.frames, n_visible=args.points)
+    fr = seq["frames"]
+    F = len(fr)
+    with torch.cuda.stream(stream):
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lo, hi = vdist.shard_range(F - 1, rank, world)           # item k = the pair (k, k+1)
+        mine = [torch.from_numpy(vo.compute_correspondences_images(fr[k]["app"], fr[k + 1]["app"], ctx=ctx)).to(dev)
+                for k in range(lo, hi)]
+        every = vdist.gather_ragged(mine, device=dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        out = None
+        if rank == 0:
+            matches = [m.cpu().numpy() for m in every]
+            sp = vo.SequencePipeline(ctx, seq, n_iters=args.iters, matches=matches)
+            sp.run(); ctx.synchronize()
+            t2 = time.perf_counter()
+            traj = sp.trajectory(); counts = sp.counts(); sp.close()
+            own = vo.SequencePipeline(ctx, seq, n_iters=args.iters)   # the same chain matching for itself
+            own.run(); ctx.synchronize()
+            same = bool(np.array_equal(own.trajectory(), traj) and np.array_equal(own.counts(), counts))
+            own.close()
+            out = {"frames": F, "ranks": world, "pairs_per_rank": hi - lo, "match_and_gather_ms": (t1 - t0) * 1e3,
+                   "chain_ms": (t2 - t1) * 1e3, "matches_total": int(counts[1:, 0].sum()),
+                   "identical_to_single_gpu_chain": same,
+                   "last_pose_t": [float(x) for x in traj[-1][:3, 3]]}
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

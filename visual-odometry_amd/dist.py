@@ -1,7 +1,12 @@
 """Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" is
 RCCL on ROCm, "gloo" in the CPU tests).  The path shards by independent frame
 pairs -- no data-path collective -- and ends with ONE gather of the SE(3) poses
-(16 floats per pair: latency-bound, 64 B..12.8 KB per rank)."""
+(16 floats per pair: latency-bound, 64 B..12.8 KB per rank).
+
+A real sequence is serial in its pose chain (replicas only), but its matcher stage
+depends on the appearances alone: all (t-1, t) pairs can be matched up front,
+sharded over the ranks, and exchanged with `gather_ragged` (counts first, then one
+padded all-gather) before one rank runs the chain (second row)."""
 from __future__ import annotations
 
 import os
@@ -50,3 +55,37 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_ragged(items, device=None):
+    """All-gather of variable-length int32 pair lists: `items` is this rank's list of (n_i, 2) int32
+    tensors (its contiguous block under shard_range); returns the list over ALL ranks in global item
+    order.  Two collectives: the per-item counts (equal-sized blocks, padded with -1), then one padded
+    all-gather of the pairs."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    device = device if device is not None else (items[0].device if items else torch.device("cpu"))
+    n_local = torch.tensor([len(items)], dtype=torch.int64, device=device)
+    n_all = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(n_all, n_local)
+    blk = int(max(int(x.item()) for x in n_all))
+    if blk == 0:
+        return []
+    counts = torch.full((blk,), -1, dtype=torch.int64, device=device)
+    for i, it in enumerate(items):
+        counts[i] = it.shape[0]
+    all_counts = torch.empty((world * blk,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(all_counts, counts)
+    width = max(int(all_counts.max().item()), 1)
+    pad = torch.zeros((blk, width, 2), dtype=torch.int32, device=device)
+    for i, it in enumerate(items):
+        pad[i, : it.shape[0]] = it.to(device=device, dtype=torch.int32)
+    allp = torch.empty((world * blk, width, 2), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(allp, pad)
+    out = []
+    for k in range(world * blk):
+        c = int(all_counts[k].item())
+        if c >= 0:
+            out.append(allp[k, :c].clone())
+    return out

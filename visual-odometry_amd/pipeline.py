@@ -239,7 +239,10 @@ class SequencePipeline:
     (PointCloudVector::update) is host code in the C++ application and not part of this chain."""
 
     def __init__(self, ctx: Context, seq: dict, n_iters: int = 100, kernel_threshold: float = 10000.0,
-                 keep_appearance: bool = False):
+                 keep_appearance: bool = False, matches: list | None = None):
+        """matches: optional precomputed appearance matches, matches[t-1] = (n,2) int32 pairs
+        (idx in frame t-1, idx in frame t) for t = 1..F-1 -- e.g. computed up front, sharded over several
+        GPUs (dist.gather_ragged); the chain then skips its own matcher launches."""
         self.ctx, self.lib = ctx, ctx.lib
         self.n_iters = n_iters
         fr = seq["frames"]
@@ -256,10 +259,20 @@ class SequencePipeline:
         self.d_app = up(np.ascontiguousarray(np.concatenate([f["app"] for f in fr]), np.float32))
         cap, F = self.cap, self.F
         self.d_m, self.d_j, self.d_model_t = a(cap * 8), a(cap * 8), a(cap * 12)
+        self.pre = None
+        if matches is not None:
+            assert len(matches) == self.F - 1
+            ms = [np.ascontiguousarray(np.asarray(m, np.int32).reshape(-1, 2)) for m in matches]
+            self.pre_n = [len(m) for m in ms]
+            self.pre_off = np.concatenate([[0], np.cumsum(self.pre_n)]).astype(np.int64)
+            self.pre = up(np.concatenate(ms + [np.zeros((1, 2), np.int32)]))
         self.d_tri_xyz, self.d_tri_pairs = a(F * cap * 12), a(F * cap * 8)      # frame t's cloud at slice t
         self.d_tri_app = a(F * cap * 40) if keep_appearance else 0
         self.d_counts = a(3 * F * 4)                                            # [t] = (n_match, n_join, n_tri)
-        ctx.h2d(self.d_counts, np.zeros(3 * F, np.int32))
+        c0 = np.zeros((F, 3), np.int32)
+        if self.pre is not None:
+            c0[1:, 0] = self.pre_n
+        ctx.h2d(self.d_counts, c0)
         self.d_traj = a(F * 64)
         self.d_ident = up(np.eye(4, dtype=np.float32))
         h = C.c_void_p()
@@ -280,7 +293,13 @@ class SequencePipeline:
     def _pairs(self, t): return C.c_void_p(self.d_tri_pairs + 8 * self.cap * t)
     def _tapp(self, t): return C.c_void_p(self.d_tri_app + 40 * self.cap * t) if self.d_tri_app else None
 
+    def _m(self, t):
+        """device address of frame t's matches"""
+        return C.c_void_p(self.d_m if self.pre is None else self.pre + 8 * int(self.pre_off[t - 1]))
+
     def _match(self, t):
+        if self.pre is not None:
+            return                                  # matched up front: pairs and count are already in place
         _chk(self.lib.vo_match_appearances_dev(self.ctx.h, self._app(t - 1), C.c_int(self.n[t - 1]), self._app(t),
                                                C.c_int(self.n[t]), C.c_float(0.1), C.c_void_p(self.d_m), self._cnt(t, 0)))
 
@@ -288,7 +307,7 @@ class SequencePipeline:
         nq = min(self.n[t - 1], self.n[t])
         _chk(self.lib.vo_triangulate_dev(self.ctx.h, _ptr(self.K), _ptr(X_host) if X_host is not None else None,
                                          None if X_host is not None else C.c_void_p(self.d_pose),
-                                         C.c_void_p(self.d_m), C.c_int(nq), self._cnt(t, 0),
+                                         self._m(t), C.c_int(nq), self._cnt(t, 0),
                                          self._pts(t - 1), C.c_int(self.n[t - 1]), self._pts(t), C.c_int(self.n[t]),
                                          self._app(t) if self.d_tri_app else None, self._xyz(t), self._pairs(t),
                                          self._tapp(t), self._cnt(t, 2)))
@@ -300,7 +319,7 @@ class SequencePipeline:
         self.ctx.d2h(c, self.d_counts + 12)
         pairs = np.zeros((max(int(c[0]), 1), 2), np.int32)
         if c[0]:
-            self.ctx.d2h(pairs[: c[0]], self.d_m)
+            self.ctx.d2h(pairs[: c[0]], self._m(1).value)
         X = np.zeros(16, np.float32)
         _chk(self.lib.vo_estimate_transform(self.ctx.h, _ptr(self.K), _ptr(pairs), C.c_int(int(c[0])),
                                             _ptr(self._host_pts[0]), C.c_int(self.n[0]), _ptr(self._host_pts[1]),
@@ -314,7 +333,7 @@ class SequencePipeline:
         """frame t >= 2 (vo_complete.cpp:150-179); asynchronous"""
         nq, nq_prev = min(self.n[t - 1], self.n[t]), min(self.n[t - 2], self.n[t - 1])
         self._match(t)
-        _chk(self.lib.vo_join_correspondences_dev(self.ctx.h, C.c_void_p(self.d_m), C.c_int(nq), self._cnt(t, 0),
+        _chk(self.lib.vo_join_correspondences_dev(self.ctx.h, self._m(t), C.c_int(nq), self._cnt(t, 0),
                                                   self._pairs(t - 1), C.c_int(nq_prev), self._cnt(t - 1, 2),
                                                   C.c_int(self.n[t - 1]), C.c_void_p(self.d_j), self._cnt(t, 1)))
         _chk(self.lib.vo_transform_points_dev(self.ctx.h, _ptr(self.X0) if t == 2 else None,
@@ -367,5 +386,6 @@ class SequencePipeline:
             self.lib.vo_picp_destroy(self.solver)
             self.solver = None
         for d in (self.d_pts, self.d_app, self.d_m, self.d_j, self.d_model_t, self.d_tri_xyz, self.d_tri_pairs,
-                  self.d_counts, self.d_traj, self.d_ident) + ((self.d_tri_app,) if self.d_tri_app else ()):
+                  self.d_counts, self.d_traj, self.d_ident) + ((self.d_tri_app,) if self.d_tri_app else ()) + \
+                ((self.pre,) if self.pre is not None else ()):
             self.ctx.free(d)
