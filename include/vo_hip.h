@@ -79,6 +79,16 @@ int vo_ctx_end_capture(vo_ctx *ctx, vo_graph **out);
 int vo_graph_launch(vo_graph *g);          /* on the stream of the context it was captured on */
 int vo_graph_destroy(vo_graph *g);
 
+/* Ordering between contexts (= streams) of one device.  Work enqueued on one context can be made to
+ * wait for a point in another context's stream without blocking the host: e.g. uploads or the
+ * matcher of frame t+1 (it depends on the appearances alone) on a second context while frame t runs on
+ * the first (pipeline.py: SequencePipeline(overlap_match=True); measured in DESIGN.md section 5). */
+typedef struct vo_event vo_event;
+int vo_event_create(vo_ctx *ctx, vo_event **out);
+int vo_event_record(vo_event *ev, vo_ctx *ctx);      /* marks the current end of ctx's stream */
+int vo_ctx_wait_event(vo_ctx *ctx, vo_event *ev);    /* later work on ctx waits for the marked point */
+int vo_event_destroy(vo_event *ev);
+
 /* device memory helpers for callers without a HIP runtime of their own */
 int vo_dev_alloc(vo_ctx *ctx, size_t bytes, void **dptr);
 int vo_dev_free(vo_ctx *ctx, void *dptr);

@@ -133,3 +133,23 @@ def test_upfront_sharded_matching_over_rccl(vo, tmp_path):
     out = json.loads(line)
     assert out["frames"] == 10 and out["ranks"] == 1 and out["identical_to_single_gpu_chain"] is True
     assert out["matches_total"] > 9 * 150
+
+
+def test_overlapped_matcher_gives_identical_chain(vo, ctx, seq_run):
+    """overlap_match=True runs every matcher one frame ahead on a second context (own stream), ordered by
+    vo_event_* against the chain: counts and poses must be bit-identical to the single-stream chain, also
+    when the same object is run twice (buffers and events are reused)."""
+    seq, d, res, P = seq_run
+    a = vo.SequencePipeline(ctx, seq, n_iters=ROUNDS)
+    a.run()
+    ta, ca = a.trajectory(), a.counts()
+    a.close()
+    b = vo.SequencePipeline(ctx, seq, n_iters=ROUNDS, overlap_match=True)
+    for _ in range(2):
+        b.run()
+        assert np.array_equal(b.trajectory(), ta) and np.array_equal(b.counts(), ca)
+    b.close()
+    # events order work across contexts without blocking the host; misuse is reported
+    e = vo.Event(ctx)
+    e.record(ctx); e.wait(ctx); ctx.synchronize(); e.close()
+    assert ctx.lib.vo_event_record(None, ctx.h) == -1

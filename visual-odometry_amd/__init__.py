@@ -10,6 +10,7 @@ from .pipeline import BatchPipeline, FramePipeline, SequencePipeline  # noqa: F4
 from .api import (  # noqa: F401
     Camera,
     Context,
+    Event,
     PICPSolver,
     VoError,
     compute_correspondences_images,

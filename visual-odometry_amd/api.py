@@ -126,6 +126,34 @@ class Context:
         return p
 
 
+class Event:
+    """A point in one context's stream that another context can wait for (vo_event_*)."""
+
+    def __init__(self, ctx: Context):
+        self.lib = ctx.lib
+        h = C.c_void_p()
+        _chk(self.lib.vo_event_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def record(self, ctx: Context):
+        _chk(self.lib.vo_event_record(self.h, ctx.h))
+
+    def wait(self, ctx: Context):
+        """make later work on `ctx` wait for the recorded point (the host does not block)"""
+        _chk(self.lib.vo_ctx_wait_event(ctx.h, self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vo_event_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _default_ctx = None
 
 

@@ -81,6 +81,11 @@ struct vo_ctx {
   bool capturing = false;
 };
 
+struct vo_event {
+  int device = 0;
+  hipEvent_t ev = nullptr;
+};
+
 struct vo_graph {
   vo_ctx* ctx = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -218,6 +223,42 @@ int vo_graph_destroy(vo_graph* g) {
   (void)hipStreamSynchronize(g->ctx->stream);
   if (g->exec) (void)hipGraphExecDestroy(g->exec);
   delete g;
+  return VO_OK;
+}
+
+// ---- cross-context ordering ------------------------------------------------------------------
+int vo_event_create(vo_ctx* c, vo_event** out) {
+  VO_REQUIRE(c && out, "null argument");
+  *out = nullptr;
+  if (int r = set_device(c)) return r;
+  hipEvent_t e = nullptr;
+  VO_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  vo_event* v = new vo_event();
+  v->device = c->device; v->ev = e;
+  *out = v;
+  return VO_OK;
+}
+
+int vo_event_record(vo_event* ev, vo_ctx* c) {
+  VO_REQUIRE(ev && ev->ev && c, "null argument");
+  VO_REQUIRE(ev->device == c->device, "event and context live on different devices");
+  if (int r = set_device(c)) return r;
+  VO_HIP_CHECK(hipEventRecord(ev->ev, c->stream));
+  return VO_OK;
+}
+
+int vo_ctx_wait_event(vo_ctx* c, vo_event* ev) {
+  VO_REQUIRE(ev && ev->ev && c, "null argument");
+  VO_REQUIRE(ev->device == c->device, "event and context live on different devices");
+  if (int r = set_device(c)) return r;
+  VO_HIP_CHECK(hipStreamWaitEvent(c->stream, ev->ev, 0));
+  return VO_OK;
+}
+
+int vo_event_destroy(vo_event* ev) {
+  if (!ev) return VO_OK;
+  if (ev->ev) (void)hipEventDestroy(ev->ev);
+  delete ev;
   return VO_OK;
 }
 

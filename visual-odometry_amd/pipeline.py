@@ -13,7 +13,7 @@ import ctypes as C
 
 import numpy as np
 
-from .api import Context, _chk, _colmajor, _ptr
+from .api import Context, Event, _chk, _colmajor, _ptr
 
 
 class FramePipeline:
@@ -239,10 +239,15 @@ class SequencePipeline:
     (PointCloudVector::update) is host code in the C++ application and not part of this chain."""
 
     def __init__(self, ctx: Context, seq: dict, n_iters: int = 100, kernel_threshold: float = 10000.0,
-                 keep_appearance: bool = False, matches: list | None = None):
+                 keep_appearance: bool = False, matches: list | None = None, overlap_match: bool = False):
         """matches: optional precomputed appearance matches, matches[t-1] = (n,2) int32 pairs
         (idx in frame t-1, idx in frame t) for t = 1..F-1 -- e.g. computed up front, sharded over several
-        GPUs (dist.gather_ragged); the chain then skips its own matcher launches."""
+        GPUs (dist.gather_ragged); the chain then skips its own matcher launches.
+        overlap_match: the matcher of frame t+1 depends on the appearances alone; run it on a second
+        context (its own HIP stream), one frame ahead into a double buffer, ordered against the chain by
+        events.  Results are identical; on MI355X at 50k points it is SLOWER than the single-stream chain
+        (1.35 k vs 1.52 k frames/s): the matcher's waves take issue slots from the latency-bound solver
+        rounds, so it is off by default and kept as a measured option."""
         self.ctx, self.lib = ctx, ctx.lib
         self.n_iters = n_iters
         fr = seq["frames"]
@@ -259,6 +264,13 @@ class SequencePipeline:
         self.d_app = up(np.ascontiguousarray(np.concatenate([f["app"] for f in fr]), np.float32))
         cap, F = self.cap, self.F
         self.d_m, self.d_j, self.d_model_t = a(cap * 8), a(cap * 8), a(cap * 12)
+        self.overlap = bool(overlap_match) and matches is None
+        if self.overlap:
+            self.ctx2 = Context(ctx.device)                   # second stream of the same device
+            self.d_mb = [self.d_m, a(cap * 8)]               # matches of frame t live in buffer t % 2
+            self.ev_matched = [Event(ctx), Event(ctx)]       # recorded on ctx2 after match(t)
+            self.ev_free = [Event(ctx), Event(ctx)]          # recorded on ctx after frame t consumed its buffer
+            self._free_recorded = [False, False]
         self.pre = None
         if matches is not None:
             assert len(matches) == self.F - 1
@@ -295,11 +307,30 @@ class SequencePipeline:
 
     def _m(self, t):
         """device address of frame t's matches"""
+        if self.overlap:
+            return C.c_void_p(self.d_mb[t % 2])
         return C.c_void_p(self.d_m if self.pre is None else self.pre + 8 * int(self.pre_off[t - 1]))
+
+    def _match_ahead(self, t):
+        """overlap mode: enqueue the matcher of frame t on the second context"""
+        b = t % 2
+        if self._free_recorded[b]:
+            self.ev_free[b].wait(self.ctx2)          # frame t-2 must have finished reading this buffer
+        _chk(self.lib.vo_match_appearances_dev(self.ctx2.h, self._app(t - 1), C.c_int(self.n[t - 1]), self._app(t),
+                                               C.c_int(self.n[t]), C.c_float(0.1), self._m(t), self._cnt(t, 0)))
+        self.ev_matched[b].record(self.ctx2)
+
+    def _release(self, t):
+        if self.overlap:
+            self.ev_free[t % 2].record(self.ctx)
+            self._free_recorded[t % 2] = True
 
     def _match(self, t):
         if self.pre is not None:
             return                                  # matched up front: pairs and count are already in place
+        if self.overlap:
+            self.ev_matched[t % 2].wait(self.ctx)    # enqueued earlier by _match_ahead(t)
+            return
         _chk(self.lib.vo_match_appearances_dev(self.ctx.h, self._app(t - 1), C.c_int(self.n[t - 1]), self._app(t),
                                                C.c_int(self.n[t]), C.c_float(0.1), C.c_void_p(self.d_m), self._cnt(t, 0)))
 
@@ -326,12 +357,15 @@ class SequencePipeline:
                                             C.c_int(self.n[1]), _ptr(X)))
         self.X0 = X
         self._triangulate(1, X)
+        self._release(1)
         self.ctx.h2d(self.d_traj, np.eye(4, dtype=np.float32))
         self.ctx.h2d(self.d_traj + 64, X)
 
     def step(self, t):
         """frame t >= 2 (vo_complete.cpp:150-179); asynchronous"""
         nq, nq_prev = min(self.n[t - 1], self.n[t]), min(self.n[t - 2], self.n[t - 1])
+        if self.overlap and t + 1 < self.F:
+            self._match_ahead(t + 1)                 # one frame ahead, on the second stream
         self._match(t)
         _chk(self.lib.vo_join_correspondences_dev(self.ctx.h, self._m(t), C.c_int(nq), self._cnt(t, 0),
                                                   self._pairs(t - 1), C.c_int(nq_prev), self._cnt(t - 1, 2),
@@ -347,9 +381,20 @@ class SequencePipeline:
                                         C.c_int(0), C.c_int(self.n_iters)))
         _chk(self.lib.vo_picp_get_pose_dev(self.solver, C.c_void_p(self.d_traj + 64 * t)))
         self._triangulate(t, None)
+        self._release(t)
+
+    def start(self):
+        """first pair (and, in overlap mode, the matchers of frames 1 and 2 on the second stream)"""
+        if self.overlap:
+            self._free_recorded = [False, False]
+            self.ctx.synchronize()                   # nothing of an earlier run may still read the match buffers
+            self._match_ahead(1)
+            if self.F > 2:
+                self._match_ahead(2)
+        self.initialise()
 
     def run(self):
-        self.initialise()
+        self.start()
         for t in range(2, self.F):
             self.step(t)
 
@@ -385,6 +430,13 @@ class SequencePipeline:
         if self.solver:
             self.lib.vo_picp_destroy(self.solver)
             self.solver = None
+        if self.overlap:
+            self.ctx.synchronize(); self.ctx2.synchronize()
+            for e in self.ev_matched + self.ev_free:
+                e.close()
+            self.ctx.free(self.d_mb[1])
+            self.ctx2.close()
+            self.overlap = False
         for d in (self.d_pts, self.d_app, self.d_m, self.d_j, self.d_model_t, self.d_tri_xyz, self.d_tri_pairs,
                   self.d_counts, self.d_traj, self.d_ident) + ((self.d_tri_app,) if self.d_tri_app else ()) + \
                 ((self.pre,) if self.pre is not None else ()):
