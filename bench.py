@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--frame-steps", type=int, default=30, help="frames of the whole-frame leg (0: skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU-baseline leg (0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="headline measurement only")
-    ap.add_argument("--legs", default="frame,batched,sequence,cpu",
-                    help="extra legs to run (comma list of frame,batched,sequence,cpu)")
+    ap.add_argument("--legs", default=None,
+                    help="extra legs to run (comma list of frame,batched,sequence,cpu); default: all four on one "
+                         "GPU, only `frame` (the sharded config-4 leg) when several ranks run")
     ap.add_argument("--seq-frames", type=int, default=200, help="frames of the sequence leg (config 3)")
     ap.add_argument("--seq-points", type=int, default=50000, help="landmarks in view per frame in the sequence leg")
     ap.add_argument("--seq-iters", type=int, default=100, help="PICP rounds per frame in the sequence leg (vo_complete.cpp:163)")
@@ -151,7 +152,10 @@ def main():
                              "event time over the timed region / launches, i.e. it includes the kernel boundary"},
     }
 
-    legs = set() if args.no_extras else set(args.legs.split(","))
+    # the rank-0-only legs (batched solver sweep, serial sequence, CPU baseline) would keep the other ranks
+    # spinning in the final barrier: with several ranks only the sharded leg runs unless asked for explicitly
+    default_legs = "frame,batched,sequence,cpu" if world == 1 else "frame"
+    legs = set() if args.no_extras else set((args.legs or default_legs).split(","))
     if "frame" in legs and args.frame_steps > 0:           # every rank: config 4 (sharded pairs + pose gather)
         with torch.cuda.stream(stream):
             cfg4 = frame_throughput(vo, torch, ctx, stream, args, dist, vdist, rank, world)
