@@ -171,9 +171,11 @@ int vo_picp_solve_batch_dev(vo_ctx *ctx, int n_problems, int rows, int cols, int
  * needs squared distance < radius*radius (strict), pairs are emitted as
  * (index in a1, index in a2).  Exact-distance ties go to the lowest index.
  * out_pairs has room for min(n1,n2) pairs. */
-/* Both variants return identical pairs.  mode 0 (default): pick by size; 1: scan every
- * (query, tree point) pair; 2: counting-sort both sets into 1024 buckets along the
- * appearance component of largest spread and scan only buckets within the radius. */
+/* All variants return identical pairs.  mode 0 (default): pick by size and frame count; 1: scan every
+ * (query, tree point) pair; 2: counting-sort both sets into 1024 buckets along the two appearance
+ * components of largest spread and scan only the buckets within the radius (LDS-tiled); 3: counting-sort
+ * both sets into a 4-D grid of cells no narrower than the radius and visit, per query, the <= 81 cells
+ * around it (about 25 candidates per query on uniform appearances). */
 int vo_match_set_mode(vo_ctx *ctx, int mode);
 int vo_match_appearances(vo_ctx *ctx, const float *a1, int n1, const float *a2, int n2,
                          float radius, int32_t *out_pairs, int *n_out);

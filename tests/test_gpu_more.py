@@ -150,14 +150,14 @@ def test_whole_frame_graph_replay(vo, ctx, o32):
     pipe.close(); c2.close()
 
 
-@pytest.mark.parametrize("n,F", [(700, 5), (6000, 3)])     # full-scan matcher / bucket-pruned matcher
+@pytest.mark.parametrize("n,F", [(700, 5), (6000, 3), (2500, 9)])   # full scan / bucket-pruned / cell-hash (F >= 8)
 def test_batched_frames_equal_single_frames(vo, o32, n, F):
     """vo_frames_batch_dev: every frame of the batch gets exactly the matches / joined pairs / survivors of the
     per-frame path and of the oracle, and its pose within the reduction-order tolerance."""
     c = vo.Context(0)
     fps = []
     for i in range(F):                                   # same sizes, different content
-        f = vo.synth.frame_pair(n, seed=7000 + 31 * i + n)
+        f = vo.synth.frame_pair(n, seed=7000 + 33 * i + n, distractors=(17 if F >= 8 else 0))   # 33: same seed % 3, same sizes
         keep = np.random.default_rng(i).permutation(n)[: n - n // 10]
         f["model_pairs"] = np.ascontiguousarray(f["model_pairs"][np.sort(keep)])     # some points without model
         fps.append(f)

@@ -77,7 +77,10 @@ struct vo_ctx {
   DevBuf counts;      // small device ints
   DevBuf batch_pack;  // packed correspondences of the batched solver
   DevBuf prune_ws;    // bucket-sorted copies of the matcher
-  int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan
+  // the cell-hash variant keeps its histograms clear between calls; a workspace that was (re)allocated, used
+  // by another variant or laid out for other sizes is cleared once
+  const void* cells_ws_ptr = nullptr; size_t cells_ws_cap = 0; int cells_nt = -1, cells_nq = -1, cells_frames = -1;
+  int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan, 3 cell-hash search
   bool capturing = false;
 };
 
@@ -716,9 +719,40 @@ int vo_picp_solve_batch_dev(vo_ctx* c, int n_problems, int rows, int cols, int z
 }
 
 // ---- matcher ------------------------------------------------------------------------------
+// the sorted variants pay several small launches: worth it from ~4 M candidate pairs on
+static int match_workspace(vo_ctx* c, int variant, int nt, int nq, int n_frames, void** ws) {
+  *ws = nullptr;
+  if (variant == 1) return VO_OK;
+  VO_HIP_CHECK(c->prune_ws.ensure(match_workspace_bytes(variant, nt, nq, n_frames), c->stream));
+  *ws = c->prune_ws.p;
+  if (variant == 3) {
+    if (c->cells_ws_ptr != c->prune_ws.p || c->cells_ws_cap != c->prune_ws.cap || c->cells_nt != nt || c->cells_nq != nq ||
+        c->cells_frames != n_frames) {
+      VO_HIP_CHECK(hipMemsetAsync(c->prune_ws.p, 0, c->prune_ws.cap, c->stream));
+      c->cells_ws_ptr = c->prune_ws.p; c->cells_ws_cap = c->prune_ws.cap;
+      c->cells_nt = nt; c->cells_nq = nq; c->cells_frames = n_frames;
+    }
+  } else {
+    c->cells_ws_ptr = nullptr;                     // another variant scribbles over the buffer
+  }
+  return VO_OK;
+}
+
+// Auto: full scan for small sets; for one frame the bucket-pruned scan (its LDS-tiled scan is the shorter
+// dependency chain when the GPU is not full: 82 vs 130 us at 50k x 50k); for many frames per call the cell-hash
+// search (25 instead of ~1400 candidates per query: 4.0 vs 4.4 ms per 200 frames, its random accesses hidden
+// by occupancy).  VO_MATCH_AUTO=2|3 forces one of the sorted variants in auto mode.
+static int match_variant(const vo_ctx* c, int nt, int nq, int n_frames) {
+  if (c->match_mode != 0) return c->match_mode;
+  if ((double)nt * (double)nq < 4.0e6) return 1;
+  static const int forced = [] { const char* e = getenv("VO_MATCH_AUTO"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 3) ? v : 0; }();
+  if (forced) return forced;
+  return n_frames >= 8 ? 3 : 2;
+}
+
 int vo_match_set_mode(vo_ctx* c, int mode) {
   VO_REQUIRE(c, "ctx is null");
-  VO_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (auto), 1 (full scan) or 2 (bucket-pruned scan)");
+  VO_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (auto), 1 (full scan), 2 (bucket-pruned scan) or 3 (cell-hash search)");
   c->match_mode = mode;
   return VO_OK;
 }
@@ -735,14 +769,11 @@ int vo_match_appearances_dev(vo_ctx* c, const float* d_a1, int n1, const float* 
   VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)(nq ? nq : 1), c->stream));
   // the pruned scan pays ~8 small launches of sorting: worth it from ~4 M candidate pairs on
   const int nt = n1 > n2 ? n1 : n2;
-  const bool prune = c->match_mode == 2 || (c->match_mode == 0 && (double)nt * (double)nq >= 4.0e6);
+  const int variant = match_variant(c, nt, nq, 1);
   void* ws = nullptr;
-  if (prune && nq > 0) {
-    VO_HIP_CHECK(c->prune_ws.ensure(match_pruned_workspace_bytes(nt, nq, 1), c->stream));
-    ws = c->prune_ws.p;
-  }
+  if (nq > 0) if (int r = match_workspace(c, variant, nt, nq, 1, &ws)) return r;
   VO_HIP_CHECK(launch_match(c->stream, d_a1, n1, d_a2, n2, radius, d_out_pairs, d_n_out,
-                            c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws));
+                            c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, variant));
   return VO_OK;
 }
 
@@ -787,19 +818,16 @@ int vo_frames_batch_dev(vo_ctx* c, const vo_frame_batch* b) {
   VO_HIP_CHECK(c->scratch.ensure(sizeof(int) * cs * (size_t)F, c->stream));
   VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)q * (size_t)F, c->stream));
   VO_HIP_CHECK(c->table.ensure(sizeof(int) * (size_t)(b->n_ref ? b->n_ref : 1) * (size_t)F, c->stream));
-  const bool prune = c->match_mode == 2 || (c->match_mode == 0 && (double)nt * (double)q >= 4.0e6);
+  const int variant = match_variant(c, nt, q, F);
   void* ws = nullptr;
-  if (prune) {
-    VO_HIP_CHECK(c->prune_ws.ensure(match_pruned_workspace_bytes(nt, q, F), c->stream));
-    ws = c->prune_ws.p;
-  }
+  if (int r = match_workspace(c, variant, nt, q, F, &ws)) return r;
   int* n_match = b->counts;
   int* n_join = b->counts + F;
   int* n_tri = b->counts + 2 * (size_t)F;
   // compute_correspondences_images, all frames                                  vo_complete.cpp:156
   VO_HIP_CHECK(launch_match_batch(c->stream, b->ref_app, b->n_ref, 10 * (size_t)b->n_ref, b->cur_app, b->n_cur,
                                   10 * (size_t)b->n_cur, b->radius, b->matches, (size_t)q, n_match,
-                                  c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, F));
+                                  c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, F, variant));
   // extract_correspondences_world                                               vo_complete.cpp:157
   VO_HIP_CHECK(launch_join_batch(c->stream, b->matches, q, n_match, b->model_pairs, b->n_model_pairs, nullptr, b->n_ref,
                                  b->joined, n_join, c->table.as<int>(), c->scratch.as<int>(), F, (size_t)q,

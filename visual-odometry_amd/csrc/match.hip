@@ -589,11 +589,335 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
   return hipGetLastError();
 }
 
+// ---- cell-hash variant ---------------------------------------------------------------
+// Exact search over a 4-D grid.  Four appearance components (largest spreads, taken from components 4..9
+// when those are not much flatter, so the filter on components 0..3 keeps its selectivity) are cut into
+// nc_k = clamp(floor(spread_k / R), 1, 20) cells of width >= R each (R = 1.001 radius); both sets are
+// counting-sorted by the cell key ((c0*nc1 + c1)*nc2 + c2)*nc3 + c3 (<= 160 000 cells).  A query visits,
+// per component, the cells [cell(q_k - R), cell(q_k + R)] (<= 3, same monotone cell function as the sort):
+// <= 27 runs of tree points that are contiguous along the last component.  A tree point outside that box
+// differs from the query by more than the radius in one component, so that single non-negative term of the
+// monotonically accumulated sum already reaches radius^2 and the strict test can never pass: the box changes
+// no decision.  Inside it the scan is the same conservative filter + exact re-evaluation as above, one
+// query per lane (its own runs: nothing is shared through LDS), ties resolved on the original index.
+// On U(-1,1)^10 appearances a query meets ~25 candidates instead of ~1400 in the 2-D rectangle.
+constexpr int HK = 4;                    // hashed components
+constexpr int HNC = 20;                  // cells per component, at most
+constexpr int HSEG = 1024;               // bins per workgroup of the local scan
+constexpr int HBINS = ((HNC * HNC * HNC * HNC + HSEG) / HSEG) * HSEG;   // 160768: every key + the end sentinel
+constexpr int HBLK = HBINS / HSEG;       // 157
+
+struct CellParams {
+  int dim[HK];
+  float lo[HK], scale[HK];
+  int nc[HK];
+  float R;
+};
+
+__device__ CellParams make_cell_params(const unsigned* __restrict__ mm, float radius) {
+  float span[10], lo[10];
+  for (int k = 0; k < 10; ++k) {
+    lo[k] = ord2f(mm[k]);
+    const float sp = ord2f(~mm[10 + k]) - lo[k];
+    span[k] = (sp < INFINITY) ? sp : -1.f;               // empty / infinite / NaN ranges rank last
+  }
+  auto top4 = [&](int k0, int* out) {                    // indices of the four largest spans in [k0, 10), descending
+    bool used[10] = {false, false, false, false, false, false, false, false, false, false};
+    for (int j = 0; j < HK; ++j) {
+      int best = -1;
+      for (int k = k0; k < 10; ++k)
+        if (!used[k] && (best < 0 || span[k] > span[best])) best = k;
+      used[best] = true;
+      out[j] = best;
+    }
+  };
+  int all4[HK], tail4[HK];
+  top4(0, all4);
+  top4(4, tail4);
+  bool tail_ok = true;
+  for (int j = 0; j < HK; ++j) tail_ok = tail_ok && span[tail4[j]] >= 0.5f * span[all4[j]];
+  CellParams cp;
+  cp.R = radius * 1.001f;
+  for (int j = 0; j < HK; ++j) {
+    const int k = tail_ok ? tail4[j] : all4[j];
+    const float sp = span[k];
+    int nc = 1;
+    if (sp > 0.f && cp.R > 0.f) {
+      const float f = sp / cp.R;
+      nc = f >= (float)HNC ? HNC : (int)f;
+      if (nc < 1) nc = 1;
+    }
+    cp.dim[j] = k; cp.lo[j] = lo[k]; cp.nc[j] = nc;
+    cp.scale[j] = sp > 0.f ? (float)nc / sp : 0.f;       // cell width sp / nc >= R
+  }
+  return cp;
+}
+
+__device__ __forceinline__ float pick10(const float* v, int k) {
+  float x = v[0];
+#pragma unroll
+  for (int j = 1; j < 10; ++j) if (k == j) x = v[j];
+  return x;
+}
+
+__device__ __forceinline__ int cell_key(const float* v, const CellParams& cp) {
+  int key = 0;
+#pragma unroll
+  for (int j = 0; j < HK; ++j) key = key * cp.nc[j] + cell_of(pick10(v, cp.dim[j]), cp.lo[j], cp.scale[j], cp.nc[j]);
+  return key;
+}
+
+// per-frame workspace of the cell variant (bytes, every block 256-aligned)
+struct CellWs {
+  size_t tree_rec, qry_rec, hist_t, hist_q, start_t, start_q, blk_t, blk_q, key, rank, cp, total;
+};
+static CellWs cell_ws_layout(int nt, int nq) {
+  CellWs w;
+  size_t o = 0;
+  w.tree_rec = o; o += align256(sizeof(float) * 12 * (size_t)nt);
+  w.qry_rec = o; o += align256(sizeof(float) * 12 * (size_t)nq);
+  w.hist_t = o; o += align256(sizeof(int) * (size_t)HBINS);
+  w.hist_q = o; o += align256(sizeof(int) * (size_t)HBINS);
+  w.start_t = o; o += align256(sizeof(int) * (size_t)HBINS);
+  w.start_q = o; o += align256(sizeof(int) * (size_t)HBINS);
+  w.blk_t = o; o += align256(sizeof(int) * 256);
+  w.blk_q = o; o += align256(sizeof(int) * 256);
+  w.key = o; o += align256(sizeof(int) * ((size_t)nt + (size_t)nq));
+  w.rank = o; o += align256(sizeof(int) * ((size_t)nt + (size_t)nq));
+  w.cp = o; o += align256(sizeof(CellParams));
+  w.total = o;
+  return w;
+}
+size_t match_cells_workspace_bytes(int nt, int nq, int n_frames) {
+  return align256(128 * (size_t)n_frames) + (size_t)n_frames * cell_ws_layout(nt, nq).total;
+}
+
+struct CellArgs {
+  const float* tree; const float* qry; int nt, nq;
+  const unsigned* mm;
+  char* ws;                 // frame 0's block; frame f = ws + f * ws_stride
+  CellWs w;
+  size_t ws_stride, tree_stride, qry_stride, best_stride, mm_stride;
+  float radius, r2;
+  unsigned long long* best;
+};
+
+// key + rank of every point (rank = arrival order inside its cell, from the histogram atomic)
+__global__ __launch_bounds__(256) void cell_hist_kernel(CellArgs a) {
+  const int f = blockIdx.z;
+  const float* tree = a.tree + f * a.tree_stride; const float* qry = a.qry + f * a.qry_stride;
+  char* ws = a.ws + f * a.ws_stride;
+  __shared__ CellParams s_cp;
+  if (threadIdx.x == 0) {
+    s_cp = make_cell_params(frame_ptr(a.mm, f * a.mm_stride), a.radius);
+    if (blockIdx.x == 0) *reinterpret_cast<CellParams*>(ws + a.w.cp) = s_cp;
+  }
+  __syncthreads();
+  const CellParams cp = s_cp;
+  int* hist_t = reinterpret_cast<int*>(ws + a.w.hist_t); int* hist_q = reinterpret_cast<int*>(ws + a.w.hist_q);
+  int* key = reinterpret_cast<int*>(ws + a.w.key); int* rank = reinterpret_cast<int*>(ws + a.w.rank);
+  const int total = a.nt + a.nq;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const bool is_t = i < a.nt;
+    const float2* src = reinterpret_cast<const float2*>(is_t ? tree + 10 * (size_t)i : qry + 10 * (size_t)(i - a.nt));
+    float v[10];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const float2 t = src[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+    const int kk = cell_key(v, cp);
+    key[i] = kk;
+    rank[i] = atomicAdd(&(is_t ? hist_t : hist_q)[kk], 1);
+  }
+}
+
+// exclusive scan of HSEG bins per workgroup (histogram -> start, histogram cleared); workgroup totals to blk[]
+__global__ __launch_bounds__(HSEG) void cell_scan_local_kernel(CellArgs a) {
+  const int f = blockIdx.z, set = blockIdx.y;
+  char* ws = a.ws + f * a.ws_stride;
+  int* hist = reinterpret_cast<int*>(ws + (set ? a.w.hist_q : a.w.hist_t)) + (size_t)blockIdx.x * HSEG;
+  int* start = reinterpret_cast<int*>(ws + (set ? a.w.start_q : a.w.start_t)) + (size_t)blockIdx.x * HSEG;
+  int* blk = reinterpret_cast<int*>(ws + (set ? a.w.blk_q : a.w.blk_t));
+  __shared__ int s_w[HSEG / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int v = hist[tid];
+  if (v) hist[tid] = 0;                                  // leaves the histogram clear for the next call
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < HSEG / 64; ++w) { const int c = s_w[w]; if (w < wave) woff += c; tot += c; }
+  start[tid] = woff + incl - v;
+  if (tid == 0) blk[blockIdx.x] = tot;
+}
+
+// exclusive scan of the HBLK workgroup totals (one workgroup per set and frame)
+__global__ __launch_bounds__(256) void cell_scan_top_kernel(CellArgs a) {
+  const int f = blockIdx.z, set = blockIdx.y;
+  char* ws = a.ws + f * a.ws_stride;
+  int* blk = reinterpret_cast<int*>(ws + (set ? a.w.blk_q : a.w.blk_t));
+  __shared__ int s_w[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int v = tid < HBLK ? blk[tid] : 0;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int woff = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) if (w < wave) woff += s_w[w];
+  if (tid < HBLK) blk[tid] = woff + incl - v;
+}
+
+__device__ __forceinline__ int cell_start(const int* __restrict__ hist, const int* __restrict__ blk, int key) {
+  return hist[key] + blk[key >> 10];
+}
+static_assert(HSEG == 1024, "cell_start shifts by 10");
+
+__global__ __launch_bounds__(256) void cell_place_kernel(CellArgs a) {
+  const int f = blockIdx.z;
+  const float* tree = a.tree + f * a.tree_stride; const float* qry = a.qry + f * a.qry_stride;
+  char* ws = a.ws + f * a.ws_stride;
+  const int* hist_t = reinterpret_cast<const int*>(ws + a.w.start_t); const int* hist_q = reinterpret_cast<const int*>(ws + a.w.start_q);
+  const int* blk_t = reinterpret_cast<const int*>(ws + a.w.blk_t); const int* blk_q = reinterpret_cast<const int*>(ws + a.w.blk_q);
+  const int* key = reinterpret_cast<const int*>(ws + a.w.key); const int* rank = reinterpret_cast<const int*>(ws + a.w.rank);
+  float* tree_rec = reinterpret_cast<float*>(ws + a.w.tree_rec); float* qry_rec = reinterpret_cast<float*>(ws + a.w.qry_rec);
+  const int total = a.nt + a.nq;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const bool is_t = i < a.nt;
+    const int idx = is_t ? i : i - a.nt;
+    const float2* src = reinterpret_cast<const float2*>((is_t ? tree : qry) + 10 * (size_t)idx);
+    float2 v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = src[k];
+    const int kk = key[i];
+    const int pos = cell_start(is_t ? hist_t : hist_q, is_t ? blk_t : blk_q, kk) + rank[i];
+    float4* dst = reinterpret_cast<float4*>((is_t ? tree_rec : qry_rec) + 12 * (size_t)pos);
+    dst[0] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+    dst[1] = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+    dst[2] = make_float4(v[4].x, v[4].y, __int_as_float(idx), __int_as_float(kk));
+  }
+}
+
+__global__ __launch_bounds__(256) void cell_search_kernel(CellArgs a) {
+  const int f = blockIdx.z;
+  char* ws = a.ws + f * a.ws_stride;
+  const int* __restrict__ start_t = reinterpret_cast<const int*>(ws + a.w.start_t);
+  const int* __restrict__ blk_t = reinterpret_cast<const int*>(ws + a.w.blk_t);
+  const float4* __restrict__ tree_rec = reinterpret_cast<const float4*>(ws + a.w.tree_rec);
+  const float4* __restrict__ qry_rec = reinterpret_cast<const float4*>(ws + a.w.qry_rec);
+  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
+  unsigned long long* best = a.best + f * a.best_stride;
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  const bool live = qi < a.nq;
+  const float4* qr = qry_rec + 3 * (size_t)(live ? qi : a.nq - 1);
+  const float4 qa = qr[0], qb = qr[1], qc = qr[2];
+  const float q[10] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};
+  const int qorig = __float_as_int(qc.z);
+  int c_lo[HK], c_hi[HK];
+#pragma unroll
+  for (int j = 0; j < HK; ++j) {
+    const float x = pick10(q, cp.dim[j]);
+    c_lo[j] = cell_of(x - cp.R, cp.lo[j], cp.scale[j], cp.nc[j]);
+    c_hi[j] = live ? cell_of(x + cp.R, cp.lo[j], cp.scale[j], cp.nc[j]) : c_lo[j] - 1;   // dead lanes: empty box
+  }
+  float bd = a.r2, thr = a.r2 * PREFIX_SLACK;
+  int bi = -1;
+  auto consider = [&](int p) {
+    const float4* r3 = tree_rec + 3 * (size_t)p;
+    const float4 ta = r3[0];
+    // conservative filter (fused, 4 terms): see PREFIX_SLACK
+    const float d0 = ta.x - q[0], d1 = ta.y - q[1], d2 = ta.z - q[2], d3 = ta.w - q[3];
+    const float s4 = __builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0)));
+    if (s4 <= thr) {                                     // <=: an exact tie with a lower original index must still be seen
+      // the decision itself: the reference's unfused left-to-right sum (brute_force_search.h:34)
+      const float4 tb4 = r3[1], tc = r3[2];
+      float d = ta.x - q[0];
+      float s = d * d;
+      d = ta.y - q[1]; s += d * d;
+      d = ta.z - q[2]; s += d * d;
+      d = ta.w - q[3]; s += d * d;
+      d = tb4.x - q[4]; s += d * d;
+      d = tb4.y - q[5]; s += d * d;
+      d = tb4.z - q[6]; s += d * d;
+      d = tb4.w - q[7]; s += d * d;
+      d = tc.x - q[8]; s += d * d;
+      d = tc.y - q[9]; s += d * d;
+      const int ti = __float_as_int(tc.z);
+      if (s < bd || (s == bd && bi >= 0 && ti < bi)) { bd = s; thr = s * PREFIX_SLACK; bi = ti; }
+    }
+  };
+  // <= 3 cells per component (cell width >= R).  One (c0, c1) plane at a time: its three runs' bounds are
+  // six independent loads; the runs are then walked two points per trip.
+  for (int i0 = 0; i0 < 3; ++i0)
+    for (int i1 = 0; i1 < 3; ++i1) {
+      const int c0 = c_lo[0] + i0, c1 = c_lo[1] + i1;
+      const bool in01 = c0 <= c_hi[0] && c1 <= c_hi[1] && c_lo[3] <= c_hi[3];
+      if (!__ballot(in01)) continue;
+      int rp[3], re[3];
+#pragma unroll
+      for (int i2 = 0; i2 < 3; ++i2) {
+        const int c2 = c_lo[2] + i2;
+        const bool in = in01 && c2 <= c_hi[2];
+        const int key0 = ((c0 * cp.nc[1] + c1) * cp.nc[2] + c2) * cp.nc[3];
+        const int ka = in ? key0 + c_lo[3] : 0, kb = in ? key0 + c_hi[3] + 1 : 0;
+        const int sa = start_t[ka] + blk_t[ka >> 10], sb = start_t[kb] + blk_t[kb >> 10];
+        rp[i2] = in ? sa : 0; re[i2] = in ? sb : 0;
+      }
+#pragma unroll
+      for (int i2 = 0; i2 < 3; ++i2) {
+        int p = rp[i2];
+        const int e = re[i2];
+        while (__ballot(p < e)) {
+          if (p < e) consider(p);
+          if (p + 1 < e) consider(p + 1);
+          p += 2;
+        }
+      }
+    }
+  if (live)
+    best[qorig] = bi >= 0 ? (((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(unsigned)bi)
+                          : (((unsigned long long)__float_as_uint(a.r2) << 32) | 0xffffffffull);
+}
+
+static hipError_t launch_match_cells(hipStream_t st, const float* tree, int nt, const float* qry, int nq,
+                                     float radius, float r2, unsigned long long* d_best, void* ws, int n_frames,
+                                     size_t tree_stride, size_t qry_stride, size_t best_stride) {
+  CellArgs a;
+  a.tree = tree; a.qry = qry; a.nt = nt; a.nq = nq;
+  a.mm = static_cast<const unsigned*>(ws);
+  a.ws = static_cast<char*>(ws) + align256(128 * (size_t)n_frames);
+  a.w = cell_ws_layout(nt, nq);
+  a.ws_stride = a.w.total; a.tree_stride = tree_stride; a.qry_stride = qry_stride; a.best_stride = best_stride;
+  a.mm_stride = 128;
+  a.radius = radius; a.r2 = r2; a.best = d_best;
+  const unsigned Z = (unsigned)n_frames;
+  hipError_t e = hipMemsetAsync(ws, 0xff, 128 * (size_t)n_frames, st);
+  if (e != hipSuccess) return e;
+  // the histograms must be all-zero on entry: the caller clears a (re)allocated workspace once, every call
+  // leaves them clear again (cell_scan_local_kernel)
+  MatchStrides ms;
+  ms.tree = tree_stride; ms.qry = qry_stride; ms.best = best_stride; ms.ws = 0; ms.mm = 128;
+  int g = (nt + nq + 255) / 256;
+  hipLaunchKernelGGL(match_minmax_kernel, dim3(g > 256 ? 256 : g, 1, Z), dim3(256), 0, st, tree, nt, qry, nq,
+                     static_cast<unsigned*>(ws), ms);
+  const int gp = g > 512 ? 512 : g;
+  hipLaunchKernelGGL(cell_hist_kernel, dim3(gp, 1, Z), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_scan_local_kernel, dim3(HBLK, 2, Z), dim3(HSEG), 0, st, a);
+  hipLaunchKernelGGL(cell_scan_top_kernel, dim3(1, 2, Z), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_place_kernel, dim3(gp, 1, Z), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_search_kernel, dim3((nq + 255) / 256, 1, Z), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 // n_frames frames with identical set sizes; frame f reads a1 + f*a1_stride etc.  d_prune_ws holds
 // match_pruned_workspace_bytes(nt, nq, n_frames) bytes (or is null: full scan).
 hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t a1_stride, const float* d_a2, int n2,
                               size_t a2_stride, float radius, int32_t* d_out_pairs, size_t out_stride, int* d_n_out,
-                              unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws, int n_frames) {
+                              unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws, int n_frames,
+                              int variant) {
   const int tree_is_1 = n1 >= n2;                 // vo_complete.cpp:15-20 (ties: a1 is the tree)
   const float* tree = tree_is_1 ? d_a1 : d_a2;
   const float* qry = tree_is_1 ? d_a2 : d_a1;
@@ -602,7 +926,11 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
   const float r2 = radius * radius;
   const size_t best_stride = n_frames > 1 ? (size_t)nq : 0;
   const unsigned Z = (unsigned)n_frames;
-  if (nq > 0 && nt > 0 && d_prune_ws) {
+  if (nq > 0 && nt > 0 && d_prune_ws && variant == 3) {
+    hipError_t ep = launch_match_cells(st, tree, nt, qry, nq, radius, r2, d_best, d_prune_ws, n_frames, ts, qs,
+                                       best_stride);
+    if (ep != hipSuccess) return ep;
+  } else if (nq > 0 && nt > 0 && d_prune_ws) {
     hipError_t ep = launch_match_pruned(st, tree, nt, qry, nq, radius, r2, d_best, d_prune_ws, n_cu, n_frames, ts, qs,
                                         best_stride);
     if (ep != hipSuccess) return ep;
@@ -630,9 +958,9 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
 
 hipError_t launch_match(hipStream_t st, const float* d_a1, int n1, const float* d_a2, int n2,
                         float radius, int32_t* d_out_pairs, int* d_n_out,
-                        unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws) {
+                        unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws, int variant) {
   return launch_match_batch(st, d_a1, n1, 0, d_a2, n2, 0, radius, d_out_pairs, 0, d_n_out, d_best, d_scratch, n_cu,
-                            d_prune_ws, 1);
+                            d_prune_ws, 1, variant);
 }
 
 }  // namespace vo

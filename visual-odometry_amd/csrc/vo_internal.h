@@ -107,13 +107,20 @@ hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const in
                        int32_t* d_out, int* d_n_out, int* d_table /* n_ref ints */,
                        int* d_scratch);
 
-// d_prune_ws: null -> full scan; else match_pruned_workspace_bytes(nt, nq, n_frames) bytes -> bucket-pruned scan
+// matcher variants: 1 = full scan (no workspace), 2 = bucket-pruned scan, 3 = cell-hash search; the
+// workspace of variant v holds match_workspace_bytes(v, nt, nq, n_frames) bytes
 size_t match_pruned_workspace_bytes(int nt, int nq, int n_frames);
+size_t match_cells_workspace_bytes(int nt, int nq, int n_frames);
+inline size_t match_workspace_bytes(int variant, int nt, int nq, int n_frames) {
+  return variant == 3 ? match_cells_workspace_bytes(nt, nq, n_frames)
+       : variant == 2 ? match_pruned_workspace_bytes(nt, nq, n_frames) : 0;
+}
 // n_frames frames of identical set sizes, frame f at base + f*stride (strides in floats / pairs);
 // d_best: n_frames*min(n1,n2) keys; d_scratch: n_frames * compaction_scratch_ints(min(n1,n2)) ints; d_n_out[n_frames]
 hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t a1_stride, const float* d_a2, int n2,
                               size_t a2_stride, float radius, int32_t* d_out_pairs, size_t out_stride, int* d_n_out,
-                              unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws, int n_frames);
+                              unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws, int n_frames,
+                              int variant);
 hipError_t launch_transform_batch(hipStream_t st, const float* d_T16, const float* d_in, int n, size_t stride,
                                   float* d_out, int n_frames);
 hipError_t launch_triangulate_batch(hipStream_t st, const float K[9], const Pose* X_host, const float* d_X16,
@@ -129,6 +136,6 @@ hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, co
 hipError_t launch_match(hipStream_t st, const float* d_a1, int n1, const float* d_a2, int n2,
                         float radius, int32_t* d_out_pairs, int* d_n_out,
                         unsigned long long* d_best /* min(n1,n2) u64 */, int* d_scratch, int n_cu,
-                        void* d_prune_ws);
+                        void* d_prune_ws, int variant);
 
 }  // namespace vo
