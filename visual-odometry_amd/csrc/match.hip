@@ -669,12 +669,13 @@ __device__ __forceinline__ int cell_key(const float* v, const CellParams& cp) {
 
 // per-frame workspace of the cell variant (bytes, every block 256-aligned)
 struct CellWs {
-  size_t tree_rec, qry_rec, hist_t, hist_q, start_t, start_q, blk_t, blk_q, key, rank, cp, total;
+  size_t tree_rec, tree_idx, qry_rec, hist_t, hist_q, start_t, start_q, blk_t, blk_q, key, rank, cp, total;
 };
 static CellWs cell_ws_layout(int nt, int nq) {
   CellWs w;
   size_t o = 0;
-  w.tree_rec = o; o += align256(sizeof(float) * 12 * (size_t)nt);
+  w.tree_rec = o; o += align256(sizeof(float) * 4 * (size_t)nt);      // filter prefix (components 0..3) in cell order
+  w.tree_idx = o; o += align256(sizeof(int) * (size_t)nt);            // original index of the sorted tree point
   w.qry_rec = o; o += align256(sizeof(float) * 12 * (size_t)nq);
   w.hist_t = o; o += align256(sizeof(int) * (size_t)HBINS);
   w.hist_q = o; o += align256(sizeof(int) * (size_t)HBINS);
@@ -784,6 +785,7 @@ __global__ __launch_bounds__(256) void cell_place_kernel(CellArgs a) {
   const int* blk_t = reinterpret_cast<const int*>(ws + a.w.blk_t); const int* blk_q = reinterpret_cast<const int*>(ws + a.w.blk_q);
   const int* key = reinterpret_cast<const int*>(ws + a.w.key); const int* rank = reinterpret_cast<const int*>(ws + a.w.rank);
   float* tree_rec = reinterpret_cast<float*>(ws + a.w.tree_rec); float* qry_rec = reinterpret_cast<float*>(ws + a.w.qry_rec);
+  int* tree_idx = reinterpret_cast<int*>(ws + a.w.tree_idx);
   const int total = a.nt + a.nq;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const bool is_t = i < a.nt;
@@ -794,10 +796,17 @@ __global__ __launch_bounds__(256) void cell_place_kernel(CellArgs a) {
     for (int k = 0; k < 5; ++k) v[k] = src[k];
     const int kk = key[i];
     const int pos = cell_start(is_t ? hist_t : hist_q, is_t ? blk_t : blk_q, kk) + rank[i];
-    float4* dst = reinterpret_cast<float4*>((is_t ? tree_rec : qry_rec) + 12 * (size_t)pos);
-    dst[0] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
-    dst[1] = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
-    dst[2] = make_float4(v[4].x, v[4].y, __int_as_float(idx), __int_as_float(kk));
+    if (is_t) {
+      // tree: only what the filter reads travels (16 B + the index); a survivor's other components are fetched
+      // from the caller's array through the index
+      reinterpret_cast<float4*>(tree_rec)[pos] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+      tree_idx[pos] = idx;
+    } else {
+      float4* dst = reinterpret_cast<float4*>(qry_rec + 12 * (size_t)pos);
+      dst[0] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+      dst[1] = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+      dst[2] = make_float4(v[4].x, v[4].y, __int_as_float(idx), __int_as_float(kk));
+    }
   }
 }
 
@@ -806,7 +815,9 @@ __global__ __launch_bounds__(256) void cell_search_kernel(CellArgs a) {
   char* ws = a.ws + f * a.ws_stride;
   const int* __restrict__ start_t = reinterpret_cast<const int*>(ws + a.w.start_t);
   const int* __restrict__ blk_t = reinterpret_cast<const int*>(ws + a.w.blk_t);
-  const float4* __restrict__ tree_rec = reinterpret_cast<const float4*>(ws + a.w.tree_rec);
+  const float4* __restrict__ tree_pre = reinterpret_cast<const float4*>(ws + a.w.tree_rec);
+  const int* __restrict__ tree_idx = reinterpret_cast<const int*>(ws + a.w.tree_idx);
+  const float* __restrict__ tree = a.tree + f * a.tree_stride;
   const float4* __restrict__ qry_rec = reinterpret_cast<const float4*>(ws + a.w.qry_rec);
   const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
   unsigned long long* best = a.best + f * a.best_stride;
@@ -826,14 +837,17 @@ __global__ __launch_bounds__(256) void cell_search_kernel(CellArgs a) {
   float bd = a.r2, thr = a.r2 * PREFIX_SLACK;
   int bi = -1;
   auto consider = [&](int p) {
-    const float4* r3 = tree_rec + 3 * (size_t)p;
-    const float4 ta = r3[0];
+    const float4 ta = tree_pre[p];
     // conservative filter (fused, 4 terms): see PREFIX_SLACK
     const float d0 = ta.x - q[0], d1 = ta.y - q[1], d2 = ta.z - q[2], d3 = ta.w - q[3];
     const float s4 = __builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0)));
     if (s4 <= thr) {                                     // <=: an exact tie with a lower original index must still be seen
       // the decision itself: the reference's unfused left-to-right sum (brute_force_search.h:34)
-      const float4 tb4 = r3[1], tc = r3[2];
+      const int ti = tree_idx[p];
+      const float2* row = reinterpret_cast<const float2*>(tree + 10 * (size_t)ti);
+      const float2 r2v = row[2], r3v = row[3], r4v = row[4];
+      const float4 tb4 = make_float4(r2v.x, r2v.y, r3v.x, r3v.y);
+      const float2 tc = r4v;
       float d = ta.x - q[0];
       float s = d * d;
       d = ta.y - q[1]; s += d * d;
@@ -845,7 +859,6 @@ __global__ __launch_bounds__(256) void cell_search_kernel(CellArgs a) {
       d = tb4.w - q[7]; s += d * d;
       d = tc.x - q[8]; s += d * d;
       d = tc.y - q[9]; s += d * d;
-      const int ti = __float_as_int(tc.z);
       if (s < bd || (s == bd && bi >= 0 && ti < bi)) { bd = s; thr = s * PREFIX_SLACK; bi = ti; }
     }
   };
