@@ -204,3 +204,31 @@ def test_device_pose_reset_and_in_place_pose(vo, ctx, o32):
     r = o32.picp_solve(OCam(480, 640, 0, 10, fp["K"], np.eye(4)), fp["model"], fp["cur_pts"], corr, 10, 10000.0, False, trace=False)
     assert np.abs(s.camera().worldInCameraPose() - r["T"]).max() < 1e-4
     ctx.free(d_I); s.close()
+
+
+def test_handles_do_not_leak_device_memory(vo):
+    """create / use / destroy contexts, solvers, pipelines and events repeatedly: free device memory returns to
+    where it was (graphs, workspaces and streams are released with their owners)."""
+    import torch
+    fp = vo.synth.frame_pair(3000, seed=901)
+
+    def cycle():
+        c = vo.Context(0)
+        p = vo.FramePipeline(c, fp, n_iters=6)
+        p.frame(); p.capture_frame(); p.frame_graph()
+        assert p.counts()[0] == 3000
+        p.close()
+        for mode in (1, 2, 3):
+            c.lib.vo_match_set_mode(c.h, mode)
+            assert len(vo.compute_correspondences_images(fp["ref_app"], fp["cur_app"], ctx=c)) == 3000
+        e = vo.Event(c); e.record(c); e.wait(c); e.close()
+        c.synchronize(); c.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    for _ in range(8):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < 8 << 20, (free0, free1)          # < 8 MiB drift over 8 cycles
