@@ -58,3 +58,12 @@ def test_vo_complete_on_example_data(tmp_path, o32):
     assert np.abs(est[:12] - ref[:12]).max() < 2e-3
     assert abs(ratio - ev["median_ratio_inv"]) < 0.015 * ev["median_ratio_inv"]
     assert abs(rmse_pos - ev["rmse_position"]) < 0.35 * ev["rmse_position"]
+
+
+def test_cpp_batch_frames_app():
+    """apps/batch_frames.cpp: config 4 driven from plain C++ over the C ABI (vo_frames_batch_dev); exits 0 only when
+    every frame found all its matches / joins / inliers and its pose is the generator's ground truth."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "apps"), "-s"])
+    r = subprocess.run([os.path.join(BIN, "batch_frames"), "12", "3000", "20", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "12 frames x 3000 points" in r.stdout and "missing match/join/inlier: 0" in r.stdout
