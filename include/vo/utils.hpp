@@ -67,6 +67,25 @@ inline IntPairVector compute_correspondences_images(const Vector10fVector& appea
   return out;
 }
 
+//! TreeNode_::fullSearch (eigen_kdtree.h:56-71) for every query at once: answers[i] = indices of ALL points of
+//! `set` closer than `norm` to queries[i] (strict <, as bruteForceSearch); the order inside a list is unspecified
+inline std::vector<std::vector<int>> full_search(const Vector10fVector& set, const Vector10fVector& queries, float norm) {
+  const int nt = (int)set.size(), nq = (int)queries.size();
+  std::vector<int32_t> offsets((size_t)nq + 1, 0), indices((size_t)(nq > 8 ? 2 * nq : 16));
+  int n_total = 0;
+  for (;;) {
+    const int rc = vo_radius_search(default_context().handle(), nt ? set[0].data() : nullptr, nt,
+                                    nq ? queries[0].data() : nullptr, nq, norm, offsets.data(), indices.data(),
+                                    (int)indices.size(), &n_total);
+    if (rc == VO_ERR_INVALID_ARG && n_total > (int)indices.size()) { indices.resize((size_t)n_total); continue; }
+    check(rc, "full_search");
+    break;
+  }
+  std::vector<std::vector<int>> answers((size_t)nq);
+  for (int i = 0; i < nq; ++i) answers[(size_t)i].assign(indices.begin() + offsets[(size_t)i], indices.begin() + offsets[(size_t)i + 1]);
+  return answers;
+}
+
 //! vo_complete.cpp:52-66 -- (ref,curr) join (ref,world) -> (curr,world), first partner wins
 inline IntPairVector extract_correspondences_world(const IntPairVector& correspondences_imgs,
                                                    const IntPairVector& correspondences_world) {

@@ -182,6 +182,22 @@ int vo_match_appearances(vo_ctx *ctx, const float *a1, int n1, const float *a2, 
 int vo_match_appearances_dev(vo_ctx *ctx, const float *d_a1, int n1, const float *d_a2, int n2,
                              float radius, int32_t *d_out_pairs, int *d_n_out);
 
+/* ---- TreeNode_::fullSearch (eigen_kdtree.h:56-71) for a whole query set -- */
+/* Every tree point within `radius` of each query (squared distance < radius*radius, strict, as
+ * bruteForceSearch brute_force_search.h:3-20), exactly -- the same 4-D cell search as matcher mode 3.
+ * CSR result: query i owns indices[offsets[i] .. offsets[i+1]) (tree indices; the order inside one query's
+ * list is unspecified, as it is in the reference, where it follows the tree traversal).  `capacity` = room
+ * in `indices`; *n_total = hits found.  If n_total > capacity the call fails with VO_ERR_INVALID_ARG and
+ * offsets/n_total tell the caller how much room to bring.  Unlike the matcher the roles are explicit: the
+ * first set is searched whatever the sizes.  The approximate modes of the reference (fastSearch,
+ * bestMatchFast: descend one side of each PCA split) depend on its tree and are not reproduced; their
+ * answers are subsets of this call's / of vo_match_appearances'. */
+int vo_radius_search(vo_ctx *ctx, const float *tree_app, int n_tree, const float *query_app, int n_q,
+                     float radius, int32_t *offsets, int32_t *indices, int capacity, int *n_total);
+/* device form: d_offsets[n_q + 1]; d_offsets[n_q] = hits found (also when > capacity: the surplus is dropped) */
+int vo_radius_search_dev(vo_ctx *ctx, const float *d_tree_app, int n_tree, const float *d_query_app,
+                         int n_q, float radius, int32_t *d_offsets, int32_t *d_indices, int capacity);
+
 /* ---- extract_correspondences_world (vo_complete.cpp:52-66) ------------- */
 /* For each image pair (ref,cur) in order, the FIRST world pair (ref',w) with
  * ref'==ref gives (cur,w); image pairs without partner are dropped.

@@ -230,6 +230,24 @@ class Oracle:
         res = out[:n].copy()
         return (res, tb.value, tq.value) if timing else res
 
+    def radius_search(self, tree_app, query_app, radius=0.1, max_leaf=10, brute=False):
+        """TreeNode_::fullSearch for every query (float32): list of ascending index arrays.  brute=True: the
+        plain double loop instead of the kd-tree traversal."""
+        t = np.ascontiguousarray(tree_app, dtype=np.float32).reshape(-1, 10)
+        q = np.ascontiguousarray(query_app, dtype=np.float32).reshape(-1, 10)
+        off = np.zeros(len(q) + 1, dtype=np.int32)
+        f = self.L.vo32_radius_search
+        f.restype = C.c_int
+        cap = max(4 * len(q), 16)
+        while True:
+            idx = np.zeros(cap, dtype=np.int32)
+            total = f(self._p(t), C.c_int(len(t)), self._p(q), C.c_int(len(q)), C.c_float(radius), C.c_int(max_leaf),
+                      C.c_int(int(brute)), self._p(off), self._p(idx), C.c_int(cap))
+            if total <= cap:
+                break
+            cap = total
+        return [np.sort(idx[off[i]:off[i + 1]]) for i in range(len(q))]
+
     def join(self, img_pairs, world_pairs, linear=False):
         a = self._pairs(img_pairs)
         b = self._pairs(world_pairs)

@@ -180,3 +180,51 @@ int vo32_match_kdtree(const float *a1, int n1, const float *a2, int n2, float ra
   free(pts);
   return n_out;
 }
+
+/* ---- TreeNode_::fullSearch, eigen_kdtree.h:56-71 (+ bruteForceSearch, brute_force_search.h:3-20) ---- */
+/* Appends to out[] (room for cap ints) the stored index of every point within `norm`, in the reference's
+ * traversal order; returns the number of matches (it keeps counting past cap). */
+static int full_search(const KdNode *n, const float *pts, const float *query, float norm, int *out, int cap, int have) {
+  if (!n->left && !n->right) {
+    const float sq = norm * norm;                                       /* brute_force_search.h:10 */
+    for (int i = n->begin; i < n->end; ++i) {
+      if (sqdist(pts + (size_t)i * DIM, query) < sq) {                  /* :14 */
+        if (have < cap) out[have] = (int)pts[(size_t)i * DIM];
+        ++have;
+      }
+    }
+    return have;
+  }
+  const float d = plane_dist(query, n->mean, n->normal);
+  if (d < -norm) return full_search(n->left, pts, query, norm, out, cap, have);            /* :64-65 */
+  if (d > norm) return full_search(n->right, pts, query, norm, out, cap, have);            /* :66-67 */
+  have = full_search(n->left, pts, query, norm, out, cap, have);                           /* :69 */
+  return full_search(n->right, pts, query, norm, out, cap, have);                          /* :70 */
+}
+
+/* CSR radius search of every query against the tree set.  brute != 0: plain double loop (the arbiter for the
+ * kd-tree restatement).  offsets[nq+1]; indices[cap]; returns the total number of matches. */
+int vo32_radius_search(const float *tree_app, int nt, const float *query_app, int nq, float radius, int max_leaf,
+                       int brute, int *offsets, int *indices, int cap) {
+  float *pts = (float *)malloc(sizeof(float) * DIM * (size_t)(nt > 0 ? nt : 1));
+  for (int i = 0; i < nt; ++i) { pts[(size_t)i * DIM] = (float)i; memcpy(pts + (size_t)i * DIM + 1, tree_app + (size_t)i * AD, sizeof(float) * AD); }
+  KdNode *root = (!brute && nt > 0) ? build(pts, 0, nt, max_leaf) : 0;
+  int total = 0;
+  float q[DIM];
+  for (int i = 0; i < nq; ++i) {
+    offsets[i] = total;
+    q[0] = (float)i;
+    memcpy(q + 1, query_app + (size_t)i * AD, sizeof(float) * AD);
+    if (root) {
+      total = full_search(root, pts, q, radius, indices, cap, total);
+    } else {
+      const float sq = radius * radius;
+      for (int j = 0; j < nt; ++j)
+        if (sqdist(pts + (size_t)j * DIM, q) < sq) { if (total < cap) indices[total] = j; ++total; }
+    }
+  }
+  offsets[nq] = total;
+  if (root) free_tree(root);
+  free(pts);
+  return total;
+}

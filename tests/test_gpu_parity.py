@@ -226,3 +226,28 @@ def test_matcher_sizes_and_branches(vo, ctx, o32):
     m_g = vo.compute_correspondences_images(tree, base, ctx=ctx)
     m_o = o32.match(tree, base)
     assert np.array_equal(m_g, m_o) and len(m_o) > 250
+
+
+def test_radius_search_is_the_oracles_full_search(vo, ctx, o32):
+    """vo_radius_search = TreeNode_::fullSearch for every query: the exact set of tree points inside the ball,
+    against the oracle's kd-tree traversal and plain double loop."""
+    rng = np.random.default_rng(12)
+    base = rng.uniform(-1, 1, (700, 10)).astype(np.float32)
+    tree = np.concatenate([base + rng.normal(0, 0.02, base.shape).astype(np.float32) for _ in range(6)])    # long lists
+    lat = (rng.integers(-2, 3, (900, 10)) / 32.0).astype(np.float32)                                        # boundary distances
+    fp = vo.synth.frame_pair(5000, seed=88, drop=0.2, distractors=50)                                        # mostly 0/1 hits
+    for t, q, r in ((tree, base, 0.1), (base, tree, 0.1), (lat, lat[:150], 0.0625), (lat[:7], lat, 0.09),
+                    (fp["ref_app"], fp["cur_app"], 0.1), (np.zeros((40, 10), np.float32), np.zeros((3, 10), np.float32), 0.1)):
+        got = vo.radius_search(t, q, r, ctx=ctx)
+        exp = o32.radius_search(t, q, r)
+        assert len(got) == len(exp) == len(q)
+        assert all(np.array_equal(a, b) for a, b in zip(got, exp)), (len(t), len(q), r)
+    assert sum(len(x) for x in vo.radius_search(tree, base, 0.1, ctx=ctx)) > 3000
+    # empty sets and the capacity protocol of the C entry point
+    assert [len(x) for x in vo.radius_search(np.zeros((0, 10), np.float32), base[:4], ctx=ctx)] == [0, 0, 0, 0]
+    import ctypes as C
+    off = np.zeros(len(base) + 1, np.int32); idx = np.zeros(8, np.int32); n_total = C.c_int()
+    rc = ctx.lib.vo_radius_search(ctx.h, tree.ctypes.data_as(C.c_void_p), C.c_int(len(tree)), base.ctypes.data_as(C.c_void_p),
+                                  C.c_int(len(base)), C.c_float(0.1), off.ctypes.data_as(C.c_void_p),
+                                  idx.ctypes.data_as(C.c_void_p), C.c_int(8), C.byref(n_total))
+    assert rc == -1 and n_total.value > 3000 and off[-1] == n_total.value

@@ -215,3 +215,19 @@ def test_all_cores_baseline_is_the_same_solver(o32, vo):
     many = o32.picp_solve_mt(cam, fp["model"], fp["cur_pts"], corr, 8, 3, 10000.0)
     assert many["threads"] == 3 and many["num_inliers"] == seq["num_inliers"]
     assert np.abs(many["T"] - seq["T"]).max() < 2e-6
+
+
+def test_radius_search_kdtree_equals_brute_force(o32):
+    """oracle-side fullSearch (eigen_kdtree.h:56-71): the PCA kd-tree traversal returns exactly the points of the
+    plain double loop, on clustered data where the lists are long and on lattice data with distances on the boundary"""
+    rng = np.random.default_rng(4)
+    base = rng.uniform(-1, 1, (300, 10)).astype(np.float32)
+    tree = np.concatenate([base + rng.normal(0, 0.02, base.shape).astype(np.float32) for _ in range(5)])
+    a = o32.radius_search(tree, base, 0.1)
+    b = o32.radius_search(tree, base, 0.1, brute=True)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and sum(len(x) for x in a) > 1000
+    lat = (rng.integers(-2, 3, (800, 10)) / 32.0).astype(np.float32)
+    a = o32.radius_search(lat, lat[:100], 0.0625)                  # neighbours at exactly the radius are excluded (strict <)
+    b = o32.radius_search(lat, lat[:100], 0.0625, brute=True)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert [len(x) for x in o32.radius_search(np.zeros((0, 10), np.float32), base[:3])] == [0, 0, 0]

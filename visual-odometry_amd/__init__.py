@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     estimate_transform,
     extract_correspondences_world,
     load_library,
+    radius_search,
     transform_points,
     triangulate_points,
     LIB_PATH,

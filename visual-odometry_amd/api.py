@@ -356,3 +356,24 @@ def estimate_transform(k, correspondences, p1_img, p2_img, ctx: Context | None =
     _chk(ctx.lib.vo_estimate_transform(ctx.h, _ptr(_colmajor(k, 3)), _ptr(pairs), C.c_int(len(pairs)), _ptr(a),
                                        C.c_int(len(a)), _ptr(b), C.c_int(len(b)), _ptr(X)))
     return X.reshape(4, 4).T.copy()
+
+
+def radius_search(tree_appearances, query_appearances, radius=0.1, ctx: Context | None = None):
+    """TreeNode_::fullSearch (eigen_kdtree.h:56-71) for every query: list of int32 arrays, one per query,
+    with the indices of ALL tree points closer than `radius` (ascending; the library's order is unspecified)."""
+    ctx = ctx or default_context()
+    t = _f32(tree_appearances, (-1, 10))
+    q = _f32(query_appearances, (-1, 10))
+    offsets = np.zeros(len(q) + 1, dtype=np.int32)
+    cap = max(2 * len(q), 16)
+    while True:
+        idx = np.zeros(cap, dtype=np.int32)
+        n_total = C.c_int()
+        rc = ctx.lib.vo_radius_search(ctx.h, _ptr(t), C.c_int(len(t)), _ptr(q), C.c_int(len(q)), C.c_float(radius),
+                                      _ptr(offsets), _ptr(idx), C.c_int(cap), C.byref(n_total))
+        if rc == -1 and n_total.value > cap:            # not enough room: the call reports what it needs
+            cap = n_total.value
+            continue
+        _chk(rc)
+        break
+    return [np.sort(idx[offsets[i]:offsets[i + 1]]) for i in range(len(q))]

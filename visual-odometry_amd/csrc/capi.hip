@@ -887,6 +887,42 @@ int vo_join_correspondences(vo_ctx* c, const int32_t* img, int n_img, const int3
   return VO_OK;
 }
 
+// ---- radius search (fullSearch) ----------------------------------------------------------------
+int vo_radius_search_dev(vo_ctx* c, const float* d_tree, int n_tree, const float* d_qry, int n_q, float radius,
+                         int32_t* d_offsets, int32_t* d_indices, int capacity) {
+  VO_REQUIRE(c && d_offsets, "null argument");
+  VO_REQUIRE(n_tree >= 0 && n_q >= 0 && capacity >= 0, "negative count");
+  VO_REQUIRE((n_tree == 0 || d_tree) && (n_q == 0 || d_qry) && (capacity == 0 || d_indices), "null array");
+  if (int r = set_device(c)) return r;
+  void* ws = nullptr;
+  if (n_tree > 0 && n_q > 0) if (int r = match_workspace(c, 3, n_tree, n_q, 1, &ws)) return r;
+  VO_HIP_CHECK(launch_radius_search(c->stream, d_tree, n_tree, d_qry, n_q, radius, d_offsets, d_indices, capacity, ws));
+  return VO_OK;
+}
+
+int vo_radius_search(vo_ctx* c, const float* tree, int n_tree, const float* qry, int n_q, float radius,
+                     int32_t* offsets, int32_t* indices, int capacity, int* n_total) {
+  VO_REQUIRE(c && offsets && n_total, "null argument");
+  VO_REQUIRE(n_tree >= 0 && n_q >= 0 && capacity >= 0, "negative count");
+  VO_REQUIRE((n_tree == 0 || tree) && (n_q == 0 || qry) && (capacity == 0 || indices), "null array");
+  if (int r = set_device(c)) return r;
+  if (int r = upload(c, c->in[0], tree, sizeof(float) * 10 * (size_t)n_tree)) return r;
+  if (int r = upload(c, c->in[1], qry, sizeof(float) * 10 * (size_t)n_q)) return r;
+  VO_HIP_CHECK(c->out[0].ensure(sizeof(int32_t) * ((size_t)n_q + 1), c->stream));
+  VO_HIP_CHECK(c->out[1].ensure(sizeof(int32_t) * (size_t)(capacity ? capacity : 1), c->stream));
+  if (int r = vo_radius_search_dev(c, c->in[0].as<float>(), n_tree, c->in[1].as<float>(), n_q, radius,
+                                   c->out[0].as<int32_t>(), c->out[1].as<int32_t>(), capacity))
+    return r;
+  VO_HIP_CHECK(hipMemcpyAsync(offsets, c->out[0].p, sizeof(int32_t) * ((size_t)n_q + 1), hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  *n_total = offsets[n_q];
+  if (*n_total > capacity)
+    return fail(VO_ERR_INVALID_ARG, "vo_radius_search: %d hits, room for %d", *n_total, capacity);
+  if (*n_total > 0)
+    VO_HIP_CHECK(hipMemcpy(indices, c->out[1].p, sizeof(int32_t) * (size_t)*n_total, hipMemcpyDeviceToHost));
+  return VO_OK;
+}
+
 // ---- transform ------------------------------------------------------------------------------
 int vo_transform_points_dev(vo_ctx* c, const float T[16], const float* d_T16, const float* d_in, int n,
                             const int* d_n, float* d_out) {

@@ -88,8 +88,7 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(int* counts, int nb, 
   }
 }
 
-static hipError_t launch_scan(hipStream_t st, int* counts, int nb, int* total, int* total2 = nullptr, int n_frames = 1,
-                              size_t counts_stride = 0) {
+hipError_t launch_scan(hipStream_t st, int* counts, int nb, int* total, int* total2, int n_frames, size_t counts_stride) {
   hipLaunchKernelGGL(scan_counts_kernel, dim3(n_frames), dim3(1024), 0, st, counts, nb, total, total2, counts_stride);
   return hipGetLastError();
 }

@@ -701,6 +701,9 @@ struct CellArgs {
   size_t ws_stride, tree_stride, qry_stride, best_stride, mm_stride;
   float radius, r2;
   unsigned long long* best;
+  int* rs_offsets;          // radius search: [nq + 1] counts, then (after the scan) offsets
+  int32_t* rs_indices;      // radius search: tree indices, room for rs_capacity
+  int rs_capacity;
 };
 
 // key + rank of every point (rank = arrival order inside its cell, from the histogram atomic)
@@ -810,6 +813,9 @@ __global__ __launch_bounds__(256) void cell_place_kernel(CellArgs a) {
   }
 }
 
+// MODE 0: best match per query (bestMatchFull);  MODE 1 / 2: count / write ALL tree points with d2 < r2
+// (fullSearch, eigen_kdtree.h:56-71 + bruteForceSearch, brute_force_search.h:3-20)
+template <int MODE>
 __global__ __launch_bounds__(256) void cell_search_kernel(CellArgs a) {
   const int f = blockIdx.z;
   char* ws = a.ws + f * a.ws_stride;
@@ -836,6 +842,9 @@ __global__ __launch_bounds__(256) void cell_search_kernel(CellArgs a) {
   }
   float bd = a.r2, thr = a.r2 * PREFIX_SLACK;
   int bi = -1;
+  int n_hit = 0;
+  int out_at = 0;
+  if (MODE == 2 && live) out_at = a.rs_offsets[qorig];
   auto consider = [&](int p) {
     const float4 ta = tree_pre[p];
     // conservative filter (fused, 4 terms): see PREFIX_SLACK
@@ -859,7 +868,12 @@ __global__ __launch_bounds__(256) void cell_search_kernel(CellArgs a) {
       d = tb4.w - q[7]; s += d * d;
       d = tc.x - q[8]; s += d * d;
       d = tc.y - q[9]; s += d * d;
-      if (s < bd || (s == bd && bi >= 0 && ti < bi)) { bd = s; thr = s * PREFIX_SLACK; bi = ti; }
+      if (MODE == 0) {
+        if (s < bd || (s == bd && bi >= 0 && ti < bi)) { bd = s; thr = s * PREFIX_SLACK; bi = ti; }
+      } else if (s < bd) {                               // bd stays radius^2: every point inside the ball
+        if (MODE == 2 && out_at + n_hit < a.rs_capacity) a.rs_indices[out_at + n_hit] = ti;
+        ++n_hit;
+      }
     }
   };
   // <= 3 cells per component (cell width >= R).  One (c0, c1) plane at a time: its three runs' bounds are
@@ -890,15 +904,15 @@ __global__ __launch_bounds__(256) void cell_search_kernel(CellArgs a) {
         }
       }
     }
-  if (live)
+  if (MODE == 0 && live)
     best[qorig] = bi >= 0 ? (((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(unsigned)bi)
                           : (((unsigned long long)__float_as_uint(a.r2) << 32) | 0xffffffffull);
+  if (MODE == 1 && live) a.rs_offsets[qorig] = n_hit;
 }
 
-static hipError_t launch_match_cells(hipStream_t st, const float* tree, int nt, const float* qry, int nq,
-                                     float radius, float r2, unsigned long long* d_best, void* ws, int n_frames,
-                                     size_t tree_stride, size_t qry_stride, size_t best_stride) {
-  CellArgs a;
+static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tree, int nt, const float* qry, int nq,
+                                    float radius, float r2, unsigned long long* d_best, void* ws, int n_frames,
+                                    size_t tree_stride, size_t qry_stride, size_t best_stride) {
   a.tree = tree; a.qry = qry; a.nt = nt; a.nq = nq;
   a.mm = static_cast<const unsigned*>(ws);
   a.ws = static_cast<char*>(ws) + align256(128 * (size_t)n_frames);
@@ -906,6 +920,7 @@ static hipError_t launch_match_cells(hipStream_t st, const float* tree, int nt, 
   a.ws_stride = a.w.total; a.tree_stride = tree_stride; a.qry_stride = qry_stride; a.best_stride = best_stride;
   a.mm_stride = 128;
   a.radius = radius; a.r2 = r2; a.best = d_best;
+  a.rs_offsets = nullptr; a.rs_indices = nullptr; a.rs_capacity = 0;
   const unsigned Z = (unsigned)n_frames;
   hipError_t e = hipMemsetAsync(ws, 0xff, 128 * (size_t)n_frames, st);
   if (e != hipSuccess) return e;
@@ -921,7 +936,33 @@ static hipError_t launch_match_cells(hipStream_t st, const float* tree, int nt, 
   hipLaunchKernelGGL(cell_scan_local_kernel, dim3(HBLK, 2, Z), dim3(HSEG), 0, st, a);
   hipLaunchKernelGGL(cell_scan_top_kernel, dim3(1, 2, Z), dim3(256), 0, st, a);
   hipLaunchKernelGGL(cell_place_kernel, dim3(gp, 1, Z), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(cell_search_kernel, dim3((nq + 255) / 256, 1, Z), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+static hipError_t launch_match_cells(hipStream_t st, const float* tree, int nt, const float* qry, int nq,
+                                     float radius, float r2, unsigned long long* d_best, void* ws, int n_frames,
+                                     size_t tree_stride, size_t qry_stride, size_t best_stride) {
+  CellArgs a;
+  hipError_t e = launch_cells_sort(st, a, tree, nt, qry, nq, radius, r2, d_best, ws, n_frames, tree_stride, qry_stride,
+                                   best_stride);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(cell_search_kernel<0>, dim3((nq + 255) / 256, 1, (unsigned)n_frames), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// fullSearch for every query: d_offsets[nq + 1] (CSR), d_indices[capacity] (tree indices, order unspecified inside a
+// query's list); d_offsets[nq] = number of hits found, also when it exceeds the capacity (the surplus is dropped)
+hipError_t launch_radius_search(hipStream_t st, const float* d_tree, int nt, const float* d_qry, int nq, float radius,
+                                int* d_offsets, int32_t* d_indices, int capacity, void* ws) {
+  if (nq <= 0 || nt <= 0) return hipMemsetAsync(d_offsets, 0, sizeof(int) * (size_t)((nq > 0 ? nq : 0) + 1), st);
+  CellArgs a;
+  hipError_t e = launch_cells_sort(st, a, d_tree, nt, d_qry, nq, radius, radius * radius, nullptr, ws, 1, 0, 0, 0);
+  if (e != hipSuccess) return e;
+  a.rs_offsets = d_offsets; a.rs_indices = d_indices; a.rs_capacity = capacity;
+  hipLaunchKernelGGL(cell_search_kernel<1>, dim3((nq + 255) / 256, 1, 1), dim3(256), 0, st, a);
+  e = launch_scan(st, d_offsets, nq, d_offsets + nq, nullptr, 1, 0);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(cell_search_kernel<2>, dim3((nq + 255) / 256, 1, 1), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

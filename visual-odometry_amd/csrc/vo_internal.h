@@ -133,6 +133,13 @@ hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, co
                              int* d_n_out, int* d_table, int* d_scratch, int n_frames, size_t img_stride,
                              size_t world_stride, size_t out_stride);
 
+// in-place exclusive scan of nb ints per frame (one workgroup per frame), total to total[frame] (and total2[frame])
+hipError_t launch_scan(hipStream_t st, int* counts, int nb, int* total, int* total2 = nullptr, int n_frames = 1,
+                       size_t counts_stride = 0);
+// TreeNode_::fullSearch for every query (workspace: match_cells_workspace_bytes(nt, nq, 1), histograms clear)
+hipError_t launch_radius_search(hipStream_t st, const float* d_tree, int nt, const float* d_qry, int nq, float radius,
+                                int* d_offsets, int32_t* d_indices, int capacity, void* ws);
+
 hipError_t launch_match(hipStream_t st, const float* d_a1, int n1, const float* d_a2, int n2,
                         float radius, int32_t* d_out_pairs, int* d_n_out,
                         unsigned long long* d_best /* min(n1,n2) u64 */, int* d_scratch, int n_cu,
