@@ -3,7 +3,10 @@
 // association.  Same call sequence, same output files (written into the
 // current directory or into argv[2]): world.txt, trajectory_gt.txt, map.txt,
 // map_appearances.txt, trajectory_est_complete.txt, trajectory_est_data.txt.
-//   usage: vo_complete <data dir> [output dir] [rounds=100]
+//   usage: vo_complete <data dir> [output dir] [rounds=100] [--resident]
+// --resident: the same sequence through vo::DeviceSequence -- all measurement files are read and uploaded first, the
+// whole frame chain runs on the GPU without a host round trip per frame, the map is built afterwards from the
+// per-frame clouds.  Same outputs.
 #include <cstdio>
 #include <iostream>
 
@@ -11,12 +14,58 @@
 
 using namespace vo;
 
+// the device-resident form of the loop below: same call sequence, the frame chain inside vo::DeviceSequence
+static int run_resident(const std::string& path, const std::string& out, int rounds, const std::string& first_file,
+                        const std::string& second_file, const std::set<std::string>& files) {
+  std::vector<PointCloudVector<2>> frames;
+  std::vector<std::string> names{first_file, second_file};
+  names.insert(names.end(), files.begin(), files.end());
+  for (const auto& f : names) {
+    PointCloudVector<2> pc;
+    if (!get_meas_content(path + f, pc)) { std::cout << "Unable to open file " << path + f << std::endl; return -1; }
+    frames.push_back(std::move(pc));
+  }
+  Vector3fVector world_points;
+  Vector10fVector world_points_appearances;
+  if (!get_meas_content(path + "world.dat", world_points_appearances, world_points, true)) { std::cout << "Unable to open world file\n"; return -1; }
+  write_eigen_vectors_to_file(out + "world.txt", world_points);
+  std::vector<int> int_params;
+  Matrix3f k;
+  Isometry3f H;
+  if (!get_camera_params(path + "camera.dat", int_params, k, H)) { std::cout << "Unable to get camera parameters\n"; return -1; }
+  Camera cam(int_params[3], int_params[2], int_params[0], int_params[1], k);
+  DeviceSequence seq(cam, frames, rounds);
+  seq.run();
+  const IsometryVector trajectory = seq.trajectory();          // waits for the chain
+  // map upkeep afterwards, in frame order (vo_complete.cpp:145-147,175-176,181)
+  PointCloudVector<3> map;
+  map.update(seq.cloud(1));
+  Isometry3f history = trajectory[1].inverse();
+  for (int t = 2; t < seq.frames(); ++t) {
+    int n_match, n_join, n_tri;
+    seq.counts(t, n_match, n_join, n_tri);
+    const Isometry3f& X = trajectory[(size_t)t];
+    std::printf("%s: %d matches, %d model correspondences, t = % .5f % .5f % .5f\n", names[(size_t)t].c_str(), n_match, n_join,
+                X(0, 3), X(1, 3), X(2, 3));
+    map.update(history * seq.cloud(t));
+    history = history * X.inverse();
+  }
+  map = H * map;
+  write_eigen_vectors_to_file(out + "map.txt", map.points());
+  write_eigen_vectors_to_file(out + "map_appearances.txt", map.appearances());
+  save_trajectory(out + "trajectory_est_complete.txt", trajectory, H);
+  save_trajectory(out + "trajectory_est_data.txt", trajectory, H, true);
+  return 0;
+}
+
 int main(int argc, char* argv[]) {
   if (argc < 2) { std::cout << "Error: need path parameter to read data" << std::endl; return -1; }
   std::string path(argv[1]);
   if (path.back() != '/') path.push_back('/');
   std::string out = argc > 2 ? argv[2] : ".";
   if (out.back() != '/') out.push_back('/');
+  bool resident = false;
+  for (int i = 1; i < argc; ++i) if (std::string(argv[i]) == "--resident") { resident = true; for (int j = i; j + 1 < argc; ++j) argv[j] = argv[j + 1]; --argc; --i; }
   const int rounds = argc > 3 ? std::atoi(argv[3]) : 100;
   try {
     save_gt_trajectory(path + "trajectory.dat", out + "trajectory_gt.txt");
@@ -28,6 +77,7 @@ int main(int argc, char* argv[]) {
     const auto second_file = *(files.erase(files.begin()));
     files.erase(files.begin());
 
+    if (resident) return run_resident(path, out, rounds, first_file, second_file, files);
     PointCloudVector<2> reference_pc, current_pc;
     if (!get_meas_content(path + first_file, reference_pc)) { std::cout << "Unable to open file measurement file 0\n"; return -1; }
     if (!get_meas_content(path + second_file, current_pc)) { std::cout << "Unable to open file measurement file 1\n"; return -1; }

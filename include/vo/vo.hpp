@@ -7,5 +7,6 @@
 #include "files.hpp"
 #include "picp_solver.hpp"
 #include "point_cloud.hpp"
+#include "sequence.hpp"
 #include "types.hpp"
 #include "utils.hpp"

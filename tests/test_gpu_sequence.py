@@ -153,3 +153,18 @@ def test_overlapped_matcher_gives_identical_chain(vo, ctx, seq_run):
     e = vo.Event(ctx)
     e.record(ctx); e.wait(ctx); ctx.synchronize(); e.close()
     assert ctx.lib.vo_event_record(None, ctx.h) == -1
+
+
+def test_cpp_resident_sequence_equals_frame_by_frame(vo, seq_run, tmp_path):
+    """apps/vo_complete --resident (vo::DeviceSequence: whole chain on the GPU, map built afterwards) writes the
+    same trajectory and map files as the frame-by-frame facade loop, and the same trajectory as SequencePipeline."""
+    seq, d, res, P = seq_run
+    exe = os.path.join(ROOT, "apps", "bin", "vo_complete")
+    a, b = str(tmp_path / "a") + "/", str(tmp_path / "b") + "/"
+    os.makedirs(a); os.makedirs(b)
+    subprocess.run([exe, d, a, str(ROUNDS)], check=True, stdout=subprocess.DEVNULL, timeout=600)
+    subprocess.run([exe, d, b, str(ROUNDS), "--resident"], check=True, stdout=subprocess.DEVNULL, timeout=600)
+    for name in ("trajectory_est_complete.txt", "trajectory_est_data.txt", "map.txt", "map_appearances.txt"):
+        x, y = np.loadtxt(a + name), np.loadtxt(b + name)
+        assert x.shape == y.shape, name
+        assert np.array_equal(x, y), (name, float(np.abs(x - y).max()))

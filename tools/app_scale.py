@@ -12,11 +12,12 @@ d = tempfile.mkdtemp(prefix="seq_")
 out = tempfile.mkdtemp(prefix="out_")
 t = time.time(); seq = vo.synth.sequence(seed=3000, n_frames=F, n_visible=N); vo.synth.write_sequence(seq, d)
 print("dataset: %d frames x ~%d points written in %.1f s" % (F, N, time.time() - t), flush=True)
-t = time.time()
-r = subprocess.run([os.path.join(ROOT, "apps/bin/vo_complete"), d, out, "100"], capture_output=True, text=True)
-dt = time.time() - t
-print("vo_complete: rc %d, %.2f s total, %.1f ms per frame" % (r.returncode, dt, dt * 1e3 / F), flush=True)
-print(r.stdout.splitlines()[-1] if r.stdout else r.stderr[-500:])
+for extra in ([], ["--resident"]):
+    t = time.time()
+    r = subprocess.run([os.path.join(ROOT, "apps/bin/vo_complete"), d, out, "100"] + extra, capture_output=True, text=True)
+    dt = time.time() - t
+    print("vo_complete %s: rc %d, %.2f s total (file parsing included), %.1f ms per frame" % (" ".join(extra) or "(frame by frame)", r.returncode, dt, dt * 1e3 / F), flush=True)
+    print(r.stdout.splitlines()[-1] if r.stdout else r.stderr[-500:])
 t = time.time()
 e = subprocess.run([os.path.join(ROOT, "apps/bin/evaluate"), d, out], capture_output=True, text=True)
 print("evaluate: %.2f s" % (time.time() - t)); print(e.stdout)
