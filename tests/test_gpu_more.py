@@ -209,7 +209,15 @@ def test_device_pose_reset_and_in_place_pose(vo, ctx, o32):
 def test_handles_do_not_leak_device_memory(vo):
     """create / use / destroy contexts, solvers, pipelines and events repeatedly: free device memory returns to
     where it was (graphs, workspaces and streams are released with their owners)."""
-    import torch
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")                        # the runtime the library itself is linked against
+
+    def free_bytes():
+        free, total = C.c_size_t(), C.c_size_t()
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
     fp = vo.synth.frame_pair(3000, seed=901)
 
     def cycle():
@@ -225,10 +233,8 @@ def test_handles_do_not_leak_device_memory(vo):
         c.synchronize(); c.close()
 
     cycle()
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info(0)
+    free0 = free_bytes()
     for _ in range(8):
         cycle()
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info(0)
+    free1 = free_bytes()
     assert free0 - free1 < 8 << 20, (free0, free1)          # < 8 MiB drift over 8 cycles

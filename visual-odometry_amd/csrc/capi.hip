@@ -76,10 +76,7 @@ struct vo_ctx {
   DevBuf out[3];
   DevBuf counts;      // small device ints
   DevBuf batch_pack;  // packed correspondences of the batched solver
-  DevBuf prune_ws;    // bucket-sorted copies of the matcher
-  // the cell-hash variant keeps its histograms clear between calls; a workspace that was (re)allocated, used
-  // by another variant or laid out for other sizes is cleared once
-  const void* cells_ws_ptr = nullptr; size_t cells_ws_cap = 0; int cells_nt = -1, cells_nq = -1, cells_frames = -1;
+  DevBuf prune_ws;    // sorted copies / tables of the matcher's sorted variants
   int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan, 3 cell-hash search
   bool capturing = false;
 };
@@ -725,16 +722,6 @@ static int match_workspace(vo_ctx* c, int variant, int nt, int nq, int n_frames,
   if (variant == 1) return VO_OK;
   VO_HIP_CHECK(c->prune_ws.ensure(match_workspace_bytes(variant, nt, nq, n_frames), c->stream));
   *ws = c->prune_ws.p;
-  if (variant == 3) {
-    if (c->cells_ws_ptr != c->prune_ws.p || c->cells_ws_cap != c->prune_ws.cap || c->cells_nt != nt || c->cells_nq != nq ||
-        c->cells_frames != n_frames) {
-      VO_HIP_CHECK(hipMemsetAsync(c->prune_ws.p, 0, c->prune_ws.cap, c->stream));
-      c->cells_ws_ptr = c->prune_ws.p; c->cells_ws_cap = c->prune_ws.cap;
-      c->cells_nt = nt; c->cells_nq = nq; c->cells_frames = n_frames;
-    }
-  } else {
-    c->cells_ws_ptr = nullptr;                     // another variant scribbles over the buffer
-  }
   return VO_OK;
 }
 

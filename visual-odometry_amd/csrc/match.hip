@@ -593,7 +593,10 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
 // Exact search over a 4-D grid.  Four appearance components (largest spreads, taken from components 4..9
 // when those are not much flatter, so the filter on components 0..3 keeps its selectivity) are cut into
 // nc_k = clamp(floor(spread_k / R), 1, 20) cells of width >= R each (R = 1.001 radius); both sets are
-// counting-sorted by the cell key ((c0*nc1 + c1)*nc2 + c2)*nc3 + c3 (<= 160 000 cells).  A query visits,
+// counting-sorted by the cell key ((c0*nc1 + c1)*nc2 + c2)*nc3 + c3 (<= 160 000 cells) in two levels, both on
+// LDS histograms (a global atomic per point -- 64 scattered memory-side requests per wave -- was 2x dearer):
+// level 1 as the bucket sort above with the <= 400 coarse bins (c0, c1); level 2 one workgroup per coarse bin,
+// ordering its points by the <= 400 fine bins (c2, c3) and writing that bin's slice of the start table.  A query visits,
 // per component, the cells [cell(q_k - R), cell(q_k + R)] (<= 3, same monotone cell function as the sort):
 // <= 27 runs of tree points that are contiguous along the last component.  A tree point outside that box
 // differs from the query by more than the radius in one component, so that single non-negative term of the
@@ -603,9 +606,9 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
 // On U(-1,1)^10 appearances a query meets ~25 candidates instead of ~1400 in the 2-D rectangle.
 constexpr int HK = 4;                    // hashed components
 constexpr int HNC = 20;                  // cells per component, at most
-constexpr int HSEG = 1024;               // bins per workgroup of the local scan
-constexpr int HBINS = ((HNC * HNC * HNC * HNC + HSEG) / HSEG) * HSEG;   // 160768: every key + the end sentinel
-constexpr int HBLK = HBINS / HSEG;       // 157
+constexpr int HCOARSE = HNC * HNC;       // coarse bins (c0, c1) / fine bins (c2, c3), at most
+constexpr int HCPAD = 512;               // HCOARSE rounded up to a power of two (scan width)
+constexpr int HBINS = HNC * HNC * HNC * HNC + 1;   // every key + the end sentinel
 
 struct CellParams {
   int dim[HK];
@@ -669,22 +672,20 @@ __device__ __forceinline__ int cell_key(const float* v, const CellParams& cp) {
 
 // per-frame workspace of the cell variant (bytes, every block 256-aligned)
 struct CellWs {
-  size_t tree_rec, tree_idx, qry_rec, hist_t, hist_q, start_t, start_q, blk_t, blk_q, key, rank, cp, total;
+  size_t tree_rec, tree_idx, qry_rec, t1_pre, t1_meta, q1_rec, block_hist, coarse_start, start_t, cp, total;
 };
 static CellWs cell_ws_layout(int nt, int nq) {
   CellWs w;
   size_t o = 0;
   w.tree_rec = o; o += align256(sizeof(float) * 4 * (size_t)nt);      // filter prefix (components 0..3) in cell order
   w.tree_idx = o; o += align256(sizeof(int) * (size_t)nt);            // original index of the sorted tree point
-  w.qry_rec = o; o += align256(sizeof(float) * 12 * (size_t)nq);
-  w.hist_t = o; o += align256(sizeof(int) * (size_t)HBINS);
-  w.hist_q = o; o += align256(sizeof(int) * (size_t)HBINS);
-  w.start_t = o; o += align256(sizeof(int) * (size_t)HBINS);
-  w.start_q = o; o += align256(sizeof(int) * (size_t)HBINS);
-  w.blk_t = o; o += align256(sizeof(int) * 256);
-  w.blk_q = o; o += align256(sizeof(int) * 256);
-  w.key = o; o += align256(sizeof(int) * ((size_t)nt + (size_t)nq));
-  w.rank = o; o += align256(sizeof(int) * ((size_t)nt + (size_t)nq));
+  w.qry_rec = o; o += align256(sizeof(float) * 12 * (size_t)nq);      // queries in cell order: 10 components, index, key
+  w.t1_pre = o; o += align256(sizeof(float) * 4 * (size_t)nt);        // level 1 (coarse order): tree prefix,
+  w.t1_meta = o; o += align256(sizeof(int) * 2 * (size_t)nt);         //   (original index, fine bin)
+  w.q1_rec = o; o += align256(sizeof(float) * 12 * (size_t)nq);       //   query records (slot 11 = fine bin)
+  w.block_hist = o; o += align256(sizeof(int) * (size_t)SORT_BLOCKS * 2 * HCPAD);
+  w.coarse_start = o; o += align256(sizeof(int) * 2 * (HCPAD + 1));
+  w.start_t = o; o += align256(sizeof(int) * (size_t)HBINS);          // first tree slot of every cell (+ end sentinel)
   w.cp = o; o += align256(sizeof(CellParams));
   w.total = o;
   return w;
@@ -706,44 +707,59 @@ struct CellArgs {
   int rs_capacity;
 };
 
-// key + rank of every point (rank = arrival order inside its cell, from the histogram atomic)
-__global__ __launch_bounds__(256) void cell_hist_kernel(CellArgs a) {
+__device__ __forceinline__ void load10(const float* p, float* v) {
+  const float2* src = reinterpret_cast<const float2*>(p);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { const float2 t = src[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+}
+__device__ __forceinline__ void cell_bins(const float* v, const CellParams& cp, int& coarse, int& fine) {
+  int c[HK];
+#pragma unroll
+  for (int j = 0; j < HK; ++j) c[j] = cell_of(pick10(v, cp.dim[j]), cp.lo[j], cp.scale[j], cp.nc[j]);
+  coarse = c[0] * cp.nc[1] + c[1];
+  fine = c[2] * cp.nc[3] + c[3];
+}
+
+// level 1, histogram: SORT_BLOCKS workgroups, each a contiguous slice of [0,nt) tree + [nt,nt+nq) queries
+__global__ __launch_bounds__(256) void cell_coarse_hist_kernel(CellArgs a) {
   const int f = blockIdx.z;
   const float* tree = a.tree + f * a.tree_stride; const float* qry = a.qry + f * a.qry_stride;
   char* ws = a.ws + f * a.ws_stride;
+  __shared__ int s_h[2 * HCPAD];
   __shared__ CellParams s_cp;
-  if (threadIdx.x == 0) {
+  for (int k = threadIdx.x; k < 2 * HCPAD; k += 256) s_h[k] = 0;
+  if (threadIdx.x == 0) {                        // every workgroup derives the same parameters from the min/max words
     s_cp = make_cell_params(frame_ptr(a.mm, f * a.mm_stride), a.radius);
     if (blockIdx.x == 0) *reinterpret_cast<CellParams*>(ws + a.w.cp) = s_cp;
   }
   __syncthreads();
   const CellParams cp = s_cp;
-  int* hist_t = reinterpret_cast<int*>(ws + a.w.hist_t); int* hist_q = reinterpret_cast<int*>(ws + a.w.hist_q);
-  int* key = reinterpret_cast<int*>(ws + a.w.key); int* rank = reinterpret_cast<int*>(ws + a.w.rank);
-  const int total = a.nt + a.nq;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+  int lo, hi;
+  sort_slice(a.nt, a.nq, lo, hi);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
     const bool is_t = i < a.nt;
-    const float2* src = reinterpret_cast<const float2*>(is_t ? tree + 10 * (size_t)i : qry + 10 * (size_t)(i - a.nt));
     float v[10];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { const float2 t = src[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
-    const int kk = cell_key(v, cp);
-    key[i] = kk;
-    rank[i] = atomicAdd(&(is_t ? hist_t : hist_q)[kk], 1);
+    load10(is_t ? tree + 10 * (size_t)i : qry + 10 * (size_t)(i - a.nt), v);
+    int coarse, fine;
+    cell_bins(v, cp, coarse, fine);
+    atomicAdd(&s_h[(is_t ? 0 : HCPAD) + coarse], 1);
   }
+  __syncthreads();
+  int* block_hist = reinterpret_cast<int*>(ws + a.w.block_hist);
+  for (int k = threadIdx.x; k < 2 * HCPAD; k += 256) block_hist[(size_t)blockIdx.x * 2 * HCPAD + k] = s_h[k];
 }
 
-// exclusive scan of HSEG bins per workgroup (histogram -> start, histogram cleared); workgroup totals to blk[]
-__global__ __launch_bounds__(HSEG) void cell_scan_local_kernel(CellArgs a) {
-  const int f = blockIdx.z, set = blockIdx.y;
+// level 1, offsets: grid 2 (tree half, query half) x HCPAD threads (one coarse bin each): exclusive scan over the
+// workgroups and over the bins -> coarse_start[2][HCPAD+1]; block_hist becomes per-(workgroup, bin) offsets
+__global__ __launch_bounds__(HCPAD) void cell_coarse_offsets_kernel(CellArgs a) {
+  const int f = blockIdx.z;
   char* ws = a.ws + f * a.ws_stride;
-  int* hist = reinterpret_cast<int*>(ws + (set ? a.w.hist_q : a.w.hist_t)) + (size_t)blockIdx.x * HSEG;
-  int* start = reinterpret_cast<int*>(ws + (set ? a.w.start_q : a.w.start_t)) + (size_t)blockIdx.x * HSEG;
-  int* blk = reinterpret_cast<int*>(ws + (set ? a.w.blk_q : a.w.blk_t));
-  __shared__ int s_w[HSEG / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int v = hist[tid];
-  if (v) hist[tid] = 0;                                  // leaves the histogram clear for the next call
+  int* block_hist = reinterpret_cast<int*>(ws + a.w.block_hist);
+  int* starts = reinterpret_cast<int*>(ws + a.w.coarse_start);
+  __shared__ int s_w[HCPAD / 64];
+  const int half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int v = 0;
+  for (int b = 0; b < SORT_BLOCKS; ++b) v += block_hist[(size_t)b * 2 * HCPAD + half * HCPAD + tid];
   int incl = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
@@ -751,19 +767,78 @@ __global__ __launch_bounds__(HSEG) void cell_scan_local_kernel(CellArgs a) {
   __syncthreads();
   int woff = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < HSEG / 64; ++w) { const int c = s_w[w]; if (w < wave) woff += c; tot += c; }
-  start[tid] = woff + incl - v;
-  if (tid == 0) blk[blockIdx.x] = tot;
+  for (int w = 0; w < HCPAD / 64; ++w) { const int c = s_w[w]; if (w < wave) woff += c; tot += c; }
+  int run = woff + incl - v;
+  starts[half * (HCPAD + 1) + tid] = run;
+  if (tid == 0) starts[half * (HCPAD + 1) + HCPAD] = tot;
+  for (int b = 0; b < SORT_BLOCKS; ++b) {
+    int* slot = &block_hist[(size_t)b * 2 * HCPAD + half * HCPAD + tid];
+    const int h = *slot;
+    *slot = run;
+    run += h;
+  }
 }
 
-// exclusive scan of the HBLK workgroup totals (one workgroup per set and frame)
-__global__ __launch_bounds__(256) void cell_scan_top_kernel(CellArgs a) {
-  const int f = blockIdx.z, set = blockIdx.y;
+// level 1, placement: coarse order.  Tree: filter prefix + (original index, fine bin); queries: whole record
+__global__ __launch_bounds__(256) void cell_coarse_place_kernel(CellArgs a) {
+  const int f = blockIdx.z;
+  const float* tree = a.tree + f * a.tree_stride; const float* qry = a.qry + f * a.qry_stride;
   char* ws = a.ws + f * a.ws_stride;
-  int* blk = reinterpret_cast<int*>(ws + (set ? a.w.blk_q : a.w.blk_t));
+  const int* block_off = reinterpret_cast<const int*>(ws + a.w.block_hist);
+  float4* t1_pre = reinterpret_cast<float4*>(ws + a.w.t1_pre);
+  int2* t1_meta = reinterpret_cast<int2*>(ws + a.w.t1_meta);
+  float* q1_rec = reinterpret_cast<float*>(ws + a.w.q1_rec);
+  __shared__ int s_off[2 * HCPAD];
+  for (int k = threadIdx.x; k < 2 * HCPAD; k += 256) s_off[k] = block_off[(size_t)blockIdx.x * 2 * HCPAD + k];
+  __syncthreads();
+  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
+  int lo, hi;
+  sort_slice(a.nt, a.nq, lo, hi);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const bool is_t = i < a.nt;
+    const int idx = is_t ? i : i - a.nt;
+    float v[10];
+    load10((is_t ? tree : qry) + 10 * (size_t)idx, v);
+    int coarse, fine;
+    cell_bins(v, cp, coarse, fine);
+    const int pos = atomicAdd(&s_off[(is_t ? 0 : HCPAD) + coarse], 1);
+    if (is_t) {
+      t1_pre[pos] = make_float4(v[0], v[1], v[2], v[3]);
+      t1_meta[pos] = make_int2(idx, fine);
+    } else {
+      float4* dst = reinterpret_cast<float4*>(q1_rec + 12 * (size_t)pos);
+      dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+      dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+      dst[2] = make_float4(v[8], v[9], __int_as_float(idx), __int_as_float(fine));
+    }
+  }
+}
+
+// level 2: one workgroup per (coarse bin, set): counting sort of the bin's points by fine bin in LDS; the tree
+// side also writes the bin's slice of the start table (absolute slots) -- the last coarse bin adds the sentinel
+__global__ __launch_bounds__(256) void cell_fine_kernel(CellArgs a) {
+  const int f = blockIdx.z, set = blockIdx.y, coarse = blockIdx.x;
+  char* ws = a.ws + f * a.ws_stride;
+  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
+  const int n_coarse = cp.nc[0] * cp.nc[1], n_fine = cp.nc[2] * cp.nc[3];
+  if (coarse >= n_coarse) return;
+  const int* cstart = reinterpret_cast<const int*>(ws + a.w.coarse_start) + set * (HCPAD + 1);
+  const int begin = cstart[coarse], end = cstart[coarse + 1];
+  __shared__ int s_cnt[HCPAD];
   __shared__ int s_w[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int v = tid < HBLK ? blk[tid] : 0;
+  for (int k = tid; k < HCPAD; k += 256) s_cnt[k] = 0;
+  __syncthreads();
+  const int2* t1_meta = reinterpret_cast<const int2*>(ws + a.w.t1_meta);
+  const float* q1_rec = reinterpret_cast<const float*>(ws + a.w.q1_rec);
+  for (int i = begin + tid; i < end; i += 256) {
+    const int fine = set ? __float_as_int(q1_rec[12 * (size_t)i + 11]) : t1_meta[i].y;
+    atomicAdd(&s_cnt[fine], 1);
+  }
+  __syncthreads();
+  // exclusive scan of the HCPAD counters: two per thread
+  const int c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+  const int v = c0 + c1;
   int incl = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
@@ -772,43 +847,33 @@ __global__ __launch_bounds__(256) void cell_scan_top_kernel(CellArgs a) {
   int woff = 0;
 #pragma unroll
   for (int w = 0; w < 4; ++w) if (w < wave) woff += s_w[w];
-  if (tid < HBLK) blk[tid] = woff + incl - v;
-}
-
-__device__ __forceinline__ int cell_start(const int* __restrict__ hist, const int* __restrict__ blk, int key) {
-  return hist[key] + blk[key >> 10];
-}
-static_assert(HSEG == 1024, "cell_start shifts by 10");
-
-__global__ __launch_bounds__(256) void cell_place_kernel(CellArgs a) {
-  const int f = blockIdx.z;
-  const float* tree = a.tree + f * a.tree_stride; const float* qry = a.qry + f * a.qry_stride;
-  char* ws = a.ws + f * a.ws_stride;
-  const int* hist_t = reinterpret_cast<const int*>(ws + a.w.start_t); const int* hist_q = reinterpret_cast<const int*>(ws + a.w.start_q);
-  const int* blk_t = reinterpret_cast<const int*>(ws + a.w.blk_t); const int* blk_q = reinterpret_cast<const int*>(ws + a.w.blk_q);
-  const int* key = reinterpret_cast<const int*>(ws + a.w.key); const int* rank = reinterpret_cast<const int*>(ws + a.w.rank);
-  float* tree_rec = reinterpret_cast<float*>(ws + a.w.tree_rec); float* qry_rec = reinterpret_cast<float*>(ws + a.w.qry_rec);
-  int* tree_idx = reinterpret_cast<int*>(ws + a.w.tree_idx);
-  const int total = a.nt + a.nq;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const bool is_t = i < a.nt;
-    const int idx = is_t ? i : i - a.nt;
-    const float2* src = reinterpret_cast<const float2*>((is_t ? tree : qry) + 10 * (size_t)idx);
-    float2 v[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) v[k] = src[k];
-    const int kk = key[i];
-    const int pos = cell_start(is_t ? hist_t : hist_q, is_t ? blk_t : blk_q, kk) + rank[i];
-    if (is_t) {
-      // tree: only what the filter reads travels (16 B + the index); a survivor's other components are fetched
-      // from the caller's array through the index
-      reinterpret_cast<float4*>(tree_rec)[pos] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
-      tree_idx[pos] = idx;
-    } else {
-      float4* dst = reinterpret_cast<float4*>(qry_rec + 12 * (size_t)pos);
-      dst[0] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
-      dst[1] = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
-      dst[2] = make_float4(v[4].x, v[4].y, __int_as_float(idx), __int_as_float(kk));
+  const int ex = begin + woff + incl - v;
+  __syncthreads();
+  s_cnt[2 * tid] = ex; s_cnt[2 * tid + 1] = ex + c0;               // cursors = absolute first slots
+  if (set == 0) {
+    int* start_t = reinterpret_cast<int*>(ws + a.w.start_t) + (size_t)coarse * n_fine;
+    if (2 * tid < n_fine) start_t[2 * tid] = ex;
+    if (2 * tid + 1 < n_fine) start_t[2 * tid + 1] = ex + c0;
+    if (coarse == n_coarse - 1 && tid == 0) start_t[n_fine] = end;   // end sentinel (= nt)
+  }
+  __syncthreads();
+  if (set == 0) {
+    const float4* t1_pre = reinterpret_cast<const float4*>(ws + a.w.t1_pre);
+    float4* tree_pre = reinterpret_cast<float4*>(ws + a.w.tree_rec);
+    int* tree_idx = reinterpret_cast<int*>(ws + a.w.tree_idx);
+    for (int i = begin + tid; i < end; i += 256) {
+      const int2 m = t1_meta[i];
+      const int pos = atomicAdd(&s_cnt[m.y], 1);
+      tree_pre[pos] = t1_pre[i];
+      tree_idx[pos] = m.x;
+    }
+  } else {
+    float4* qry_rec = reinterpret_cast<float4*>(ws + a.w.qry_rec);
+    const float4* src = reinterpret_cast<const float4*>(q1_rec);
+    for (int i = begin + tid; i < end; i += 256) {
+      const float4 r0 = src[3 * (size_t)i], r1 = src[3 * (size_t)i + 1], r2 = src[3 * (size_t)i + 2];
+      const int pos = atomicAdd(&s_cnt[__float_as_int(r2.w)], 1);
+      qry_rec[3 * (size_t)pos] = r0; qry_rec[3 * (size_t)pos + 1] = r1; qry_rec[3 * (size_t)pos + 2] = r2;
     }
   }
 }
@@ -820,7 +885,6 @@ __global__ __launch_bounds__(256) void cell_search_kernel(CellArgs a) {
   const int f = blockIdx.z;
   char* ws = a.ws + f * a.ws_stride;
   const int* __restrict__ start_t = reinterpret_cast<const int*>(ws + a.w.start_t);
-  const int* __restrict__ blk_t = reinterpret_cast<const int*>(ws + a.w.blk_t);
   const float4* __restrict__ tree_pre = reinterpret_cast<const float4*>(ws + a.w.tree_rec);
   const int* __restrict__ tree_idx = reinterpret_cast<const int*>(ws + a.w.tree_idx);
   const float* __restrict__ tree = a.tree + f * a.tree_stride;
@@ -890,7 +954,7 @@ __global__ __launch_bounds__(256) void cell_search_kernel(CellArgs a) {
         const bool in = in01 && c2 <= c_hi[2];
         const int key0 = ((c0 * cp.nc[1] + c1) * cp.nc[2] + c2) * cp.nc[3];
         const int ka = in ? key0 + c_lo[3] : 0, kb = in ? key0 + c_hi[3] + 1 : 0;
-        const int sa = start_t[ka] + blk_t[ka >> 10], sb = start_t[kb] + blk_t[kb >> 10];
+        const int sa = start_t[ka], sb = start_t[kb];
         rp[i2] = in ? sa : 0; re[i2] = in ? sb : 0;
       }
 #pragma unroll
@@ -924,18 +988,15 @@ static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tr
   const unsigned Z = (unsigned)n_frames;
   hipError_t e = hipMemsetAsync(ws, 0xff, 128 * (size_t)n_frames, st);
   if (e != hipSuccess) return e;
-  // the histograms must be all-zero on entry: the caller clears a (re)allocated workspace once, every call
-  // leaves them clear again (cell_scan_local_kernel)
   MatchStrides ms;
   ms.tree = tree_stride; ms.qry = qry_stride; ms.best = best_stride; ms.ws = 0; ms.mm = 128;
   int g = (nt + nq + 255) / 256;
   hipLaunchKernelGGL(match_minmax_kernel, dim3(g > 256 ? 256 : g, 1, Z), dim3(256), 0, st, tree, nt, qry, nq,
                      static_cast<unsigned*>(ws), ms);
-  const int gp = g > 512 ? 512 : g;
-  hipLaunchKernelGGL(cell_hist_kernel, dim3(gp, 1, Z), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(cell_scan_local_kernel, dim3(HBLK, 2, Z), dim3(HSEG), 0, st, a);
-  hipLaunchKernelGGL(cell_scan_top_kernel, dim3(1, 2, Z), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(cell_place_kernel, dim3(gp, 1, Z), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_coarse_hist_kernel, dim3(SORT_BLOCKS, 1, Z), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_coarse_offsets_kernel, dim3(2, 1, Z), dim3(HCPAD), 0, st, a);
+  hipLaunchKernelGGL(cell_coarse_place_kernel, dim3(SORT_BLOCKS, 1, Z), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_fine_kernel, dim3(HCOARSE, 2, Z), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -136,7 +136,7 @@ hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, co
 // in-place exclusive scan of nb ints per frame (one workgroup per frame), total to total[frame] (and total2[frame])
 hipError_t launch_scan(hipStream_t st, int* counts, int nb, int* total, int* total2 = nullptr, int n_frames = 1,
                        size_t counts_stride = 0);
-// TreeNode_::fullSearch for every query (workspace: match_cells_workspace_bytes(nt, nq, 1), histograms clear)
+// TreeNode_::fullSearch for every query (workspace: match_cells_workspace_bytes(nt, nq, 1))
 hipError_t launch_radius_search(hipStream_t st, const float* d_tree, int nt, const float* d_qry, int nq, float radius,
                                 int* d_offsets, int32_t* d_indices, int capacity, void* ws);
 
