@@ -663,13 +663,6 @@ __device__ __forceinline__ float pick10(const float* v, int k) {
   return x;
 }
 
-__device__ __forceinline__ int cell_key(const float* v, const CellParams& cp) {
-  int key = 0;
-#pragma unroll
-  for (int j = 0; j < HK; ++j) key = key * cp.nc[j] + cell_of(pick10(v, cp.dim[j]), cp.lo[j], cp.scale[j], cp.nc[j]);
-  return key;
-}
-
 // per-frame workspace of the cell variant (bytes, every block 256-aligned)
 struct CellWs {
   size_t tree_rec, tree_idx, qry_rec, t1_pre, t1_meta, q1_rec, block_hist, coarse_start, start_t, cp, total;
