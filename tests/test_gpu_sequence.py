@@ -133,6 +133,20 @@ def test_upfront_sharded_matching_over_rccl(vo, tmp_path):
     out = json.loads(line)
     assert out["frames"] == 10 and out["ranks"] == 1 and out["identical_to_single_gpu_chain"] is True
     assert out["matches_total"] > 9 * 150
+    assert abs(out["evaluation"]["mean_orientation_error"]) < 1e-5
+    # BASELINE configs[4] in its one-rank form: the reference's example sequence, matcher stage up front over RCCL,
+    # chain on rank 0; the README's scale figure (README.md:74-79; the chain's tail is chaotic)
+    data = os.path.join(ROOT, "tests", "golden", "example_data", "data")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tools", "sharded_sequence.py"), "--data", data],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["frames"] == 121 and out["identical_to_single_gpu_chain"] is True
+    assert abs(out["evaluation"]["inverse_median_ratio"] - 0.47337) < 0.015 * 0.47337, out["evaluation"]
+    assert out["evaluation"]["rmse_position"] < 0.145332 * 1.5, out["evaluation"]
 
 
 def test_overlapped_matcher_gives_identical_chain(vo, ctx, seq_run):

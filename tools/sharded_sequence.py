@@ -41,7 +41,30 @@ def read_dataset(d):
         rows = [ln.split() for ln in open(os.path.join(d, f)).read().splitlines()[3:] if ln.strip()]
         a = np.array([[float(x) for x in r[3:15]] for r in rows], np.float32).reshape(-1, 12)
         frames.append(dict(ids=np.array([int(r[2]) for r in rows], np.int64), pts=a[:, :2].copy(), app=a[:, 2:].copy()))
-    return dict(K=K, H=H, rows=ints["height"], cols=ints["width"], z_near=ints["z_near"], z_far=ints["z_far"], frames=frames)
+    gt = np.array([[float(x) for x in ln.split()[4:7]] for ln in open(os.path.join(d, "trajectory.dat")) if ln.strip()])
+    return dict(K=K, H=H, rows=ints["height"], cols=ints["width"], z_near=ints["z_near"], z_far=ints["z_far"], frames=frames,
+                gt=gt[: len(frames)])
+
+
+def metrics(vo, seq, traj):
+    """the trajectory measures of evaluate.cpp:18-60 (README.md:33-50) against trajectory.dat / the generator:
+    rotation part of rel_est^-1 rel_gt, median translation-norm ratio, position RMSE after rescaling"""
+    H = seq["H"].astype(np.float64)
+    Hi = np.linalg.inv(H)
+    gt = [vo.synth.planar_pose(*g) for g in seq["gt"]]
+    est = [np.eye(4)]
+    for X in traj[1:]:                                   # save_trajectory (files_utils.cpp:136-153): W <- W C X^-1 C^-1
+        est.append(est[-1] @ H @ np.linalg.inv(X.astype(np.float64)) @ Hi)
+    e_th, ratio = [], []
+    for i in range(1, len(gt)):
+        Xr, Xg = np.linalg.inv(est[i - 1]) @ est[i], np.linalg.inv(gt[i - 1]) @ gt[i]
+        e_th.append(float(np.trace(np.eye(3) - Xr[:3, :3].T @ Xg[:3, :3])))
+        ng = np.linalg.norm(Xg[:3, 3])
+        if ng > 0:
+            ratio.append(float(np.linalg.norm(Xr[:3, 3]) / ng))
+    r = float(np.median(ratio))
+    rmse = float(np.sqrt(np.mean([np.linalg.norm(g[:3, 3] - e[:3, 3] / r) ** 2 for g, e in zip(gt, est)])))
+    return {"mean_orientation_error": float(np.mean(e_th)), "inverse_median_ratio": 1.0 / r, "rmse_position": rmse}
 
 
 def main():
@@ -87,7 +110,7 @@ def main():
             out = {"frames": F, "ranks": world, "pairs_per_rank": hi - lo, "match_and_gather_ms": (t1 - t0) * 1e3,
                    "chain_ms": (t2 - t1) * 1e3, "matches_total": int(counts[1:, 0].sum()),
                    "identical_to_single_gpu_chain": same,
-                   "last_pose_t": [float(x) for x in traj[-1][:3, 3]]}
+                   "last_pose_t": [float(x) for x in traj[-1][:3, 3]], "evaluation": metrics(vo, seq, traj)}
         dist.barrier()
     if rank == 0:
         print(json.dumps(out))
