@@ -359,6 +359,17 @@ def batched_leg(torch, vo, ctx, stream, args):
             r = _batched_run(torch, vo, ctx, stream, args, P)
             out["chip_full"].append({"pairs": P, "kernel_ms": r["kernel_ms"], "iters_per_sec": r["iters_per_sec"],
                                      "achieved_GBs": r["roofline"]["achieved"], "frac": r["roofline"]["frac"]})
+        # a few problems per call: the launch-per-round form (problem = grid dimension) against one workgroup per problem
+        out["few_problems"] = []
+        for P in (4, 16):
+            row = {"pairs": P}
+            for form, name in ((1, "launch_per_round"), (2, "one_workgroup_per_problem"), (0, "auto")):
+                _chk(ctx.lib, ctx.lib.vo_picp_batch_set_form(ctx.h, form))
+                r = _batched_run(torch, vo, ctx, stream, args, P)
+                row[name + "_ms"] = r["ms_per_call"]
+            _chk(ctx.lib, ctx.lib.vo_picp_batch_set_form(ctx.h, 0))
+            row["iters_per_sec"] = P * args.iters / (row["auto_ms"] * 1e-3)
+            out["few_problems"].append(row)
     return out
 
 

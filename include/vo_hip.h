@@ -157,6 +157,11 @@ int vo_picp_get_system(vo_picp *s, float H[36], float b[6]);
  * d_T0: n_problems initial poses (16 floats each) or NULL for identity;
  * d_T_out: n_problems final poses; d_stats_out (may be NULL): per problem
  * {chi_inliers, chi_outliers, (float)num_inliers, 0}. */
+/* Two forms, same results up to the summation order of H and b: one workgroup per problem with all rounds
+ * inside one launch (many problems: HBM-bound streaming), or one launch per round with many workgroups per
+ * problem (a few problems: the single-problem kernels with the problem as a grid dimension; 4x faster at 4
+ * problems of 50k, equal at ~30).  form 0 (default) picks by a cost model, 1 / 2 force one. */
+int vo_picp_batch_set_form(vo_ctx *ctx, int form);
 int vo_picp_solve_batch_dev(vo_ctx *ctx, int n_problems, int rows, int cols, int z_near, int z_far,
                             const float K[9], float kernel_threshold, int keep_outliers,
                             const float *d_world_xyz, size_t world_stride, const float *d_meas_uv,

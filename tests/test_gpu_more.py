@@ -68,8 +68,12 @@ def test_many_correspondences_per_thread_and_reuse(vo, ctx, o32):
     s.close()
 
 
-def test_batched_keep_outliers_and_empty_problems(vo, ctx, o32):
-    P, n, iters, thr = 4, 2000, 6, 40.0
+@pytest.mark.parametrize("form,iters", [(1, 6), (2, 6), (0, 6), (1, 0), (2, 0), (1, 1)])
+def test_batched_keep_outliers_and_empty_problems(vo, ctx, o32, form, iters):
+    """both forms of the batched solver (1: one launch per round, problem = grid dimension; 2: one workgroup per
+    problem), with outliers kept, an empty problem, per-problem starting poses and zero / one round"""
+    assert ctx.lib.vo_picp_batch_set_form(ctx.h, form) == 0 and ctx.lib.vo_picp_batch_set_form(ctx.h, 3) != 0
+    P, n, thr = 4, 2000, 40.0
     fps = [vo.synth.frame_pair(n, seed=5000 + p) for p in range(P)]
     pairs = [_corr(f) for f in fps]
     pairs[2] = pairs[2][:0]                               # an empty problem: pose must stay at T0
@@ -102,6 +106,7 @@ def test_batched_keep_outliers_and_empty_problems(vo, ctx, o32):
     assert np.array_equal(T[2].reshape(4, 4).T, T0[2])    # H = I, b = 0: dx = 0 exactly
     for x in d + [d_T, d_stats]:
         ctx.free(x)
+    ctx.lib.vo_picp_batch_set_form(ctx.h, 0)
 
 
 def test_frame_pipeline_device_resident(vo, ctx, o32):
@@ -206,35 +211,16 @@ def test_device_pose_reset_and_in_place_pose(vo, ctx, o32):
     ctx.free(d_I); s.close()
 
 
-def test_handles_do_not_leak_device_memory(vo):
-    """create / use / destroy contexts, solvers, pipelines and events repeatedly: free device memory returns to
-    where it was (graphs, workspaces and streams are released with their owners)."""
-    import ctypes as C
-    hip = C.CDLL("libamdhip64.so")                        # the runtime the library itself is linked against
-
-    def free_bytes():
-        free, total = C.c_size_t(), C.c_size_t()
-        assert hip.hipDeviceSynchronize() == 0
-        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
-        return free.value
-
-    fp = vo.synth.frame_pair(3000, seed=901)
-
-    def cycle():
-        c = vo.Context(0)
-        p = vo.FramePipeline(c, fp, n_iters=6)
-        p.frame(); p.capture_frame(); p.frame_graph()
-        assert p.counts()[0] == 3000
-        p.close()
-        for mode in (1, 2, 3):
-            c.lib.vo_match_set_mode(c.h, mode)
-            assert len(vo.compute_correspondences_images(fp["ref_app"], fp["cur_app"], ctx=c)) == 3000
-        e = vo.Event(c); e.record(c); e.wait(c); e.close()
-        c.synchronize(); c.close()
-
-    cycle()
-    free0 = free_bytes()
-    for _ in range(8):
-        cycle()
-    free1 = free_bytes()
-    assert free0 - free1 < 8 << 20, (free0, free1)          # < 8 MiB drift over 8 cycles
+def test_handles_do_not_leak_device_memory():
+    """create / use / destroy contexts, solvers, pipelines, graphs and events repeatedly: free device memory returns
+    to where it was.  Measured in a process of its own (tools/leak_probe.py): inside the test process the runtime's
+    own pools and other tests' live objects move the number."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "leak_probe.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = re.findall(r"^(\w+)\s*: drift MiB after each cycle:(.*)$", r.stdout, flags=re.M)
+    assert [k for k, _ in rows] == ["ctx", "event", "match", "frame", "capture", "all"], r.stdout
+    for kind, vals in rows:
+        drift = [float(x) for x in vals.split()]
+        assert max(drift) < 8.0 and drift[-1] <= drift[0] + 1.0, (kind, drift)      # no growth from cycle to cycle

@@ -60,9 +60,12 @@ def test_frame_50k_against_oracle(vo, ctx, o32, o64, big):
     s.close()
 
 
-def test_batched_solver_matches_single(vo, ctx):
-    """vo_picp_solve_batch_dev on P problems == P independent PICPSolver runs."""
+@pytest.mark.parametrize("form", [1, 2])
+def test_batched_solver_matches_single(vo, ctx, form):
+    """vo_picp_solve_batch_dev on P problems == P independent PICPSolver runs, in both forms (1: one launch per
+    round, the single-problem kernels with the problem as a grid dimension; 2: one workgroup per problem)."""
     import ctypes as C
+    assert ctx.lib.vo_picp_batch_set_form(ctx.h, form) == 0
     P, n, iters = 5, 3000, 15
     fps = [vo.synth.frame_pair(n, seed=4000 + p) for p in range(P)]
     lib = ctx.lib
@@ -98,6 +101,7 @@ def test_batched_solver_matches_single(vo, ctx):
         s.close()
     for d in (d_world, d_meas, d_pairs, d_n, d_T, d_stats):
         ctx.free(d)
+    ctx.lib.vo_picp_batch_set_form(ctx.h, 0)
 
 
 def test_beyond_benchmark_size_300k(vo, ctx, o32, o64):

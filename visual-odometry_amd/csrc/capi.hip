@@ -76,8 +76,10 @@ struct vo_ctx {
   DevBuf out[3];
   DevBuf counts;      // small device ints
   DevBuf batch_pack;  // packed correspondences of the batched solver
+  DevBuf batch_states, batch_partials;   // launch-per-round form of the batched solver: per-problem state + partial rows
   DevBuf prune_ws;    // sorted copies / tables of the matcher's sorted variants
   int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan, 3 cell-hash search
+  int batch_form = 0; // batched solver: 0 auto, 1 one launch per round, 2 one workgroup per problem
   bool capturing = false;
 };
 
@@ -160,7 +162,7 @@ int vo_ctx_destroy(vo_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   c->scratch.release(); c->best.release(); c->table.release(); c->counts.release();
-  c->batch_pack.release(); c->prune_ws.release();
+  c->batch_pack.release(); c->prune_ws.release(); c->batch_states.release(); c->batch_partials.release();
   for (auto& b : c->in) b.release();
   for (auto& b : c->out) b.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -686,6 +688,13 @@ int vo_picp_get_system(vo_picp* s, float H[36], float b[6]) {
   return r;
 }
 
+int vo_picp_batch_set_form(vo_ctx* c, int form) {
+  VO_REQUIRE(c, "ctx is null");
+  VO_REQUIRE(form >= 0 && form <= 2, "form must be 0 (auto), 1 (one launch per round) or 2 (one workgroup per problem)");
+  c->batch_form = form;
+  return VO_OK;
+}
+
 int vo_picp_solve_batch_dev(vo_ctx* c, int n_problems, int rows, int cols, int z_near, int z_far,
                             const float K[9], float thr, int keep_outliers, const float* d_world,
                             size_t world_stride, const float* d_meas, size_t meas_stride,
@@ -711,6 +720,29 @@ int vo_picp_solve_batch_dev(vo_ctx* c, int n_problems, int rows, int cols, int z
   a.n_world = (int)world_stride; a.n_meas = (int)meas_stride;
   VO_HIP_CHECK(c->batch_pack.ensure(sizeof(float) * 5 * a.cap * (size_t)n_problems, c->stream));
   a.packed = c->batch_pack.as<float>();
+  a.states = nullptr; a.partials = nullptr; a.params = nullptr; a.grid = 0;
+  static const int env_form = [] { const char* e = getenv("VO_PICP_BATCH_FORM"); return e ? atoi(e) : 0; }();
+  const int form = c->batch_form ? c->batch_form : env_form;
+  const bool rounds = form == 1 || (form != 2 && picp_batch_prefers_rounds(n_problems, a.cap, n_iters, c->n_cu));
+  if (rounds && !c->capturing) {
+    // a few problems: one launch per round with many workgroups per problem (the single-problem kernel with the
+    // problem as a grid dimension) instead of one workgroup per problem
+    a.grid = picp_grid_for((int)a.cap, c->n_cu);
+    const size_t rows = ((size_t)a.grid + 255) & ~(size_t)255;
+    const size_t part_bytes = sizeof(float) * 2 * rows * PICP_PSTRIDE * (size_t)n_problems;
+    VO_HIP_CHECK(c->batch_states.ensure(sizeof(PicpState) * (size_t)n_problems + sizeof(PicpParams), c->stream));
+    VO_HIP_CHECK(c->batch_partials.ensure(part_bytes, c->stream));
+    VO_HIP_CHECK(hipMemsetAsync(c->batch_partials.p, 0, part_bytes, c->stream));       // rows >= grid must read as zero
+    PicpParams hp;
+    memset(&hp, 0, sizeof(hp));
+    hp.cam = a.cam; hp.thr = thr; hp.damping = 1.f; hp.keep_outliers = a.keep_outliers; hp.n_corr = 0;
+    PicpParams* d_params = reinterpret_cast<PicpParams*>(c->batch_states.as<char>() + sizeof(PicpState) * (size_t)n_problems);
+    VO_HIP_CHECK(hipMemcpyAsync(d_params, &hp, sizeof(hp), hipMemcpyHostToDevice, c->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(c->stream));                                       // hp lives on this stack frame
+    a.states = c->batch_states.as<PicpState>();
+    a.partials = c->batch_partials.as<float>();
+    a.params = d_params;
+  }
   VO_HIP_CHECK(launch_picp_batch(c->stream, a));
   return VO_OK;
 }

@@ -21,6 +21,8 @@
 // Reduction: per-thread registers -> DPP row reduction (16 lanes) -> LDS across
 // rows and waves -> workgroup partial.  No MFMA: the normal equations are a
 // tall-skinny accumulate (21+6+3 sums per correspondence), not a contraction.
+#include <stdlib.h>
+
 #include "vo_internal.h"
 
 namespace vo {
@@ -216,10 +218,26 @@ __global__ __launch_bounds__(256) void picp_pack_kernel(const int32_t* __restric
 // ---- one Gauss-Newton round ---------------------------------------------------
 // PRE:    first derive this round's pose from the partials of launch it-1.
 // FINISH: only derive the pose (single workgroup), publish the statistics.
-template <bool PRE, bool FINISH, bool PINHOLE, bool KEEP>
+// BATCH: several problems per launch, problem = blockIdx.y (a few problems with many workgroups each; many problems
+// go through picp_batch_kernel instead).  Everything per-problem is reached through strides.
+struct RoundBatch {
+  const int* n_pairs;        // live correspondences per problem
+  size_t cap;                // capacity of a problem's packed arrays
+  size_t partials_stride;    // floats between two problems' partial buffers
+  float* T_out;              // FINISH: n_problems x 16
+  float* stats_out;          // FINISH: n_problems x 4, or null
+};
+
+template <bool PRE, bool FINISH, bool PINHOLE, bool KEEP, bool BATCH = false>
 __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams* __restrict__ P,
                                                                 PicpState* S, PackedCorr pk,
-                                                                float* partials, int it, int nb) {
+                                                                float* partials, int it, int nb, RoundBatch rb) {
+  if (BATCH) {
+    const size_t p = blockIdx.y;
+    S += p;
+    pk.base += p * 5 * rb.cap;
+    partials += p * rb.partials_stride;
+  }
   __shared__ __attribute__((aligned(16))) float s_acc[PICP_BLOCK * ACC_STRIDE];   // also the staging of the partial rows
   __shared__ float s_part[8 * 32];
   __shared__ float s_sys[PICP_BLOCK / 64][48];
@@ -248,7 +266,11 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams
   }
 
   // (2) this thread's first correspondence (coalesced SoA loads), in flight during the solve
-  const int n = P->n_corr;
+  int n = P->n_corr;
+  if (BATCH) {
+    n = rb.n_pairs[blockIdx.y];
+    n = n < 0 ? 0 : ((size_t)n > rb.cap ? (int)rb.cap : n);
+  }
   int i = blockIdx.x * PICP_BLOCK + tid;
   bool have = !FINISH && i < n;
   float x = 0.f, y = 0.f, z = 0.f, u = 0.f, v = 0.f;
@@ -319,6 +341,14 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams
           S->chi_in = s_stat[0];
           S->chi_out = s_stat[1];
           S->n_in = (int)(s_stat[2] + 0.5f);
+          if (BATCH) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) rb.T_out[16 * (size_t)blockIdx.y + k] = T16[k];
+            if (rb.stats_out) {
+              float* so = rb.stats_out + 4 * (size_t)blockIdx.y;
+              so[0] = s_stat[0]; so[1] = s_stat[1]; so[2] = s_stat[2]; so[3] = 0.f;
+            }
+          }
         }
       }
       T = uniform_pose(Tn);
@@ -383,12 +413,12 @@ template <bool PINHOLE, bool KEEP>
 static void launch_rounds_t(hipStream_t st, const PicpParams* d_params, PicpState* d_state, PackedCorr pk,
                             float* d_partials, int grid, int n_iters) {
   hipLaunchKernelGGL((picp_round_kernel<false, false, PINHOLE, KEEP>), dim3(grid), dim3(PICP_BLOCK), 0, st,
-                     d_params, d_state, pk, d_partials, 0, grid);
+                     d_params, d_state, pk, d_partials, 0, grid, RoundBatch{});
   for (int it = 1; it < n_iters; ++it)
     hipLaunchKernelGGL((picp_round_kernel<true, false, PINHOLE, KEEP>), dim3(grid), dim3(PICP_BLOCK), 0, st,
-                       d_params, d_state, pk, d_partials, it, grid);
+                       d_params, d_state, pk, d_partials, it, grid, RoundBatch{});
   hipLaunchKernelGGL((picp_round_kernel<true, true, false, false>), dim3(1), dim3(PICP_BLOCK), 0, st, d_params,
-                     d_state, pk, d_partials, n_iters, grid);
+                     d_state, pk, d_partials, n_iters, grid, RoundBatch{});
 }
 
 hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpState* d_state,
@@ -415,6 +445,13 @@ __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
   const float* world = a.world + 3 * (size_t)p * a.world_stride;
   const float* meas = a.meas + 2 * (size_t)p * a.meas_stride;
   float* dst = a.packed + (size_t)p * 5 * a.cap;
+  if (a.states && blockIdx.x == 0 && threadIdx.x < 12) {       // launch-per-round form: the problem's starting pose
+    const int k = threadIdx.x;
+    float v;
+    if (a.T0) v = k < 9 ? a.T0[16 * (size_t)p + (k % 3) + 4 * (k / 3)] : a.T0[16 * (size_t)p + 12 + (k - 9)];
+    else v = (k < 9 && (k % 4) == 0) ? 1.f : 0.f;
+    a.states[p].pose[0][k] = v;
+  }
   const float qnan = __int_as_float(0x7fc00000);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int m = pairs[2 * i], w = pairs[2 * i + 1];
@@ -425,6 +462,14 @@ __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
     }
     dst[i] = x; dst[a.cap + i] = y; dst[2 * a.cap + i] = z; dst[3 * a.cap + i] = u; dst[4 * a.cap + i] = v;
   }
+}
+
+// zero rounds in the launch-per-round form: T_out = T0 (or identity), statistics zero
+__global__ void picp_batch_T0_out_kernel(BatchArgs a) {
+  const size_t p = blockIdx.x;
+  const int k = threadIdx.x;
+  if (k < 16) a.T_out[16 * p + k] = a.T0 ? a.T0[16 * p + k] : ((k % 5) == 0 ? 1.f : 0.f);
+  if (k < 4 && a.stats_out) a.stats_out[4 * p + k] = 0.f;
 }
 
 template <bool PINHOLE, bool KEEP>
@@ -533,7 +578,45 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
     pose_to_T16(T, T16);
 #pragma unroll
     for (int k = 0; k < 16; ++k) a.T_out[16 * (size_t)p + k] = T16[k];
+    if (a.n_iters <= 0 && a.stats_out) {                   // no round: no statistics
+      float* so = a.stats_out + 4 * (size_t)p;
+      so[0] = so[1] = so[2] = so[3] = 0.f;
+    }
   }
+}
+
+// launch-per-round form for a few problems: n_iters + 1 launches, grid (workgroups per problem, problems)
+template <bool PINHOLE, bool KEEP>
+static void launch_rounds_batch_t(hipStream_t st, const BatchArgs& a) {
+  const size_t rows = ((size_t)a.grid + 255) & ~(size_t)255;
+  const RoundBatch rb{a.n_pairs, a.cap, 2 * rows * PICP_PSTRIDE, a.T_out, a.stats_out};
+  const PackedCorr pk{a.packed, a.cap};
+  const dim3 g(a.grid, a.n_problems), b(PICP_BLOCK);
+  if (a.n_iters <= 0) {       // no round: the starting poses are the result
+    hipLaunchKernelGGL(picp_batch_T0_out_kernel, dim3(a.n_problems), dim3(64), 0, st, a);
+    return;
+  }
+  hipLaunchKernelGGL((picp_round_kernel<false, false, PINHOLE, KEEP, true>), g, b, 0, st, a.params, a.states, pk, a.partials,
+                     0, a.grid, rb);
+  for (int it = 1; it < a.n_iters; ++it)
+    hipLaunchKernelGGL((picp_round_kernel<true, false, PINHOLE, KEEP, true>), g, b, 0, st, a.params, a.states, pk, a.partials,
+                       it, a.grid, rb);
+  hipLaunchKernelGGL((picp_round_kernel<true, true, false, false, true>), dim3(1, a.n_problems), b, 0, st, a.params, a.states,
+                     pk, a.partials, a.n_iters, a.grid, rb);
+}
+
+// One workgroup per problem (all rounds in one launch) costs ~36 us per round at 50k correspondences whatever the problem
+// count (up to one per CU); the launch-per-round form costs ~5.5 us per round while its workgroups fit the chip once and
+// grows with their number.
+bool picp_batch_prefers_rounds(int n_problems, size_t cap, int n_iters, int n_cu) {
+  if (n_iters <= 0 || n_cu <= 0) return false;
+  // per-round cost model fitted on MI355X (tools/batch_forms.py, 50k correspondences: the forms cross at ~30 problems):
+  // launch per round 5.5 us + 1.3 us per further "wave" of workgroups over the CUs; one workgroup per problem 36 us per
+  // 50k correspondences and per ceil(problems / CUs)
+  const double wg_waves = (double)n_problems * (double)picp_grid_for((int)cap, n_cu) / (double)n_cu;
+  const double t_rounds = 5.5 + 1.3 * (wg_waves > 1.0 ? wg_waves - 1.0 : 0.0);
+  const double t_onewg = 36.0 * ((double)cap / 50000.0) * (double)((n_problems + n_cu - 1) / n_cu);
+  return t_rounds < t_onewg;
 }
 
 hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a) {
@@ -543,6 +626,13 @@ hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a) {
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(picp_batch_pack_kernel, dim3(gx, a.n_problems), dim3(256), 0, st, a);
   const bool ph = is_pinhole(a.cam.K), keep = a.keep_outliers != 0;
+  if (a.states) {
+    if (ph && !keep) launch_rounds_batch_t<true, false>(st, a);
+    else if (ph) launch_rounds_batch_t<true, true>(st, a);
+    else if (!keep) launch_rounds_batch_t<false, false>(st, a);
+    else launch_rounds_batch_t<false, true>(st, a);
+    return hipGetLastError();
+  }
   const dim3 g(a.n_problems), b(PICP_BATCH_BLOCK);
   if (ph && !keep) hipLaunchKernelGGL((picp_batch_kernel<true, false>), g, b, 0, st, a);
   else if (ph) hipLaunchKernelGGL((picp_batch_kernel<true, true>), g, b, 0, st, a);

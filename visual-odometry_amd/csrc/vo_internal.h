@@ -79,8 +79,15 @@ struct BatchArgs {
   float* packed;       // workspace: n_problems x 5 x cap floats
   size_t cap;          // per-array capacity (multiple of 4)
   int n_world, n_meas; // bounds for index checks (per problem)
+  // launch-per-round form only (a few problems, many workgroups each): per-problem state and partial buffers
+  PicpState* states;   // n_problems, or null (one-workgroup-per-problem kernel)
+  float* partials;     // n_problems x 2 x round_up(grid,256) x PICP_PSTRIDE floats, zero-padded rows
+  const PicpParams* params;   // device copy of (cam, thr, damping, keep_outliers); n_corr unused
+  int grid;            // workgroups per problem
 };
 hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a);
+// when is the launch-per-round form the faster one?  (measured: DESIGN.md section 4.1)
+bool picp_batch_prefers_rounds(int n_problems, size_t cap, int n_iters, int n_cu);
 
 // ---- geometry / matcher / join (geom.hip, match.hip) -------------------------
 struct Workspace;  // scratch owned by the context
