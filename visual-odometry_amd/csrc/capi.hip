@@ -77,6 +77,8 @@ struct vo_ctx {
   DevBuf counts;      // small device ints
   DevBuf batch_pack;  // packed correspondences of the batched solver
   DevBuf batch_states, batch_partials;   // launch-per-round form of the batched solver: per-problem state + partial rows
+  PicpParams batch_params_host{};        //   its parameter block as last uploaded, and where
+  const PicpParams* batch_params_dev = nullptr;
   DevBuf prune_ws;    // sorted copies / tables of the matcher's sorted variants
   int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan, 3 cell-hash search
   int batch_form = 0; // batched solver: 0 auto, 1 one launch per round, 2 one workgroup per problem
@@ -730,15 +732,22 @@ int vo_picp_solve_batch_dev(vo_ctx* c, int n_problems, int rows, int cols, int z
     a.grid = picp_grid_for((int)a.cap, c->n_cu);
     const size_t rows = ((size_t)a.grid + 255) & ~(size_t)255;
     const size_t part_bytes = sizeof(float) * 2 * rows * PICP_PSTRIDE * (size_t)n_problems;
+    const size_t states_cap = c->batch_states.cap;
     VO_HIP_CHECK(c->batch_states.ensure(sizeof(PicpState) * (size_t)n_problems + sizeof(PicpParams), c->stream));
+    if (c->batch_states.cap != states_cap) c->batch_params_dev = nullptr;               // reallocated: nothing uploaded yet
     VO_HIP_CHECK(c->batch_partials.ensure(part_bytes, c->stream));
     VO_HIP_CHECK(hipMemsetAsync(c->batch_partials.p, 0, part_bytes, c->stream));       // rows >= grid must read as zero
     PicpParams hp;
     memset(&hp, 0, sizeof(hp));
     hp.cam = a.cam; hp.thr = thr; hp.damping = 1.f; hp.keep_outliers = a.keep_outliers; hp.n_corr = 0;
     PicpParams* d_params = reinterpret_cast<PicpParams*>(c->batch_states.as<char>() + sizeof(PicpState) * (size_t)n_problems);
-    VO_HIP_CHECK(hipMemcpyAsync(d_params, &hp, sizeof(hp), hipMemcpyHostToDevice, c->stream));
-    VO_HIP_CHECK(hipStreamSynchronize(c->stream));                                       // hp lives on this stack frame
+    if (d_params != c->batch_params_dev || memcmp(&hp, &c->batch_params_host, sizeof(hp)) != 0) {
+      // the parameter block changes rarely: upload (and wait, the source is this object) only then
+      c->batch_params_host = hp;
+      VO_HIP_CHECK(hipMemcpyAsync(d_params, &c->batch_params_host, sizeof(hp), hipMemcpyHostToDevice, c->stream));
+      VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+      c->batch_params_dev = d_params;
+    }
     a.states = c->batch_states.as<PicpState>();
     a.partials = c->batch_partials.as<float>();
     a.params = d_params;
