@@ -72,7 +72,8 @@ int vo_ctx_device_info(vo_ctx *ctx, char *name, int name_len, int *n_cu);
  * already have been sized by a previous identical call) becomes one replayable graph:
  * a whole frame (match, join, transform, n rounds, triangulate = ~80 launches) then
  * costs one launch on the host.  Device pointers and counts are baked in; data and
- * device-side counts may change between replays. */
+ * device-side counts may change between replays.  A graph (like a vo_picp or a vo_event)
+ * must be destroyed before the context it was made on. */
 typedef struct vo_graph vo_graph;
 int vo_ctx_begin_capture(vo_ctx *ctx);
 int vo_ctx_end_capture(vo_ctx *ctx, vo_graph **out);
