@@ -339,11 +339,18 @@ __global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a0) {
     const size_t dst = (size_t)a.counts[blockIdx.x] + r;
     a.out_xyz[3 * dst] = p[0]; a.out_xyz[3 * dst + 1] = p[1]; a.out_xyz[3 * dst + 2] = p[2];
     if (a.out_pairs) { a.out_pairs[2 * dst] = i2; a.out_pairs[2 * dst + 1] = (int)dst; }   // utils.cpp:97
-    if (a.out_app && a.app2) {                                                               // utils.cpp:127
-      const float2* src = reinterpret_cast<const float2*>(a.app2 + 10 * (size_t)i2);
-      float2* o = reinterpret_cast<float2*>(a.out_app + 10 * dst);
-#pragma unroll
-      for (int j = 0; j < 5; ++j) o[j] = src[j];
+  }
+  if (a.out_app && a.app2) {                                                                 // utils.cpp:127
+    // appearance copy-through, cooperatively: the survivors' source indices go through LDS in output order, then
+    // consecutive threads move consecutive 8-byte pieces (coalesced stores, 40-byte gathers)
+    __shared__ int s_src[CB];
+    if (ok) s_src[r] = i2;
+    __syncthreads();
+    const float2* app = reinterpret_cast<const float2*>(a.app2);
+    float2* o = reinterpret_cast<float2*>(a.out_app) + 5 * (size_t)a.counts[blockIdx.x];
+    for (int j = threadIdx.x; j < 5 * total; j += CB) {
+      const int pt = j / 5;
+      o[j] = app[5 * (size_t)s_src[pt] + (j - 5 * pt)];
     }
   }
 }
