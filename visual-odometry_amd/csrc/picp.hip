@@ -228,10 +228,9 @@ struct RoundBatch {
   float* stats_out;          // FINISH: n_problems x 4, or null
 };
 
-template <bool PRE, bool FINISH, bool PINHOLE, bool KEEP, bool BATCH = false>
-__global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams* __restrict__ P,
-                                                                PicpState* S, PackedCorr pk,
-                                                                float* partials, int it, int nb, RoundBatch rb) {
+template <bool PRE, bool FINISH, bool PINHOLE, bool KEEP, bool BATCH>
+__device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P, PicpState* S, PackedCorr pk,
+                                                float* partials, int it, int nb, const RoundBatch& rb) {
   if (BATCH) {
     const size_t p = blockIdx.y;
     S += p;
@@ -384,6 +383,21 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams
   VO_STAMP(6);
 }
 
+// single problem: no batch view among the kernel arguments (a launch graph of 101 of these is replayed per frame)
+template <bool PRE, bool FINISH, bool PINHOLE, bool KEEP>
+__global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams* __restrict__ P, PicpState* S,
+                                                                PackedCorr pk, float* partials, int it, int nb) {
+  picp_round_body<PRE, FINISH, PINHOLE, KEEP, false>(P, S, pk, partials, it, nb, RoundBatch{});
+}
+
+// a few problems per launch: problem = blockIdx.y
+template <bool PRE, bool FINISH, bool PINHOLE, bool KEEP>
+__global__ __launch_bounds__(PICP_BLOCK) void picp_round_batch_kernel(const PicpParams* __restrict__ P, PicpState* S,
+                                                                      PackedCorr pk, float* partials, int it, int nb,
+                                                                      RoundBatch rb) {
+  picp_round_body<PRE, FINISH, PINHOLE, KEEP, true>(P, S, pk, partials, it, nb, rb);
+}
+
 int picp_grid_for(int n_corr, int n_cu) {
   int g = (n_corr + PICP_BLOCK - 1) / PICP_BLOCK;
   if (g < 1) g = 1;
@@ -413,12 +427,12 @@ template <bool PINHOLE, bool KEEP>
 static void launch_rounds_t(hipStream_t st, const PicpParams* d_params, PicpState* d_state, PackedCorr pk,
                             float* d_partials, int grid, int n_iters) {
   hipLaunchKernelGGL((picp_round_kernel<false, false, PINHOLE, KEEP>), dim3(grid), dim3(PICP_BLOCK), 0, st,
-                     d_params, d_state, pk, d_partials, 0, grid, RoundBatch{});
+                     d_params, d_state, pk, d_partials, 0, grid);
   for (int it = 1; it < n_iters; ++it)
     hipLaunchKernelGGL((picp_round_kernel<true, false, PINHOLE, KEEP>), dim3(grid), dim3(PICP_BLOCK), 0, st,
-                       d_params, d_state, pk, d_partials, it, grid, RoundBatch{});
+                       d_params, d_state, pk, d_partials, it, grid);
   hipLaunchKernelGGL((picp_round_kernel<true, true, false, false>), dim3(1), dim3(PICP_BLOCK), 0, st, d_params,
-                     d_state, pk, d_partials, n_iters, grid, RoundBatch{});
+                     d_state, pk, d_partials, n_iters, grid);
 }
 
 hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpState* d_state,
@@ -596,12 +610,12 @@ static void launch_rounds_batch_t(hipStream_t st, const BatchArgs& a) {
     hipLaunchKernelGGL(picp_batch_T0_out_kernel, dim3(a.n_problems), dim3(64), 0, st, a);
     return;
   }
-  hipLaunchKernelGGL((picp_round_kernel<false, false, PINHOLE, KEEP, true>), g, b, 0, st, a.params, a.states, pk, a.partials,
+  hipLaunchKernelGGL((picp_round_batch_kernel<false, false, PINHOLE, KEEP>), g, b, 0, st, a.params, a.states, pk, a.partials,
                      0, a.grid, rb);
   for (int it = 1; it < a.n_iters; ++it)
-    hipLaunchKernelGGL((picp_round_kernel<true, false, PINHOLE, KEEP, true>), g, b, 0, st, a.params, a.states, pk, a.partials,
+    hipLaunchKernelGGL((picp_round_batch_kernel<true, false, PINHOLE, KEEP>), g, b, 0, st, a.params, a.states, pk, a.partials,
                        it, a.grid, rb);
-  hipLaunchKernelGGL((picp_round_kernel<true, true, false, false, true>), dim3(1, a.n_problems), b, 0, st, a.params, a.states,
+  hipLaunchKernelGGL((picp_round_batch_kernel<true, true, false, false>), dim3(1, a.n_problems), b, 0, st, a.params, a.states,
                      pk, a.partials, a.n_iters, a.grid, rb);
 }
 
