@@ -251,6 +251,17 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
   // written by workgroups on all eight XCDs: Infinity-Cache/HBM round trips that must
   // overlap, not chain).
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+  // The previous round's pose (written by workgroup 0 of the previous launch, i.e. on another XCD for most readers)
+  // goes out with the partial rows, as VECTOR loads: left to the compiler it becomes a scalar load sunk to just before
+  // its use at the end of the solve, and that miss (it shares lgkmcnt with the LDS reads there) then sits on the chain.
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  f4v pz0 = {0.f, 0.f, 0.f, 0.f}, pz1 = pz0, pz2 = pz0;
+  if (PRE) {
+    int lane_zero;                                                     // 0, but opaque to the compiler: keeps the
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));                 // address in a VGPR, hence a vector load
+    const f4v* pp = reinterpret_cast<const f4v*>(S->pose[(it - 1) & 1]) + lane_zero;
+    pz0 = pp[0]; pz1 = pp[1]; pz2 = pp[2];
+  }
   if (PRE) {
     const int nb_pad = (nb + 255) & ~255;
     const float* prev = partials + (size_t)((it - 1) & 1) * nb_pad * PICP_PSTRIDE;
@@ -328,7 +339,11 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     VO_STAMP(2);
     {
-      const Pose Told = uniform_pose(load_pose12(S->pose[(it - 1) & 1]));
+      Pose Tprev;
+      Tprev.R[0] = pz0.x; Tprev.R[1] = pz0.y; Tprev.R[2] = pz0.z; Tprev.R[3] = pz0.w;
+      Tprev.R[4] = pz1.x; Tprev.R[5] = pz1.y; Tprev.R[6] = pz1.z; Tprev.R[7] = pz1.w;
+      Tprev.R[8] = pz2.x; Tprev.t[0] = pz2.y; Tprev.t[1] = pz2.z; Tprev.t[2] = pz2.w;
+      const Pose Told = uniform_pose(Tprev);
       const Pose Tn = picp_tail_wave(sys, Told);
       if (tid == 0 && blockIdx.x == 0) {
         store_pose12(S->pose[FINISH ? 0 : (it & 1)], Tn);
