@@ -281,6 +281,17 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     n = rb.n_pairs[blockIdx.y];
     n = n < 0 ? 0 : ((size_t)n > rb.cap ? (int)rb.cap : n);
   }
+  // camera and threshold: fetched here, while the partial rows are in flight, and pinned in scalar registers (left
+  // alone the compiler re-loads them after the solve, on the chain)
+  CamK cam = P->cam;
+  float thr = P->thr;
+  float damping = P->damping;
+  asm volatile("" : "+s"(damping), "+s"(nb));
+  if (!FINISH) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) asm volatile("" : "+s"(cam.K[k]));
+    asm volatile("" : "+s"(cam.rows), "+s"(cam.cols), "+s"(cam.z_near), "+s"(cam.z_far), "+s"(thr));
+  }
   int i = blockIdx.x * PICP_BLOCK + tid;
   bool have = !FINISH && i < n;
   float x = 0.f, y = 0.f, z = 0.f, u = 0.f, v = 0.f;
@@ -322,7 +333,7 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
 #pragma unroll
       for (int k = 0; k < 8; ++k) { const float4 t4 = row[k]; tsum += t4.x; tsum += t4.y; tsum += t4.z; tsum += t4.w; }
       if (lane < 36) {
-        const float hv = diag ? tsum + 1.f * P->damping : tsum;
+        const float hv = diag ? tsum + 1.f * damping : tsum;
         sys[lane] = hv;
         if (FINISH && blockIdx.x == 0 && wave == 0) S->H[(lane % 6) * 6 + lane / 6] = hv;    // col-major
       } else if (lane < 42) {
@@ -374,8 +385,6 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     T = uniform_pose(load_pose12(S->pose[0]));
   }
 
-  const CamK cam = P->cam;
-  const float thr = P->thr;
   float acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
