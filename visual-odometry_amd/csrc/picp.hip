@@ -408,10 +408,13 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
 }
 
 // single problem: no batch view among the kernel arguments (a launch graph of 101 of these is replayed per frame)
+// Its arguments are all scalars (no aggregate), so that -amdgpu-kernarg-preload-count hands every one of them to
+// the wave in SGPRs at launch: no kernel-argument load at the head of the chain.
 template <bool PRE, bool FINISH, bool PINHOLE, bool KEEP>
 __global__ __launch_bounds__(PICP_BLOCK) void picp_round_kernel(const PicpParams* __restrict__ P, PicpState* S,
-                                                                PackedCorr pk, float* partials, int it, int nb) {
-  picp_round_body<PRE, FINISH, PINHOLE, KEEP, false>(P, S, pk, partials, it, nb, RoundBatch{});
+                                                                float* pk_base, size_t pk_cap, float* partials, int it,
+                                                                int nb) {
+  picp_round_body<PRE, FINISH, PINHOLE, KEEP, false>(P, S, PackedCorr{pk_base, pk_cap}, partials, it, nb, RoundBatch{});
 }
 
 // a few problems per launch: problem = blockIdx.y
@@ -451,12 +454,12 @@ template <bool PINHOLE, bool KEEP>
 static void launch_rounds_t(hipStream_t st, const PicpParams* d_params, PicpState* d_state, PackedCorr pk,
                             float* d_partials, int grid, int n_iters) {
   hipLaunchKernelGGL((picp_round_kernel<false, false, PINHOLE, KEEP>), dim3(grid), dim3(PICP_BLOCK), 0, st,
-                     d_params, d_state, pk, d_partials, 0, grid);
+                     d_params, d_state, pk.base, pk.cap, d_partials, 0, grid);
   for (int it = 1; it < n_iters; ++it)
     hipLaunchKernelGGL((picp_round_kernel<true, false, PINHOLE, KEEP>), dim3(grid), dim3(PICP_BLOCK), 0, st,
-                       d_params, d_state, pk, d_partials, it, grid);
+                       d_params, d_state, pk.base, pk.cap, d_partials, it, grid);
   hipLaunchKernelGGL((picp_round_kernel<true, true, false, false>), dim3(1), dim3(PICP_BLOCK), 0, st, d_params,
-                     d_state, pk, d_partials, n_iters, grid);
+                     d_state, pk.base, pk.cap, d_partials, n_iters, grid);
 }
 
 hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpState* d_state,
