@@ -3,10 +3,13 @@
 // association.  Same call sequence, same output files (written into the
 // current directory or into argv[2]): world.txt, trajectory_gt.txt, map.txt,
 // map_appearances.txt, trajectory_est_complete.txt, trajectory_est_data.txt.
-//   usage: vo_complete <data dir> [output dir] [rounds=100] [--resident]
+//   usage: vo_complete <data dir> [output dir] [rounds=100] [--resident] [--exact]
 // --resident: the same sequence through vo::DeviceSequence -- all measurement files are read and uploaded first, the
 // whole frame chain runs on the GPU without a host round trip per frame, the map is built afterwards from the
 // per-frame clouds.  Same outputs.
+// --exact: the solver in reference-order arithmetic (PICPSolver::setExact): every pose of the chain is then
+// bit-identical to the reference's float32 arithmetic given the same first relative pose.
+// Also written: poses_raw.txt, one camera pose per line (row-major 4x4, %.9g = exact float32 round trip).
 #include <cstdio>
 #include <iostream>
 
@@ -14,8 +17,18 @@
 
 using namespace vo;
 
+static void write_poses_raw(const std::string& file, const IsometryVector& trajectory) {
+  std::FILE* f = std::fopen(file.c_str(), "w");
+  if (!f) return;
+  for (const auto& X : trajectory) {
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) std::fprintf(f, "%.9g ", X(r, c));
+    std::fprintf(f, "\n");
+  }
+  std::fclose(f);
+}
+
 // the device-resident form of the loop below: same call sequence, the frame chain inside vo::DeviceSequence
-static int run_resident(const std::string& path, const std::string& out, int rounds, const std::string& first_file,
+static int run_resident(const std::string& path, const std::string& out, int rounds, bool exact, const std::string& first_file,
                         const std::string& second_file, const std::set<std::string>& files) {
   std::vector<PointCloudVector<2>> frames;
   std::vector<std::string> names{first_file, second_file};
@@ -35,6 +48,7 @@ static int run_resident(const std::string& path, const std::string& out, int rou
   if (!get_camera_params(path + "camera.dat", int_params, k, H)) { std::cout << "Unable to get camera parameters\n"; return -1; }
   Camera cam(int_params[3], int_params[2], int_params[0], int_params[1], k);
   DeviceSequence seq(cam, frames, rounds);
+  seq.setExact(exact);
   seq.run();
   const IsometryVector trajectory = seq.trajectory();          // waits for the chain
   // map upkeep afterwards, in frame order (vo_complete.cpp:145-147,175-176,181)
@@ -55,18 +69,27 @@ static int run_resident(const std::string& path, const std::string& out, int rou
   write_eigen_vectors_to_file(out + "map_appearances.txt", map.appearances());
   save_trajectory(out + "trajectory_est_complete.txt", trajectory, H);
   save_trajectory(out + "trajectory_est_data.txt", trajectory, H, true);
+  write_poses_raw(out + "poses_raw.txt", trajectory);
   return 0;
 }
 
 int main(int argc, char* argv[]) {
-  if (argc < 2) { std::cout << "Error: need path parameter to read data" << std::endl; return -1; }
-  std::string path(argv[1]);
+  // flags first, wherever they stand; what is left are the positional arguments
+  bool resident = false, exact = false;
+  std::vector<std::string> pos;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a(argv[i]);
+    if (a == "--resident") resident = true;
+    else if (a == "--exact") exact = true;
+    else if (a.rfind("--", 0) == 0) { std::cout << "unknown option " << a << std::endl; return -1; }
+    else pos.push_back(a);
+  }
+  if (pos.empty()) { std::cout << "Error: need path parameter to read data" << std::endl; return -1; }
+  std::string path(pos[0]);
   if (path.back() != '/') path.push_back('/');
-  std::string out = argc > 2 ? argv[2] : ".";
+  std::string out = pos.size() > 1 ? pos[1] : ".";
   if (out.back() != '/') out.push_back('/');
-  bool resident = false;
-  for (int i = 1; i < argc; ++i) if (std::string(argv[i]) == "--resident") { resident = true; for (int j = i; j + 1 < argc; ++j) argv[j] = argv[j + 1]; --argc; --i; }
-  const int rounds = argc > 3 ? std::atoi(argv[3]) : 100;
+  const int rounds = pos.size() > 2 ? std::atoi(pos[2].c_str()) : 100;
   try {
     save_gt_trajectory(path + "trajectory.dat", out + "trajectory_gt.txt");
     const std::regex pattern("^meas-\\d.*\\.dat$");
@@ -77,7 +100,7 @@ int main(int argc, char* argv[]) {
     const auto second_file = *(files.erase(files.begin()));
     files.erase(files.begin());
 
-    if (resident) return run_resident(path, out, rounds, first_file, second_file, files);
+    if (resident) return run_resident(path, out, rounds, exact, first_file, second_file, files);
     PointCloudVector<2> reference_pc, current_pc;
     if (!get_meas_content(path + first_file, reference_pc)) { std::cout << "Unable to open file measurement file 0\n"; return -1; }
     if (!get_meas_content(path + second_file, current_pc)) { std::cout << "Unable to open file measurement file 1\n"; return -1; }
@@ -105,6 +128,7 @@ int main(int argc, char* argv[]) {
     trajectory.push_back(X);
     PICPSolver solver;
     solver.setKernelThreshold(10000);
+    solver.setExact(exact);
 
     reference_pc = current_pc;   // correspondences_world now reads (ref_idx,world_idx)
     PointCloudVector<3> triangulated_transformed, map;
@@ -135,6 +159,7 @@ int main(int argc, char* argv[]) {
     write_eigen_vectors_to_file(out + "map_appearances.txt", map.appearances());
     save_trajectory(out + "trajectory_est_complete.txt", trajectory, H);
     save_trajectory(out + "trajectory_est_data.txt", trajectory, H, true);
+    write_poses_raw(out + "poses_raw.txt", trajectory);
     return 0;
   } catch (const vo::Error& e) {
     std::fprintf(stderr, "vo_complete: %s\n", e.what());

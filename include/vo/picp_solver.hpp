@@ -9,9 +9,12 @@
 //    0 and has no setter (picp_solver.cpp:11,103-107).
 //  * init() copies the point vectors to the GPU (the reference keeps raw
 //    pointers, picp_solver.cpp:21-22): changing them afterwards needs a new init().
-//  * the correspondences are uploaded when the vector (address, size, sampled
-//    content) changes between calls; solve(corr, keep, n) runs n rounds with no
-//    host round trip at all.
+//  * every oneRound honours the vector it is given, like the reference
+//    (picp_solver.cpp:62): the library compares it in full with its GPU copy and
+//    uploads it again when anything changed (in-place edits included);
+//    solve(corr, keep, n) runs n rounds with no host round trip at all.
+//  * setExact(true) switches the handle to reference-order arithmetic: results
+//    bit-identical to the reference's scalar float32 loop (vo_picp_set_exact).
 #pragma once
 
 #include "camera.hpp"
@@ -22,8 +25,17 @@ class PICPSolver {
  public:
   PICPSolver() { check(vo_picp_create(default_context().handle(), &h_), "vo_picp_create"); }
   ~PICPSolver() { vo_picp_destroy(h_); }
-  PICPSolver(const PICPSolver&) = delete;
-  PICPSolver& operator=(const PICPSolver&) = delete;
+  // copyable like the reference's (picp_solver.h has no copy restrictions): a copy is a fresh device twin with the
+  // same settings; like the reference's raw point-vector pointers, the points need a new init() to be shared safely
+  PICPSolver(const PICPSolver& o) : _camera(o._camera), exact_(o.exact_) {
+    check(vo_picp_create(default_context().handle(), &h_), "vo_picp_create");
+    setKernelThreshold(o.kernelThreshold());
+    setExact(o.exact_);
+  }
+  PICPSolver& operator=(const PICPSolver& o) {
+    if (this != &o) { _camera = o._camera; setKernelThreshold(o.kernelThreshold()); setExact(o.exact_); }
+    return *this;
+  }
 
   //! init method, call it at the beginning (picp_solver.cpp:16-23)
   void init(const Camera& camera, const Vector3fVector& world_points, const Vector2fVector& image_points) {
@@ -61,11 +73,15 @@ class PICPSolver {
     check(vo_picp_solve(h_, pair_data(correspondences), static_cast<int>(correspondences.size()),
                         keep_outliers ? 1 : 0, n_iters), "PICPSolver::solve");
   }
+  //! reference-order arithmetic: bit-identical to the reference's float32 loop (extension, off by default)
+  void setExact(bool on) { check(vo_picp_set_exact(h_, on ? 1 : 0), "PICPSolver::setExact"); exact_ = on; }
+  bool exact() const { return exact_; }
   vo_picp* handle() const { return h_; }
 
  protected:
   vo_picp* h_ = nullptr;
   mutable Camera _camera;
+  bool exact_ = false;
 };
 
 }  // namespace vo

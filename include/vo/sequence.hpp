@@ -61,6 +61,8 @@ class DeviceSequence {
   DeviceSequence& operator=(const DeviceSequence&) = delete;
 
   int frames() const { return F_; }
+  //! reference-order arithmetic for every solve of the chain (vo_picp_set_exact)
+  void setExact(bool on) { check(vo_picp_set_exact(solver_, on ? 1 : 0), "vo_picp_set_exact"); }
 
   //! enqueue the whole sequence; returns after the (host) epipolar initialisation, the chain runs on
   void run() {

@@ -130,12 +130,29 @@ int vo_picp_get_kernel_threshold(vo_picp *s, float *thr);       /* picp_solver.h
 /* oneRound(correspondences, keep_outliers) (picp_solver.cpp:98-112):
  * pairs = (measurement index, world index).  Enqueues one Gauss-Newton
  * iteration and returns without waiting; the pose/statistics getters are the
- * synchronisation points.  The pairs are uploaded when (pointer, count,
- * sampled content) differ from the previous call.  As in the reference it
- * cannot fail on "too few inliers" (min_num_inliers is 0 with no setter). */
+ * synchronisation points.  Like the reference (picp_solver.cpp:62) every call
+ * honours the array it is given: the pairs are compared IN FULL with the copy
+ * already on the GPU (memcmp, ~15 us per 50k pairs) and uploaded again when
+ * anything differs, so editing the vector in place between two rounds is seen.
+ * As in the reference it cannot fail on "too few inliers" (min_num_inliers is
+ * 0 with no setter). */
 int vo_picp_one_round(vo_picp *s, const int32_t *pairs, int n_pairs, int keep_outliers);
 /* n_iters x oneRound with no host round trip in between */
 int vo_picp_solve(vo_picp *s, const int32_t *pairs, int n_pairs, int keep_outliers, int n_iters);
+/* Explicit form of the same, for callers that iterate on one fixed set: hand the pairs over once
+ * (always uploaded), then run rounds on them with no per-call comparison at all. */
+int vo_picp_set_correspondences(vo_picp *s, const int32_t *pairs, int n_pairs);
+int vo_picp_rounds(vo_picp *s, int keep_outliers, int n_iters);
+/* Reference-order arithmetic (off by default).  on != 0: every later round of this handle is computed
+ * with the reference's own rounding -- per-correspondence terms unfused, (J0r*J0c + J1r*J1c)*lambda,
+ * H / b / chi summed sequentially in correspondence order (picp_solver.cpp:62-95), Eigen's pivoted
+ * LDLT with true divisions (:109), sin/cos in double rounded to float (utils.h:16-78) -- so pose,
+ * H, b, chi and the inlier count are BIT-IDENTICAL to the reference's scalar float32 arithmetic
+ * (as restated by oracle/: tests/test_gpu_exact.py).  One workgroup, all rounds in one launch:
+ * a few microseconds per round at the <= 127 points per frame of the reference's dataset, ~1 ms
+ * per round at 50k.  The default (fast) mode differs from it by rounding only (tree reduction,
+ * FMA in the accumulators, Newton reciprocal, float sincos). */
+int vo_picp_set_exact(vo_picp *s, int on);
 /* device pairs; d_n_pairs (may be NULL) points at a device int that overrides
  * n_pairs (<= n_pairs), so the output of the join kernel can be consumed
  * without a host round trip. */

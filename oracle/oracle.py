@@ -151,6 +151,27 @@ class Oracle:
             res["T_trace"] = tT.reshape(n_iters, 4, 4).transpose(0, 2, 1).copy()
         return res
 
+    def picp_solve_raw(self, cam: Camera, world, meas, corr, n_iters: int, kernel_threshold=1000.0,
+                       keep_outliers: bool = False):
+        """n_iters x oneRound from cam.T; per round what the solver holds afterwards, untouched: H WITH the
+        damping (as _H is left, picp_solver.cpp:102), b, (chi_in, chi_out, n_in), pose -- for bitwise checks."""
+        w = self._arr(world, (-1, 3))
+        z = self._arr(meas, (-1, 2))
+        cp = self._pairs(corr)
+        s = self.picp_t()
+        self._f("picp_ctor")(C.byref(s))
+        cs = self._cam(cam)
+        self._f("picp_init")(C.byref(s), C.byref(cs), self._p(w), self._p(z))
+        s.kernel_threshold = kernel_threshold
+        tH = np.zeros((n_iters, 36), dtype=self.dt)
+        tb = np.zeros((n_iters, 6), dtype=self.dt)
+        ts = np.zeros((n_iters, 3), dtype=self.dt)
+        tT = np.zeros((n_iters, 16), dtype=self.dt)
+        self._f("picp_solve_raw")(C.byref(s), self._p(cp), C.c_int(len(cp)), C.c_int(int(keep_outliers)),
+                                  C.c_int(n_iters), self._p(tH), self._p(tb), self._p(ts), self._p(tT))
+        return {"H": tH.reshape(n_iters, 6, 6).transpose(0, 2, 1).copy(), "b": tb, "stats": ts,
+                "T": tT.reshape(n_iters, 4, 4).transpose(0, 2, 1).copy()}
+
     def picp_solve_mt(self, cam: Camera, world, meas, corr, n_iters: int, n_threads: int,
                       kernel_threshold=1000.0, keep_outliers: bool = False):
         """all-cores baseline (float32 only): per-thread partial sums, see vo_oracle.c"""

@@ -351,6 +351,22 @@ void FN(picp_solve)(FN(picp) * s, const int *corr, int n, int keep_outliers, int
   }
 }
 
+/* Same rounds, recording what oneRound LEAVES in the solver after each round, untouched: _H with the
+ * damping on its diagonal (picp_solver.cpp:102), _b, (chi_in, chi_out, n_in), pose.  For bitwise
+ * comparisons (the trace above removes the damping again, which rounds). */
+void FN(picp_solve_raw)(FN(picp) * s, const int *corr, int n, int keep_outliers, int n_iters,
+                        REAL *trace_H, REAL *trace_b, REAL *trace_stats, REAL *trace_T) {
+  for (int it = 0; it < n_iters; ++it) {
+    FN(picp_one_round)(s, corr, n, keep_outliers);
+    for (int i = 0; i < 36; ++i) trace_H[36 * it + i] = s->H[i];
+    for (int i = 0; i < 6; ++i) trace_b[6 * it + i] = s->b[i];
+    trace_stats[3 * it + 0] = s->chi_inliers;
+    trace_stats[3 * it + 1] = s->chi_outliers;
+    trace_stats[3 * it + 2] = (REAL)s->num_inliers;
+    for (int i = 0; i < 16; ++i) trace_T[16 * it + i] = s->cam.T[i];
+  }
+}
+
 /* ---- small inverses used by triangulate_points ------------------------- */
 /* Isometry inverse (Eigen Transform::inverse(Isometry)): R^T, -R^T t */
 void FN(iso_inverse)(const REAL X[16], REAL iX[16]) {

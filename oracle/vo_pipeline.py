@@ -149,7 +149,8 @@ class Map:
                 self.pts.append(p); self.app.append(a)
 
 
-def run_vo_complete(data_dir, rounds=100, o: Oracle | None = None):
+def run_vo_complete(data_dir, rounds=100, o: Oracle | None = None, X0=None):
+    """X0: first relative pose to start the chain from (default: the epipolar initialisation below)."""
     o = o or Oracle(32)
     files = sorted(f for f in os.listdir(data_dir) if re.search(r"^meas-\d.*\.dat$", f))
     K, H, ints = read_camera(os.path.join(data_dir, "camera.dat"))
@@ -157,7 +158,7 @@ def run_vo_complete(data_dir, rounds=100, o: Oracle | None = None):
     ref_pts, ref_app, _ = read_meas(os.path.join(data_dir, files[0]))
     cur_pts, cur_app, _ = read_meas(os.path.join(data_dir, files[1]))
     corr = o.match(ref_app, cur_app)
-    X = estimate_transform(o, K, corr, ref_pts, cur_pts)
+    X = estimate_transform(o, K, corr, ref_pts, cur_pts) if X0 is None else np.asarray(X0, np.float32).reshape(4, 4).copy()
     tri, corr_world, tri_app = o.triangulate(K, X, corr, ref_pts, cur_pts, cur_app)
     traj = [np.eye(4, dtype=np.float32), X.copy()]
     m = Map(); m.update(tri, tri_app)

@@ -80,4 +80,30 @@ void hc_tri_constants(const float* K, const float* X16, float* iK, float* iRiK, 
 }
 
 void hc_v2t(const float* v, float* T16) { pose_to_T16(v2t_euler(v), T16); }
+
+// The arithmetic of picp_exact_kernel on the host: terms by picp_term_exact, entry k summed sequentially in
+// correspondence order, tail picp_update_t<true>.  Records per round H (damping included, col-major), b,
+// (chi_in, chi_out, n_in), pose -- must equal the oracle's picp_solve_raw bit for bit.
+void hc_picp_exact(int rows, int cols, int zn, int zf, const float* K, const float* T16, float thr, int keep,
+                   const float* world, const float* meas, const int* corr, int n, int n_iters, float* tH, float* tb,
+                   float* ts, float* tT) {
+  const CamK cam = mk(rows, cols, zn, zf, K);
+  Pose T = pose_from_T16(T16);
+  for (int it = 0; it < n_iters; ++it) {
+    float acc[NACC];
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float* w = world + 3 * corr[2 * i + 1];
+      const float* z = meas + 2 * corr[2 * i];
+      float term[NTERM];
+      const int f = picp_term_exact(cam, T, thr, w[0], w[1], w[2], z[0], z[1], term);
+      if (!f) continue;
+      if (f == 1 || keep) for (int k = 0; k < 27; ++k) acc[k] += term[k];
+      if (f == 1) { acc[27] += term[27]; acc[29] += 1.f; } else acc[28] += term[27];
+    }
+    T = picp_update_t<true>(acc, 1.f, T, tH + 36 * it, tb + 6 * it);
+    ts[3 * it] = acc[27]; ts[3 * it + 1] = acc[28]; ts[3 * it + 2] = acc[29];
+    pose_to_T16(T, tT + 16 * it);
+  }
+}
 }

@@ -68,11 +68,12 @@ def test_many_correspondences_per_thread_and_reuse(vo, ctx, o32):
     s.close()
 
 
-@pytest.mark.parametrize("form,iters", [(1, 6), (2, 6), (0, 6), (1, 0), (2, 0), (1, 1)])
+@pytest.mark.parametrize("form,iters", [(1, 6), (2, 6), (0, 6), (3, 6), (1, 0), (2, 0), (3, 0), (1, 1)])
 def test_batched_keep_outliers_and_empty_problems(vo, ctx, o32, form, iters):
-    """both forms of the batched solver (1: one launch per round, problem = grid dimension; 2: one workgroup per
-    problem), with outliers kept, an empty problem, per-problem starting poses and zero / one round"""
-    assert ctx.lib.vo_picp_batch_set_form(ctx.h, form) == 0 and ctx.lib.vo_picp_batch_set_form(ctx.h, 3) != 0
+    """every form of the batched solver (1: one launch per round, problem = grid dimension; 2: one workgroup per
+    problem; 3: reference-order arithmetic), with outliers kept, an empty problem, per-problem starting poses and
+    zero / one round"""
+    assert ctx.lib.vo_picp_batch_set_form(ctx.h, 4) != 0 and ctx.lib.vo_picp_batch_set_form(ctx.h, form) == 0
     P, n, thr = 4, 2000, 40.0
     fps = [vo.synth.frame_pair(n, seed=5000 + p) for p in range(P)]
     pairs = [_corr(f) for f in fps]
@@ -103,6 +104,8 @@ def test_batched_keep_outliers_and_empty_problems(vo, ctx, o32, form, iters):
         assert np.abs(Tp - r["T"]).max() < 1e-4
         assert int(st[p, 2]) == r["num_inliers"]
         assert abs(st[p, 1] - r["chi_outliers"]) <= 1e-4 * max(1.0, r["chi_outliers"])
+        if form == 3:                                     # reference-order arithmetic: bit for bit
+            assert np.array_equal(Tp, r["T"]) and (iters == 0 or st[p, 1] == np.float32(r["chi_outliers"]))
     assert np.array_equal(T[2].reshape(4, 4).T, T0[2])    # H = I, b = 0: dx = 0 exactly
     for x in d + [d_T, d_stats]:
         ctx.free(x)

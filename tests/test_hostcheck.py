@@ -150,3 +150,24 @@ def test_tri_constants_and_v2t(hc, o32, vo):
     T = np.zeros(16, np.float32)
     hc.hc_v2t(p(v), p(T))
     assert T.reshape(4, 4).T.tobytes() == o32.v2t_euler(v).tobytes()
+
+
+@pytest.mark.parametrize("thr,keep", [(10000.0, 0), (60.0, 0), (60.0, 1)])
+def test_exact_mode_arithmetic_is_the_oracles_bit_for_bit(hc, o32, vo, thr, keep):
+    """picp_term_exact + sequential sums + picp_update_t<true> (what picp_exact_kernel runs) == ref32, bitwise,
+    over many chained rounds: H (with damping), b, chi, inlier count and pose."""
+    fp = vo.synth.frame_pair(1200, seed=43, drop=0.05, distractors=5, model_drop=0.05)
+    j = o32.join(o32.match(fp["ref_app"], fp["cur_app"]), fp["model_pairs"])
+    cam = Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4))
+    n_it = 25
+    r = o32.picp_solve_raw(cam, fp["model"], fp["cur_pts"], j, n_it, thr, bool(keep))
+    tH = np.zeros((n_it, 36), np.float32); tb = np.zeros((n_it, 6), np.float32)
+    ts = np.zeros((n_it, 3), np.float32); tT = np.zeros((n_it, 16), np.float32)
+    hc.hc_picp_exact(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], p(cm(fp["K"], 3)), p(cm(np.eye(4), 4)),
+                     C.c_float(thr), keep, p(fp["model"]), p(fp["cur_pts"]), p(j), len(j), n_it, p(tH), p(tb), p(ts), p(tT))
+    assert np.array_equal(tH.reshape(n_it, 6, 6).transpose(0, 2, 1), r["H"])
+    assert np.array_equal(tb, r["b"])
+    assert np.array_equal(ts, r["stats"])
+    assert np.array_equal(tT.reshape(n_it, 4, 4).transpose(0, 2, 1), r["T"])
+    if keep == 0 and thr < 100:
+        assert 0 < ts[0, 2] < len(j) and ts[0, 1] > 0       # both branches of the chi test taken

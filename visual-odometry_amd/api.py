@@ -214,7 +214,6 @@ class PICPSolver:
         _chk(self.lib.vo_picp_create(self.ctx.h, C.byref(h)))
         self.h = h
         self._cam = Camera(ctx=self.ctx)
-        self._keep = {}
 
     def close(self):
         if getattr(self, "h", None):
@@ -247,13 +246,20 @@ class PICPSolver:
         _chk(self.lib.vo_picp_set_kernel_threshold(self.h, C.c_float(thr)))
 
     def _pairs(self, correspondences):
-        # keep the converted array alive and stable so the library's upload cache can hit
-        key = id(correspondences)
-        ent = self._keep.get(key)
-        if ent is None or ent[0] is not correspondences:
-            self._keep = {key: (correspondences, _i32pairs(correspondences))}
-            ent = self._keep[key]
-        return ent[1]
+        # converted on every call (no copy for a C-contiguous int32 array): the library compares the whole array
+        # with its GPU copy, so an in-place edit between two rounds is honoured (picp_solver.cpp:62)
+        return _i32pairs(correspondences)
+
+    def setExact(self, on=True):
+        """reference-order arithmetic (vo_picp_set_exact): bit-identical to the reference's float32 loop"""
+        _chk(self.lib.vo_picp_set_exact(self.h, C.c_int(int(bool(on)))))
+
+    def setCorrespondences(self, correspondences):
+        p = _i32pairs(correspondences)
+        _chk(self.lib.vo_picp_set_correspondences(self.h, _ptr(p), C.c_int(len(p))))
+
+    def rounds(self, keep_outliers=False, n_iters=1):
+        _chk(self.lib.vo_picp_rounds(self.h, C.c_int(int(keep_outliers)), C.c_int(n_iters)))
 
     def oneRound(self, correspondences, keep_outliers=False) -> bool:
         """picp_solver.cpp:98-112; pairs are (measurement index, world index)."""

@@ -106,12 +106,13 @@ struct vo_picp {
   const float* d_meas = nullptr;
   int n_world = 0, n_meas = 0;
   bool have_points = false;
-  // cache key of the correspondences already packed
-  const void* key_ptr = nullptr;
-  int key_n = -1;
-  uint64_t key_hash = 0;
-  bool key_dev = false;
+  // host copy of the correspondences already uploaded and packed: a call whose pairs compare equal to it
+  // (whole array, memcmp) skips the upload; anything else -- including an in-place edit -- is re-uploaded
+  std::vector<int32_t> shadow;
+  bool shadow_valid = false;
   bool packed_valid = false;
+  int exact = 0;              // reference-order arithmetic (picp_exact_kernel)
+  int set_n = -1;             // pair count handed over by vo_picp_set_correspondences
   int grid = 1;
   const float* pending_T0 = nullptr;   // device 4x4 to load as the pose by the next pack launch
   int zeroed_for_grid = -1;   // grid the (zero-padded) partial buffers were last cleared for
@@ -472,21 +473,6 @@ __global__ void T16_to_pose12_kernel(const float* T, float* p) {
   else if (k < 12) p[k] = T[12 + (k - 9)];
 }
 
-static uint64_t sample_hash(const int32_t* pairs, int n) {
-  // cheap content fingerprint: <= 64 pairs spread over the array
-  uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
-  const int step = n > 64 ? n / 64 : 1;
-  for (int i = 0; i < n; i += step) {
-    h = (h ^ (uint32_t)pairs[2 * i]) * 1099511628211ull;
-    h = (h ^ (uint32_t)pairs[2 * i + 1]) * 1099511628211ull;
-  }
-  if (n > 0) {
-    h = (h ^ (uint32_t)pairs[2 * (n - 1)]) * 1099511628211ull;
-    h = (h ^ (uint32_t)pairs[2 * (n - 1) + 1]) * 1099511628211ull;
-  }
-  return h;
-}
-
 static int picp_prepare(vo_picp* s, const int32_t* d_pairs, int n_pairs, const int* d_n, int keep_outliers) {
   vo_ctx* c = s->ctx;
   if (!s->have_points) return fail(VO_ERR_NOT_READY, "vo_picp: set_points has not been called");
@@ -533,6 +519,10 @@ static int picp_enqueue(vo_picp* s, int n_iters) {
   PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
   float* partials = s->partials.as<float>();
   const bool pinhole = is_pinhole(s->hp.cam.K), keep = s->hp.keep_outliers != 0;
+  if (s->exact) {
+    VO_HIP_CHECK(launch_picp_exact(c->stream, s->d_params, s->d_state, pk, n_iters));
+    return VO_OK;
+  }
   if (s->use_graph && n_iters >= 2 && !c->capturing) {
     auto key = std::make_tuple(n_iters, s->grid, (const void*)pk.base, pk.cap, (const void*)partials,
                                (pinhole ? 1 : 0) | (keep ? 2 : 0));
@@ -578,31 +568,68 @@ int vo_picp_solve_dev(vo_picp* s, const int32_t* d_pairs, int n_pairs, const int
   if (int r = set_device(s->ctx)) return r;
   // device pairs may have been rewritten in place by the producer: always re-pack
   s->packed_valid = false;
-  s->key_ptr = nullptr; s->key_n = -1;
+  s->shadow_valid = false;
   if (int r = picp_prepare(s, d_pairs, n_pairs, d_n_pairs, keep_outliers)) return r;
   return picp_enqueue(s, n_iters);
+}
+
+// Uploads `pairs` unless the whole array equals what is already packed.  The reference reads the vector on every
+// call (picp_solver.cpp:62): an in-place edit between two rounds must be seen, so the comparison covers every
+// pair (memcmp against a host copy: ~15 us at 50k pairs, no stream synchronisation when nothing changed).
+static int picp_take_pairs(vo_picp* s, const int32_t* pairs, int n_pairs) {
+  vo_ctx* c = s->ctx;
+  const size_t words = 2 * (size_t)n_pairs;
+  const bool same = s->packed_valid && s->shadow_valid && s->shadow.size() == words &&
+                    (words == 0 || memcmp(s->shadow.data(), pairs, sizeof(int32_t) * words) == 0);
+  if (same) return VO_OK;
+  s->shadow_valid = false;
+  s->shadow.assign(pairs, pairs + words);
+  if (int r = upload(c, s->pairs_own, s->shadow.data(), sizeof(int32_t) * words)) return r;
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  s->packed_valid = false;
+  s->shadow_valid = true;
+  return VO_OK;
 }
 
 int vo_picp_solve(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_outliers, int n_iters) {
   VO_REQUIRE(s, "null argument");
   VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || pairs), "bad pairs");
   VO_REQUIRE(n_iters >= 0, "negative n_iters");
-  vo_ctx* c = s->ctx;
-  if (int r = set_device(c)) return r;
-  const uint64_t h = sample_hash(pairs, n_pairs);
-  const bool same = s->packed_valid && !s->key_dev && s->key_ptr == pairs && s->key_n == n_pairs && s->key_hash == h;
-  if (!same) {
-    if (int r = upload(c, s->pairs_own, pairs, sizeof(int32_t) * 2 * (size_t)n_pairs)) return r;
-    VO_HIP_CHECK(hipStreamSynchronize(c->stream));
-    s->packed_valid = false;
-    s->key_ptr = pairs; s->key_n = n_pairs; s->key_hash = h; s->key_dev = false;
-  }
+  if (int r = set_device(s->ctx)) return r;
+  if (int r = picp_take_pairs(s, pairs, n_pairs)) return r;
   if (int r = picp_prepare(s, s->pairs_own.as<int32_t>(), n_pairs, nullptr, keep_outliers)) return r;
   return picp_enqueue(s, n_iters);
 }
 
 int vo_picp_one_round(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_outliers) {
   return vo_picp_solve(s, pairs, n_pairs, keep_outliers, 1);
+}
+
+int vo_picp_set_correspondences(vo_picp* s, const int32_t* pairs, int n_pairs) {
+  VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || pairs), "bad pairs");
+  if (int r = set_device(s->ctx)) return r;
+  s->packed_valid = false;          // explicit hand-over: always uploaded
+  s->shadow_valid = false;
+  if (int r = picp_take_pairs(s, pairs, n_pairs)) return r;
+  s->set_n = n_pairs;
+  return VO_OK;
+}
+
+int vo_picp_rounds(vo_picp* s, int keep_outliers, int n_iters) {
+  VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(n_iters >= 0, "negative n_iters");
+  if (s->set_n < 0 || !s->shadow_valid)
+    return fail(VO_ERR_NOT_READY, "vo_picp_rounds: vo_picp_set_correspondences has not been called");
+  if (int r = set_device(s->ctx)) return r;
+  if (int r = picp_prepare(s, s->pairs_own.as<int32_t>(), s->set_n, nullptr, keep_outliers)) return r;
+  return picp_enqueue(s, n_iters);
+}
+
+int vo_picp_set_exact(vo_picp* s, int on) {
+  VO_REQUIRE(s, "null argument");
+  s->exact = on ? 1 : 0;
+  return VO_OK;
 }
 
 static int picp_read_state(vo_picp* s, PicpState* h) {
@@ -692,7 +719,8 @@ int vo_picp_get_system(vo_picp* s, float H[36], float b[6]) {
 
 int vo_picp_batch_set_form(vo_ctx* c, int form) {
   VO_REQUIRE(c, "ctx is null");
-  VO_REQUIRE(form >= 0 && form <= 2, "form must be 0 (auto), 1 (one launch per round) or 2 (one workgroup per problem)");
+  VO_REQUIRE(form >= 0 && form <= 3,
+             "form must be 0 (auto), 1 (one launch per round), 2 (one workgroup per problem) or 3 (reference-order arithmetic)");
   c->batch_form = form;
   return VO_OK;
 }
@@ -722,10 +750,11 @@ int vo_picp_solve_batch_dev(vo_ctx* c, int n_problems, int rows, int cols, int z
   a.n_world = (int)world_stride; a.n_meas = (int)meas_stride;
   VO_HIP_CHECK(c->batch_pack.ensure(sizeof(float) * 5 * a.cap * (size_t)n_problems, c->stream));
   a.packed = c->batch_pack.as<float>();
-  a.states = nullptr; a.partials = nullptr; a.params = nullptr; a.grid = 0;
+  a.states = nullptr; a.partials = nullptr; a.params = nullptr; a.grid = 0; a.exact = 0;
   static const int env_form = [] { const char* e = getenv("VO_PICP_BATCH_FORM"); return e ? atoi(e) : 0; }();
   const int form = c->batch_form ? c->batch_form : env_form;
-  const bool rounds = form == 1 || (form != 2 && picp_batch_prefers_rounds(n_problems, a.cap, n_iters, c->n_cu));
+  a.exact = form == 3;
+  const bool rounds = form == 1 || (form == 0 && picp_batch_prefers_rounds(n_problems, a.cap, n_iters, c->n_cu));
   if (rounds && !c->capturing) {
     // a few problems: one launch per round with many workgroups per problem (the single-problem kernel with the
     // problem as a grid dimension) instead of one workgroup per problem

@@ -626,6 +626,159 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
   }
 }
 
+// ---- reference-order ("exact") solver ---------------------------------------------------
+// Bit-identical to the reference's scalar float32 arithmetic (picp_solver.cpp:55-112; checked against the
+// CPU restatement by tests/test_gpu_exact.py): the per-correspondence terms are computed in parallel with every
+// product unfused (picp_term_exact), staged through LDS, and lane k of the first wave adds entry
+// k of H / b / chi SEQUENTIALLY IN CORRESPONDENCE ORDER -- parallel across the 30 entries, serial
+// across the correspondences, which is the reference's summation order.  The tail is Eigen's
+// pivoted LDLT with true divisions (ldlt6_solve) and sin/cos in double rounded to float
+// (v2t_euler_exact).  One workgroup per problem, all rounds inside the launch.  Meant for
+// verification and for small frames (the reference's dataset has <= 127 points per frame, where
+// a round costs a few microseconds); at 50k correspondences a round is ~1 ms.
+constexpr int EX_BLOCK = 256;
+constexpr int EX_STRIDE = NTERM + 1;   // 29 floats per staged correspondence: odd stride, conflict-free stores
+
+struct ExactArgs {
+  const float* packed;       // 5 SoA arrays of `cap` floats per problem
+  size_t cap;
+  const int* n_pairs;        // per problem (device), or null: params->n_corr
+  const PicpParams* params;  // single problem: camera / threshold / damping / count in device memory
+  CamK cam; float thr, damping; int keep_outliers;   // batched: by value
+  int n_iters;
+  PicpState* state;          // single problem: pose in, everything out
+  const float* T0;           // batched: n_problems x 16 or null (identity)
+  float* T_out;              // batched: n_problems x 16
+  float* stats_out;          // batched: n_problems x 4 or null
+};
+
+template <bool SINGLE>
+__global__ __launch_bounds__(EX_BLOCK) void picp_exact_kernel(ExactArgs a) {
+  __shared__ float s_term[EX_BLOCK * EX_STRIDE];
+  __shared__ int s_flag[EX_BLOCK];
+  __shared__ float s_sum[NACC + 2];
+  __shared__ float s_pose[12];
+  const int tid = threadIdx.x;
+  const size_t p = blockIdx.x;
+  CamK cam; float thr, damping; int keep, n;
+  Pose T;
+  if (SINGLE) {
+    cam = a.params->cam; thr = a.params->thr; damping = a.params->damping; keep = a.params->keep_outliers;
+    n = a.params->n_corr;
+    T = load_pose12(a.state->pose[0]);
+  } else {
+    cam = a.cam; thr = a.thr; damping = a.damping; keep = a.keep_outliers;
+    n = a.n_pairs[p];
+    if (a.T0) {
+      T = pose_from_T16(a.T0 + 16 * p);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) T.R[k] = (k % 4 == 0) ? 1.f : 0.f;
+      T.t[0] = T.t[1] = T.t[2] = 0.f;
+    }
+  }
+  if (n < 0) n = 0;
+  if ((size_t)n > a.cap) n = (int)a.cap;
+  const float* X = a.packed + p * 5 * a.cap;
+  const float* Y = X + a.cap;
+  const float* Z = Y + a.cap;
+  const float* U = Z + a.cap;
+  const float* V = U + a.cap;
+  for (int it = 0; it < a.n_iters; ++it) {
+    float run = 0.f;                                   // lane k < NACC of wave 0: running sum of entry k (:57-61)
+    for (int base = 0; base < n; base += EX_BLOCK) {
+      const int i = base + tid;
+      int flag = 0;
+      if (i < n) {
+        float term[NTERM];
+        flag = picp_term_exact(cam, T, thr, X[i], Y[i], Z[i], U[i], V[i], term);
+        if (flag) {
+#pragma unroll
+          for (int k = 0; k < NTERM; ++k) s_term[tid * EX_STRIDE + k] = term[k];
+        }
+      }
+      s_flag[tid] = flag;
+      __syncthreads();
+      if (tid < NACC) {
+        const int m = (n - base) < EX_BLOCK ? (n - base) : EX_BLOCK;
+        for (int j = 0; j < m; ++j) {
+          const int f = s_flag[j];
+          if (f == 0) continue;                                            // :72-73
+          bool add;
+          float v;
+          if (tid < 27) { add = f == 1 || keep != 0; v = s_term[j * EX_STRIDE + tid]; }      // :90-94
+          else if (tid == 27) { add = f == 1; v = s_term[j * EX_STRIDE + 27]; }            // :86
+          else if (tid == 28) { add = f == 2; v = s_term[j * EX_STRIDE + 27]; }            // :82
+          else { add = f == 1; v = 1.f; }                                                  // :87 (exact below 2^24)
+          if (add) run += v;
+        }
+      }
+      __syncthreads();
+    }
+    if (tid < NACC) s_sum[tid] = run;
+    __syncthreads();
+    if (tid < 64) {                                    // one wave, every lane the same values: nothing diverges
+      float acc[NACC];
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) acc[k] = s_sum[k];
+      float H[36], b[6];
+      const Pose Tn = picp_update_t<true>(acc, damping, T, H, b);          // :102-110
+      if (tid == 0) {
+        store_pose12(s_pose, Tn);
+        if (it == a.n_iters - 1) {
+          float T16[16];
+          pose_to_T16(Tn, T16);
+          if (SINGLE) {
+            PicpState* S = a.state;
+            store_pose12(S->pose[0], Tn);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) S->T16[k] = T16[k];
+#pragma unroll
+            for (int k = 0; k < 36; ++k) S->H[k] = H[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) S->b[k] = b[k];
+            S->chi_in = acc[27]; S->chi_out = acc[28]; S->n_in = (int)acc[29];
+          } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a.T_out[16 * p + k] = T16[k];
+            if (a.stats_out) {
+              float* so = a.stats_out + 4 * p;
+              so[0] = acc[27]; so[1] = acc[28]; so[2] = acc[29]; so[3] = 0.f;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    T = load_pose12(s_pose);
+  }
+  if (!SINGLE && a.n_iters <= 0 && tid == 0) {          // no round: the starting pose is the result
+    float T16[16];
+    pose_to_T16(T, T16);
+    for (int k = 0; k < 16; ++k) a.T_out[16 * p + k] = T16[k];
+    if (a.stats_out) { float* so = a.stats_out + 4 * p; so[0] = so[1] = so[2] = so[3] = 0.f; }
+  }
+}
+
+hipError_t launch_picp_exact(hipStream_t st, const PicpParams* d_params, PicpState* d_state, PackedCorr pk,
+                             int n_iters) {
+  if (n_iters <= 0) return hipSuccess;
+  ExactArgs a{};
+  a.packed = pk.base; a.cap = pk.cap; a.n_pairs = nullptr; a.params = d_params; a.n_iters = n_iters;
+  a.state = d_state;
+  hipLaunchKernelGGL(picp_exact_kernel<true>, dim3(1), dim3(EX_BLOCK), 0, st, a);
+  return hipGetLastError();
+}
+
+static hipError_t launch_picp_exact_batch(hipStream_t st, const BatchArgs& b) {
+  ExactArgs a{};
+  a.packed = b.packed; a.cap = b.cap; a.n_pairs = b.n_pairs; a.params = nullptr;
+  a.cam = b.cam; a.thr = b.thr; a.damping = b.damping; a.keep_outliers = b.keep_outliers;
+  a.n_iters = b.n_iters; a.state = nullptr; a.T0 = b.T0; a.T_out = b.T_out; a.stats_out = b.stats_out;
+  hipLaunchKernelGGL(picp_exact_kernel<false>, dim3(b.n_problems), dim3(EX_BLOCK), 0, st, a);
+  return hipGetLastError();
+}
+
 // launch-per-round form for a few problems: n_iters + 1 launches, grid (workgroups per problem, problems)
 template <bool PINHOLE, bool KEEP>
 static void launch_rounds_batch_t(hipStream_t st, const BatchArgs& a) {
@@ -666,6 +819,7 @@ hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a) {
   if (gx > 64) gx = 64;
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(picp_batch_pack_kernel, dim3(gx, a.n_problems), dim3(256), 0, st, a);
+  if (a.exact) return launch_picp_exact_batch(st, a);
   const bool ph = is_pinhole(a.cam.K), keep = a.keep_outliers != 0;
   if (a.states) {
     if (ph && !keep) launch_rounds_batch_t<true, false>(st, a);

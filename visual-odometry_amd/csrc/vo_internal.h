@@ -63,6 +63,11 @@ hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpSt
 
 int picp_grid_for(int n_corr, int n_cu);
 
+// Reference-order solver (bit-identical to the reference's scalar arithmetic): n_iters rounds in one launch of one
+// workgroup; reads the packed correspondences and P->n_corr, leaves pose / T16 / H / b / statistics in *d_state.
+hipError_t launch_picp_exact(hipStream_t st, const PicpParams* d_params, PicpState* d_state, PackedCorr pk,
+                             int n_iters);
+
 struct BatchArgs {
   CamK cam;
   float thr, damping;
@@ -84,6 +89,7 @@ struct BatchArgs {
   float* partials;     // n_problems x 2 x round_up(grid,256) x PICP_PSTRIDE floats, zero-padded rows
   const PicpParams* params;   // device copy of (cam, thr, damping, keep_outliers); n_corr unused
   int grid;            // workgroups per problem
+  int exact;           // reference-order form (picp_exact_kernel): one workgroup per problem, sequential sums
 };
 hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a);
 // when is the launch-per-round form the faster one?  (measured: DESIGN.md section 4.1)

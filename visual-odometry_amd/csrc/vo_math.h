@@ -246,6 +246,62 @@ VO_HD void picp_accumulate_t(const CamK& cam, const Pose& T, float thr, float wx
   }
 }
 
+// ---- reference-order ("exact") form of the same term --------------------------
+// What linearize adds for ONE correspondence, rounded exactly like the reference's
+// scalar loop (picp_solver.cpp:62-95): J from the general 3x3 formulas (:39-51), every
+// product unfused, H_rc term = (J0r*J0c + J1r*J1c)*lambda, b_r term = (J0r*e0 + J1r*e1)*lambda.
+// term[0..20] upper triangle of J^T J * lambda row by row (the product is symmetric bit for
+// bit: float multiplication commutes), term[21..26] J^T e * lambda, term[27] chi.
+// Returns 0 = skipped before any statistic (:72-73), 1 = inlier, 2 = outlier (:78).
+// The caller adds term k to its running sum IN CORRESPONDENCE ORDER: that sequential sum is
+// what makes the result bit-identical to the reference arithmetic (picp_exact_kernel).
+constexpr int NTERM = 28;
+VO_HD int picp_term_exact(const CamK& cam, const Pose& T, float thr, float wx, float wy, float wz, float zu,
+                          float zv, float term[NTERM]) {
+  float pc[3], ph[3];
+  pose_apply(T, wx, wy, wz, pc[0], pc[1], pc[2]);                       // camera.h:27
+  if (!(wx == wx)) return 0;                                            // dropped correspondence (pack marker)
+  if (pc[2] > (float)cam.z_far || pc[2] < (float)cam.z_near) return 0;  // camera.h:28
+  mat3_vec(cam.K, 3, pc, ph);                                           // camera.h:30
+  const float iz = 1.0f / ph[2];                                        // camera.h:31, picp_solver.cpp:44
+  const float u = ph[0] * iz, v = ph[1] * iz;
+  if (u < 0.f || u > (float)(cam.cols - 1)) return 0;                   // camera.h:32
+  if (v < 0.f || v > (float)(cam.rows - 1)) return 0;                   // camera.h:34
+  const float e0 = u - zu, e1 = v - zv;                                 // :35
+  const float chi = e0 * e0 + e1 * e1;                                  // :75
+  const float iz2 = iz * iz;                                            // :45
+  const float g0 = -ph[0] * iz2, g1 = -ph[1] * iz2;                     // :47-49
+  float A0[3], A1[3];                                                   // Jp*K, :51 (Jp's structural zeros dropped)
+  for (int c = 0; c < 3; ++c) {
+    A0[c] = iz * cam.K[3 * c] + g0 * cam.K[2 + 3 * c];
+    A1[c] = iz * cam.K[1 + 3 * c] + g1 * cam.K[2 + 3 * c];
+  }
+  const float v0 = -pc[0], v1 = -pc[1], v2 = -pc[2];                    // skew(-pc), utils.h:96-102
+  float J0[6], J1[6];
+  J0[0] = A0[0]; J0[1] = A0[1]; J0[2] = A0[2];
+  J1[0] = A1[0]; J1[1] = A1[1]; J1[2] = A1[2];
+  J0[3] = A0[1] * v2 + A0[2] * (-v1);
+  J1[3] = A1[1] * v2 + A1[2] * (-v1);
+  J0[4] = A0[0] * (-v2) + A0[2] * v0;
+  J1[4] = A1[0] * (-v2) + A1[2] * v0;
+  J0[5] = A0[0] * v1 + A0[1] * (-v0);
+  J1[5] = A1[0] * v1 + A1[1] * (-v0);
+  const bool outl = chi > thr;                                          // :78 (strict)
+  const float lambda = outl ? sqrtf(thr / chi) : 1.f;                   // :80 (double sqrt rounded = float sqrt)
+  int k = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) {
+      const float jtj = J0[r] * J0[c] + J1[r] * J1[c];
+      term[k++] = jtj * lambda;                                         // :92
+    }
+  for (int r = 0; r < 6; ++r) {
+    const float jte = J0[r] * e0 + J1[r] * e1;
+    term[21 + r] = jte * lambda;                                        // :93
+  }
+  term[27] = chi;
+  return outl ? 2 : 1;
+}
+
 VO_HD void picp_accumulate(const CamK& cam, const Pose& T, float thr, bool keep_outliers, float wx,
                            float wy, float wz, float zu, float zv, float acc[NACC]) {
   if (keep_outliers) picp_accumulate_t<false, true>(cam, T, thr, wx, wy, wz, zu, zv, acc);
@@ -475,7 +531,15 @@ VO_HD void ldlt2_solve(float m00, float m10, float m11, float r0, float r1, floa
 }
 
 // v2tEuler (utils.h:64-78): t = v[0:3], R = Rx(v3) Ry(v4) Rz(v5).  The
-// reference's sin/cos resolve to the double libm functions rounded to float.
+// reference's sin/cos resolve to the double libm functions rounded to float:
+// v2t_euler_exact does the same on host and device.
+VO_HD Pose v2t_euler_exact(const float v[6]) {
+  const float sx = (float)sin((double)v[3]), cx = (float)cos((double)v[3]);
+  const float sy = (float)sin((double)v[4]), cy = (float)cos((double)v[4]);
+  const float sz = (float)sin((double)v[5]), cz = (float)cos((double)v[5]);
+  return v2t_from_sincos(v, sx, cx, sy, cy, sz, cz);
+}
+
 VO_HD Pose v2t_euler(const float v[6]) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // device: float sincos (ocml); differs from the double-then-round value by
@@ -484,20 +548,18 @@ VO_HD Pose v2t_euler(const float v[6]) {
   sincosf(v[3], &sx, &cx);
   sincosf(v[4], &sy, &cy);
   sincosf(v[5], &sz, &cz);
-#else
-  const float sx = (float)sin((double)v[3]), cx = (float)cos((double)v[3]);
-  const float sy = (float)sin((double)v[4]), cy = (float)cos((double)v[4]);
-  const float sz = (float)sin((double)v[5]), cz = (float)cos((double)v[5]);
-#endif
   return v2t_from_sincos(v, sx, cx, sy, cy, sz, cz);
+#else
+  return v2t_euler_exact(v);
+#endif
 }
 
 // Tail of PICPSolver::oneRound (picp_solver.cpp:102-110): from the reduced
 // accumulators build H (+damping), solve H dx = -b, T <- v2tEuler(dx) * T.
 // H_out (36, col-major, damping included) and b_out are what the reference
 // leaves in _H/_b.
-VO_HD Pose picp_update(const float acc[NACC], float damping, const Pose& T, float* H_out,
-                       float* b_out) {
+template <bool EXACT>
+VO_HD Pose picp_update_t(const float acc[NACC], float damping, const Pose& T, float* H_out, float* b_out) {
   float a[6][6];
   int k = 0;
 #pragma unroll
@@ -516,8 +578,12 @@ VO_HD Pose picp_update(const float acc[NACC], float damping, const Pose& T, floa
 #pragma unroll
   for (int i = 0; i < 6; ++i) { nb[i] = -acc[21 + i]; if (b_out) b_out[i] = acc[21 + i]; }
   ldlt6_solve(a, nb, dx);
-  const Pose dT = v2t_euler(dx);
+  const Pose dT = EXACT ? v2t_euler_exact(dx) : v2t_euler(dx);
   return pose_mul(dT, T);
+}
+
+VO_HD Pose picp_update(const float acc[NACC], float damping, const Pose& T, float* H_out, float* b_out) {
+  return picp_update_t<false>(acc, damping, T, H_out, b_out);
 }
 
 // ---- triangulate_point (utils.cpp:36-49) -----------------------------------
