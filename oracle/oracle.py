@@ -41,6 +41,12 @@ def lib():
     return _LIB
 
 
+def native_lib():
+    """the same sources compiled -march=native ON THIS HOST (bench.py's second, separately labelled CPU baseline)"""
+    subprocess.check_call(["make", "-C", _HERE, "-s", "native"])
+    return C.CDLL(os.path.join(_HERE, "libvo_oracle_native.so"))
+
+
 @dataclass
 class Camera:
     """Mirror of the reference Camera's state (camera.h:55-61)."""
@@ -69,7 +75,7 @@ def _picp_struct(real, cam_t):
 
 
 class Oracle:
-    def __init__(self, bits: int = 32):
+    def __init__(self, bits: int = 32, library=None):
         assert bits in (32, 64)
         self.bits = bits
         self.dt = np.float32 if bits == 32 else np.float64
@@ -77,7 +83,7 @@ class Oracle:
         self.pfx = "vo32_" if bits == 32 else "vo64_"
         self.cam_t = _cam_struct(self.real)
         self.picp_t = _picp_struct(self.real, self.cam_t)
-        self.L = lib()
+        self.L = library if library is not None else lib()
 
     # -- helpers ---------------------------------------------------------
     def _f(self, name):

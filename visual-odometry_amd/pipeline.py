@@ -157,27 +157,46 @@ class _FrameBatch(C.Structure):
 
 
 class BatchPipeline:
-    """n_frames independent frame pairs per call (vo_frames_batch_dev): every stage is one batched launch,
-    the solver is the batched kernel.  All frames must have the same set sizes."""
+    """n_frames independent frame pairs (vo_frames_batch_dev): every stage is one batched launch per call, the solver
+    is the batched kernel.  All frames must have the same set sizes.  `fps` is a list of frame-pair dicts, or -- for
+    many frames -- a callable gen(lo, hi) -> list of the dicts of frames lo..hi-1, asked for `upload_block` frames at a
+    time so that the host never holds the whole set; `frames_per_call` splits run() into several calls."""
 
-    def __init__(self, ctx: Context, fps: list, n_iters: int = 50, kernel_threshold: float = 10000.0,
-                 with_appearance: bool = True, poses_ptr: int | None = None):
+    _IN = (("ref_app", np.float32, 10), ("cur_app", np.float32, 10), ("ref_pts", np.float32, 2), ("cur_pts", np.float32, 2),
+           ("model", np.float32, 3), ("model_pairs", np.int32, 2))
+
+    def __init__(self, ctx: Context, fps, n_iters: int = 50, kernel_threshold: float = 10000.0,
+                 with_appearance: bool = True, poses_ptr: int | None = None, n_frames: int | None = None,
+                 upload_block: int = 100, frames_per_call: int | None = None):
         """poses_ptr: optional device buffer (n_frames*16 floats, e.g. a torch tensor's data_ptr) that
         receives the poses directly, so that a collective can read them without a copy."""
         self.ctx, self.lib = ctx, ctx.lib
-        F = self.F = len(fps)
-        f0 = fps[0]
+        gen = fps if callable(fps) else (lambda lo, hi: fps[lo:hi])
+        F = self.F = int(n_frames if n_frames is not None else len(fps))
+        first = gen(0, min(upload_block, F))
+        f0 = first[0]
         self.n_ref, self.n_cur = len(f0["ref_app"]), len(f0["cur_app"])
         self.n_model, self.n_mp = len(f0["model"]), len(f0["model_pairs"])
-        for f in fps:
-            assert (len(f["ref_app"]), len(f["cur_app"]), len(f["model"]), len(f["model_pairs"])) == \
-                (self.n_ref, self.n_cur, self.n_model, self.n_mp), "frames of a batch must have identical sizes"
+        per = {"ref_app": self.n_ref, "cur_app": self.n_cur, "ref_pts": self.n_ref, "cur_pts": self.n_cur,
+               "model": self.n_model, "model_pairs": self.n_mp}
         self.q = min(self.n_ref, self.n_cur)
-        stack = lambda k, dt: np.ascontiguousarray(np.stack([np.asarray(f[k], dt) for f in fps]))
-        up = ctx.to_device
-        self._in = [up(stack("ref_app", np.float32)), up(stack("cur_app", np.float32)), up(stack("ref_pts", np.float32)),
-                    up(stack("cur_pts", np.float32)), up(stack("model", np.float32)), up(stack("model_pairs", np.int32))]
         a = ctx.alloc
+        self._in = [a(max(F * per[k] * w * 4, 16)) for k, _, w in self._IN]
+        self.X_gt = np.zeros((F, 4, 4), np.float32)      # ground truth of the generator, when the dicts carry it
+        lo = 0
+        while lo < F:
+            blk = first if lo == 0 else gen(lo, min(lo + upload_block, F))
+            for f in blk:
+                assert (len(f["ref_app"]), len(f["cur_app"]), len(f["model"]), len(f["model_pairs"])) == \
+                    (self.n_ref, self.n_cur, self.n_model, self.n_mp), "frames of a batch must have identical sizes"
+            for d, (k, dt, w) in zip(self._in, self._IN):
+                arr = np.ascontiguousarray(np.stack([np.asarray(f[k], dt).reshape(per[k], w) for f in blk]))
+                ctx.h2d(d + lo * per[k] * w * 4, arr)
+            for i, f in enumerate(blk):
+                if "X_gt" in f:
+                    self.X_gt[lo + i] = f["X_gt"]
+            lo += len(blk)
+            del blk
         q = self.q
         self.d_matches, self.d_joined = a(F * q * 8), a(F * q * 8)
         self._own_poses = poses_ptr is None
@@ -185,22 +204,36 @@ class BatchPipeline:
         self.d_tri_xyz, self.d_tri_pairs = a(F * q * 12), a(F * q * 8)
         self.d_tri_app = a(F * q * 40) if with_appearance else 0
         self.d_counts = a(3 * F * 4)
-        b = self.b = _FrameBatch()
-        b.n_frames, b.n_ref, b.n_cur, b.n_model, b.n_model_pairs = F, self.n_ref, self.n_cur, self.n_model, self.n_mp
-        (b.ref_app, b.cur_app, b.ref_pts, b.cur_pts, b.model, b.model_pairs) = self._in
-        b.X_prev = None
-        b.rows, b.cols, b.z_near, b.z_far = int(f0["rows"]), int(f0["cols"]), int(f0["z_near"]), int(f0["z_far"])
-        b.K[:] = _colmajor(f0["K"], 3).tolist()
-        b.kernel_threshold, b.keep_outliers, b.n_iters, b.radius = kernel_threshold, 0, n_iters, 0.1
-        b.matches, b.joined, b.model_moved, b.poses, b.stats = self.d_matches, self.d_joined, self.d_moved, self.d_poses, self.d_stats
-        b.tri_xyz, b.tri_pairs, b.tri_app, b.counts = self.d_tri_xyz, self.d_tri_pairs, self.d_tri_app or None, self.d_counts
+        per_call = F if not frames_per_call else max(1, min(int(frames_per_call), F))
+        self.calls = []
+        for lo in range(0, F, per_call):
+            hi = min(lo + per_call, F)
+            b = _FrameBatch()
+            b.n_frames, b.n_ref, b.n_cur, b.n_model, b.n_model_pairs = hi - lo, self.n_ref, self.n_cur, self.n_model, self.n_mp
+            (b.ref_app, b.cur_app, b.ref_pts, b.cur_pts, b.model, b.model_pairs) = \
+                [d + lo * per[k] * w * 4 for d, (k, _, w) in zip(self._in, self._IN)]
+            b.X_prev = None
+            b.rows, b.cols, b.z_near, b.z_far = int(f0["rows"]), int(f0["cols"]), int(f0["z_near"]), int(f0["z_far"])
+            b.K[:] = _colmajor(f0["K"], 3).tolist()
+            b.kernel_threshold, b.keep_outliers, b.n_iters, b.radius = kernel_threshold, 0, n_iters, 0.1
+            b.matches, b.joined = self.d_matches + lo * q * 8, self.d_joined + lo * q * 8
+            b.model_moved, b.poses, b.stats = self.d_moved + lo * self.n_model * 12, self.d_poses + lo * 64, self.d_stats + lo * 16
+            b.tri_xyz, b.tri_pairs = self.d_tri_xyz + lo * q * 12, self.d_tri_pairs + lo * q * 8
+            b.tri_app = (self.d_tri_app + lo * q * 40) if self.d_tri_app else None
+            b.counts = self.d_counts + 3 * lo * 4        # this call's [3][hi - lo] block
+            self.calls.append((lo, hi, b))
+        self.b = self.calls[0][2]
 
     def run(self):
-        _chk(self.lib.vo_frames_batch_dev(self.ctx.h, C.byref(self.b)))
+        for _, _, b in self.calls:
+            _chk(self.lib.vo_frames_batch_dev(self.ctx.h, C.byref(b)))
 
     def counts(self):
+        raw = np.zeros(3 * self.F, np.int32)
+        self.ctx.d2h(raw, self.d_counts)
         c = np.zeros((3, self.F), np.int32)
-        self.ctx.d2h(c, self.d_counts)
+        for lo, hi, _ in self.calls:
+            c[:, lo:hi] = raw[3 * lo:3 * hi].reshape(3, hi - lo)
         return c
 
     def poses(self):
