@@ -592,23 +592,44 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
 // ---- cell-hash variant ---------------------------------------------------------------
 // Exact search over a 4-D grid.  Four appearance components (largest spreads, taken from components 4..9
 // when those are not much flatter, so the filter on components 0..3 keeps its selectivity) are cut into
-// nc_k = clamp(floor(spread_k / R), 1, 20) cells of width >= R each (R = 1.001 radius); both sets are
-// counting-sorted by the cell key ((c0*nc1 + c1)*nc2 + c2)*nc3 + c3 (<= 160 000 cells) in two levels, both on
-// LDS histograms (a global atomic per point -- 64 scattered memory-side requests per wave -- was 2x dearer):
-// level 1 as the bucket sort above with the <= 400 coarse bins (c0, c1); level 2 one workgroup per coarse bin,
-// ordering its points by the <= 400 fine bins (c2, c3) and writing that bin's slice of the start table.  A query visits,
-// per component, the cells [cell(q_k - R), cell(q_k + R)] (<= 3, same monotone cell function as the sort):
-// <= 27 runs of tree points that are contiguous along the last component.  A tree point outside that box
-// differs from the query by more than the radius in one component, so that single non-negative term of the
-// monotonically accumulated sum already reaches radius^2 and the strict test can never pass: the box changes
-// no decision.  Inside it the scan is the same conservative filter + exact re-evaluation as above, one
-// query per lane (its own runs: nothing is shared through LDS), ties resolved on the original index.
-// On U(-1,1)^10 appearances a query meets ~25 candidates instead of ~1400 in the 2-D rectangle.
+// nc_k = clamp(floor(spread_k / R), 1, 20) cells of width >= R each (R = 1.001 radius).  The spreads come
+// from a strided SAMPLE of both sets (<= CELL_SAMPLE points each): any bounds give a correct grid, because
+// the cell function is monotone and clamps -- points beyond the sampled range fall into the edge cells.
+// The tree is counting-sorted by the cell key ((c0*nc1 + c1)*nc2 + c2)*nc3 + c3 (<= 160 000 cells) in two
+// levels, both on LDS histograms (a global atomic per point -- 64 scattered memory-side requests per wave --
+// was 2x dearer): level 1 like the bucket sort above with the <= 400 coarse bins (c0, c1); level 2 one
+// workgroup per coarse bin, ordering its points by the <= 400 fine bins (c2, c3) and writing that bin's slice
+// of the start table.  The queries are only grouped by coarse bin (level 1 writes their indices).
+//
+// Search: one workgroup per coarse bin (c0, c1).  Every query of the bin can only meet tree points of the
+// 3 x 3 coarse bins around it, i.e. nine CONTIGUOUS segments of the sorted tree (~125 points each on 50k
+// uniform points) and nine rows of the start table: the workgroup stages both in LDS with coalesced loads
+// and every lane then walks its own <= 27 runs (3 x 3 x 3 cells in c0, c1, c2; contiguous along c3) out of LDS.
+// (Per-lane gathers from global memory -- 54 table reads and ~25 16-byte candidate reads per query, each
+// its own cache line -- made the first version L1-request-bound: 1.41 ms per 200 x 50k frames.)  A query
+// visits, per component, the cells [cell(q - R), cell(q - R) + 2] clipped to cell(q + R): any tree value t
+// with |t - q| < radius has cell(q - R) <= cell(t) (monotone) and (t - (q - R)) * scale < (r + R) * scale
+// <= 1.9991 (1 + eps) < 2, so cell(t) <= cell(q - R) + 2.  A tree point outside that box differs from the
+// query by at least the radius in one component, so that single non-negative term of the monotonically
+// accumulated sum already reaches radius^2 and the strict test can never pass: the box changes no decision.
+// Inside it the scan is the same conservative filter + exact re-evaluation as above, ties resolved on the
+// original index.  On U(-1,1)^10 appearances a query meets ~25 candidates instead of ~1400 in the 2-D
+// rectangle.  Segments too long for the LDS budget (clustered data) or a box reaching beyond the staged
+// bins (cells narrower than R by a rounding) fall back to the same walk on global memory.
 constexpr int HK = 4;                    // hashed components
 constexpr int HNC = 20;                  // cells per component, at most
 constexpr int HCOARSE = HNC * HNC;       // coarse bins (c0, c1) / fine bins (c2, c3), at most
 constexpr int HCPAD = 512;               // HCOARSE rounded up to a power of two (scan width)
 constexpr int HBINS = HNC * HNC * HNC * HNC + 1;   // every key + the end sentinel
+constexpr int HROW = 408;                // u16 entries per row of the relative start table (>= HCOARSE + 1, 16-byte rows)
+constexpr int CELL_SAMPLE = 2048;        // points per set that define the grid's bounds
+#ifndef VO_CS_NB
+#define VO_CS_NB 3
+#endif
+constexpr int CS_NB = VO_CS_NB;          // coarse bins per search workgroup (a strip along c1)
+constexpr int CS_THREADS = CS_NB == 1 ? 192 : (CS_NB == 2 ? 320 : 448);   // a coarse bin holds ~140 queries at 50k points
+constexpr int CS_SURV = 8;               // filter survivors a lane parks before it evaluates them
+constexpr int CS_CAP = 576 * (CS_NB + 2);   // tree points a search workgroup can stage (20 B each; ~140 per bin at 50k)
 
 struct CellParams {
   int dim[HK];
@@ -617,11 +638,11 @@ struct CellParams {
   float R;
 };
 
-__device__ CellParams make_cell_params(const unsigned* __restrict__ mm, float radius) {
+__device__ CellParams make_cell_params(const float* lo_in, const float* hi_in, float radius) {
   float span[10], lo[10];
   for (int k = 0; k < 10; ++k) {
-    lo[k] = ord2f(mm[k]);
-    const float sp = ord2f(~mm[10 + k]) - lo[k];
+    lo[k] = lo_in[k];
+    const float sp = hi_in[k] - lo[k];
     span[k] = (sp < INFINITY) ? sp : -1.f;               // empty / infinite / NaN ranges rank last
   }
   auto top4 = [&](int k0, int* out) {                    // indices of the four largest spans in [k0, 10), descending
@@ -665,40 +686,53 @@ __device__ __forceinline__ float pick10(const float* v, int k) {
 
 // per-frame workspace of the cell variant (bytes, every block 256-aligned)
 struct CellWs {
-  size_t tree_rec, tree_idx, qry_rec, t1_pre, t1_meta, q1_rec, block_hist, coarse_start, start_t, cp, total;
+  size_t tree_rec, tree_idx, t1_pre, t1_meta, q1_idx, block_hist, coarse_start, start_t, start_rel, cp, total;
 };
 static CellWs cell_ws_layout(int nt, int nq) {
   CellWs w;
   size_t o = 0;
   w.tree_rec = o; o += align256(sizeof(float) * 4 * (size_t)nt);      // filter prefix (components 0..3) in cell order
   w.tree_idx = o; o += align256(sizeof(int) * (size_t)nt);            // original index of the sorted tree point
-  w.qry_rec = o; o += align256(sizeof(float) * 12 * (size_t)nq);      // queries in cell order: 10 components, index, key
   w.t1_pre = o; o += align256(sizeof(float) * 4 * (size_t)nt);        // level 1 (coarse order): tree prefix,
   w.t1_meta = o; o += align256(sizeof(int) * 2 * (size_t)nt);         //   (original index, fine bin)
-  w.q1_rec = o; o += align256(sizeof(float) * 12 * (size_t)nq);       //   query records (slot 11 = fine bin)
+  w.q1_idx = o; o += align256(sizeof(int) * (size_t)nq);              //   query indices grouped by coarse bin
   w.block_hist = o; o += align256(sizeof(int) * (size_t)SORT_BLOCKS * 2 * HCPAD);
   w.coarse_start = o; o += align256(sizeof(int) * 2 * (HCPAD + 1));
   w.start_t = o; o += align256(sizeof(int) * (size_t)HBINS);          // first tree slot of every cell (+ end sentinel)
+  w.start_rel = o; o += align256(sizeof(unsigned short) * (size_t)HCOARSE * HROW);   // the same per coarse bin, relative to
+                                                                      //   the bin's first slot (16-bit, rows of HROW)
   w.cp = o; o += align256(sizeof(CellParams));
   w.total = o;
   return w;
 }
 size_t match_cells_workspace_bytes(int nt, int nq, int n_frames) {
-  return align256(128 * (size_t)n_frames) + (size_t)n_frames * cell_ws_layout(nt, nq).total;
+  return (size_t)n_frames * cell_ws_layout(nt, nq).total;
 }
 
 struct CellArgs {
   const float* tree; const float* qry; int nt, nq;
-  const unsigned* mm;
   char* ws;                 // frame 0's block; frame f = ws + f * ws_stride
   CellWs w;
-  size_t ws_stride, tree_stride, qry_stride, best_stride, mm_stride;
+  size_t ws_stride, tree_stride, qry_stride, best_stride;
+  int n_frames;
   float radius, r2;
   unsigned long long* best;
   int* rs_offsets;          // radius search: [nq + 1] counts, then (after the scan) offsets
   int32_t* rs_indices;      // radius search: tree indices, room for rs_capacity
   int rs_capacity;
 };
+
+// XCD-aware decomposition of a 1-D grid of 8 * ceil(n_frames / 8) * per_frame workgroups.  Workgroups are dealt
+// round-robin over the 8 XCDs (observed; speed only, nothing depends on it), so giving every frame the workgroups of
+// ONE residue class of blockIdx.x mod 8 keeps a frame's working set (4 MB of input, <= 3.6 MB of sorted records) in one
+// XCD's L2: partial lines written by the frame's workgroups merge there, segments staged by neighbouring bins hit there.
+__device__ __forceinline__ bool xcd_frame_block(int per_frame, int n_frames, int& frame, int& blk) {
+  const unsigned L = blockIdx.x, s = L >> 3;
+  frame = (int)(s / (unsigned)per_frame) * 8 + (int)(L & 7u);
+  blk = (int)(s % (unsigned)per_frame);
+  return frame < n_frames;
+}
+static unsigned xcd_grid(int per_frame, int n_frames) { return 8u * (unsigned)((n_frames + 7) / 8) * (unsigned)per_frame; }
 
 __device__ __forceinline__ void load10(const float* p, float* v) {
   const float2* src = reinterpret_cast<const float2*>(p);
@@ -713,22 +747,66 @@ __device__ __forceinline__ void cell_bins(const float* v, const CellParams& cp, 
   fine = c[2] * cp.nc[3] + c[3];
 }
 
-// level 1, histogram: SORT_BLOCKS workgroups, each a contiguous slice of [0,nt) tree + [nt,nt+nq) queries
+// grid bounds: one workgroup per frame, min/max per component over a strided sample of both sets -> CellParams
+__global__ __launch_bounds__(1024) void cell_bounds_kernel(CellArgs a) {
+  const int f = blockIdx.x;
+  const float* tree = a.tree + f * a.tree_stride; const float* qry = a.qry + f * a.qry_stride;
+  __shared__ float s_lo[16][10], s_hi[16][10];
+  float lo[10], hi[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+  const int st_t = (a.nt + CELL_SAMPLE - 1) / CELL_SAMPLE, st_q = (a.nq + CELL_SAMPLE - 1) / CELL_SAMPLE;
+  const int ns_t = st_t ? (a.nt + st_t - 1) / st_t : 0, ns_q = st_q ? (a.nq + st_q - 1) / st_q : 0;
+  for (int i = threadIdx.x; i < ns_t + ns_q; i += 1024) {
+    const float* row = i < ns_t ? tree + 10 * (size_t)i * st_t : qry + 10 * (size_t)(i - ns_t) * st_q;
+    const float2* p = reinterpret_cast<const float2*>(row);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float2 v = p[k];
+      lo[2 * k] = fminf(lo[2 * k], v.x); hi[2 * k] = fmaxf(hi[2 * k], v.x);          // fmin/fmax drop NaNs
+      lo[2 * k + 1] = fminf(lo[2 * k + 1], v.y); hi[2 * k + 1] = fmaxf(hi[2 * k + 1], v.y);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k)
+    for (int d = 32; d >= 1; d >>= 1) {
+      lo[k] = fminf(lo[k], __shfl_xor(lo[k], d));
+      hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], d));
+    }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l[10], h[10];
+    for (int k = 0; k < 10; ++k) {
+      l[k] = INFINITY; h[k] = -INFINITY;
+      for (int w = 0; w < 16; ++w) { l[k] = fminf(l[k], s_lo[w][k]); h[k] = fmaxf(h[k], s_hi[w][k]); }
+    }
+    *reinterpret_cast<CellParams*>(a.ws + f * a.ws_stride + a.w.cp) = make_cell_params(l, h, a.radius);
+  }
+}
+
+// level 1, histogram: SORT_BLOCKS workgroups per frame, each a contiguous slice of [0,nt) tree + [nt,nt+nq) queries
+__device__ __forceinline__ void cell_slice(int blk, int nt, int nq, int& lo, int& hi) {
+  const int total = nt + nq;
+  const int per = (total + SORT_BLOCKS - 1) / SORT_BLOCKS;
+  lo = blk * per;
+  hi = lo + per < total ? lo + per : total;
+}
+
 __global__ __launch_bounds__(256) void cell_coarse_hist_kernel(CellArgs a) {
-  const int f = blockIdx.z;
+  int f, blk;
+  if (!xcd_frame_block(SORT_BLOCKS, a.n_frames, f, blk)) return;
   const float* tree = a.tree + f * a.tree_stride; const float* qry = a.qry + f * a.qry_stride;
   char* ws = a.ws + f * a.ws_stride;
   __shared__ int s_h[2 * HCPAD];
-  __shared__ CellParams s_cp;
   for (int k = threadIdx.x; k < 2 * HCPAD; k += 256) s_h[k] = 0;
-  if (threadIdx.x == 0) {                        // every workgroup derives the same parameters from the min/max words
-    s_cp = make_cell_params(frame_ptr(a.mm, f * a.mm_stride), a.radius);
-    if (blockIdx.x == 0) *reinterpret_cast<CellParams*>(ws + a.w.cp) = s_cp;
-  }
+  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
   __syncthreads();
-  const CellParams cp = s_cp;
   int lo, hi;
-  sort_slice(a.nt, a.nq, lo, hi);
+  cell_slice(blk, a.nt, a.nq, lo, hi);
   for (int i = lo + threadIdx.x; i < hi; i += 256) {
     const bool is_t = i < a.nt;
     float v[10];
@@ -739,7 +817,7 @@ __global__ __launch_bounds__(256) void cell_coarse_hist_kernel(CellArgs a) {
   }
   __syncthreads();
   int* block_hist = reinterpret_cast<int*>(ws + a.w.block_hist);
-  for (int k = threadIdx.x; k < 2 * HCPAD; k += 256) block_hist[(size_t)blockIdx.x * 2 * HCPAD + k] = s_h[k];
+  for (int k = threadIdx.x; k < 2 * HCPAD; k += 256) block_hist[(size_t)blk * 2 * HCPAD + k] = s_h[k];
 }
 
 // level 1, offsets: grid 2 (tree half, query half) x HCPAD threads (one coarse bin each): exclusive scan over the
@@ -772,21 +850,22 @@ __global__ __launch_bounds__(HCPAD) void cell_coarse_offsets_kernel(CellArgs a) 
   }
 }
 
-// level 1, placement: coarse order.  Tree: filter prefix + (original index, fine bin); queries: whole record
+// level 1, placement in coarse order.  Tree: filter prefix + (original index, fine bin); queries: the index alone
 __global__ __launch_bounds__(256) void cell_coarse_place_kernel(CellArgs a) {
-  const int f = blockIdx.z;
+  int f, blk;
+  if (!xcd_frame_block(SORT_BLOCKS, a.n_frames, f, blk)) return;
   const float* tree = a.tree + f * a.tree_stride; const float* qry = a.qry + f * a.qry_stride;
   char* ws = a.ws + f * a.ws_stride;
   const int* block_off = reinterpret_cast<const int*>(ws + a.w.block_hist);
   float4* t1_pre = reinterpret_cast<float4*>(ws + a.w.t1_pre);
   int2* t1_meta = reinterpret_cast<int2*>(ws + a.w.t1_meta);
-  float* q1_rec = reinterpret_cast<float*>(ws + a.w.q1_rec);
+  int* q1_idx = reinterpret_cast<int*>(ws + a.w.q1_idx);
   __shared__ int s_off[2 * HCPAD];
-  for (int k = threadIdx.x; k < 2 * HCPAD; k += 256) s_off[k] = block_off[(size_t)blockIdx.x * 2 * HCPAD + k];
+  for (int k = threadIdx.x; k < 2 * HCPAD; k += 256) s_off[k] = block_off[(size_t)blk * 2 * HCPAD + k];
   __syncthreads();
   const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
   int lo, hi;
-  sort_slice(a.nt, a.nq, lo, hi);
+  cell_slice(blk, a.nt, a.nq, lo, hi);
   for (int i = lo + threadIdx.x; i < hi; i += 256) {
     const bool is_t = i < a.nt;
     const int idx = is_t ? i : i - a.nt;
@@ -799,23 +878,21 @@ __global__ __launch_bounds__(256) void cell_coarse_place_kernel(CellArgs a) {
       t1_pre[pos] = make_float4(v[0], v[1], v[2], v[3]);
       t1_meta[pos] = make_int2(idx, fine);
     } else {
-      float4* dst = reinterpret_cast<float4*>(q1_rec + 12 * (size_t)pos);
-      dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-      dst[1] = make_float4(v[4], v[5], v[6], v[7]);
-      dst[2] = make_float4(v[8], v[9], __int_as_float(idx), __int_as_float(fine));
+      q1_idx[pos] = idx;
     }
   }
 }
 
-// level 2: one workgroup per (coarse bin, set): counting sort of the bin's points by fine bin in LDS; the tree
-// side also writes the bin's slice of the start table (absolute slots) -- the last coarse bin adds the sentinel
+// level 2 (tree): one workgroup per coarse bin: counting sort of the bin's points by fine bin in LDS, and the bin's
+// slice of the start table (absolute slots) -- the last coarse bin adds the sentinel
 __global__ __launch_bounds__(256) void cell_fine_kernel(CellArgs a) {
-  const int f = blockIdx.z, set = blockIdx.y, coarse = blockIdx.x;
+  int f, coarse;
+  if (!xcd_frame_block(HCOARSE, a.n_frames, f, coarse)) return;
   char* ws = a.ws + f * a.ws_stride;
   const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
   const int n_coarse = cp.nc[0] * cp.nc[1], n_fine = cp.nc[2] * cp.nc[3];
   if (coarse >= n_coarse) return;
-  const int* cstart = reinterpret_cast<const int*>(ws + a.w.coarse_start) + set * (HCPAD + 1);
+  const int* cstart = reinterpret_cast<const int*>(ws + a.w.coarse_start);
   const int begin = cstart[coarse], end = cstart[coarse + 1];
   __shared__ int s_cnt[HCPAD];
   __shared__ int s_w[4];
@@ -823,11 +900,7 @@ __global__ __launch_bounds__(256) void cell_fine_kernel(CellArgs a) {
   for (int k = tid; k < HCPAD; k += 256) s_cnt[k] = 0;
   __syncthreads();
   const int2* t1_meta = reinterpret_cast<const int2*>(ws + a.w.t1_meta);
-  const float* q1_rec = reinterpret_cast<const float*>(ws + a.w.q1_rec);
-  for (int i = begin + tid; i < end; i += 256) {
-    const int fine = set ? __float_as_int(q1_rec[12 * (size_t)i + 11]) : t1_meta[i].y;
-    atomicAdd(&s_cnt[fine], 1);
-  }
+  for (int i = begin + tid; i < end; i += 256) atomicAdd(&s_cnt[t1_meta[i].y], 1);
   __syncthreads();
   // exclusive scan of the HCPAD counters: two per thread
   const int c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
@@ -843,153 +916,260 @@ __global__ __launch_bounds__(256) void cell_fine_kernel(CellArgs a) {
   const int ex = begin + woff + incl - v;
   __syncthreads();
   s_cnt[2 * tid] = ex; s_cnt[2 * tid + 1] = ex + c0;               // cursors = absolute first slots
-  if (set == 0) {
-    int* start_t = reinterpret_cast<int*>(ws + a.w.start_t) + (size_t)coarse * n_fine;
-    if (2 * tid < n_fine) start_t[2 * tid] = ex;
-    if (2 * tid + 1 < n_fine) start_t[2 * tid + 1] = ex + c0;
-    if (coarse == n_coarse - 1 && tid == 0) start_t[n_fine] = end;   // end sentinel (= nt)
+  int* start_t = reinterpret_cast<int*>(ws + a.w.start_t) + (size_t)coarse * n_fine;
+  if (2 * tid < n_fine) start_t[2 * tid] = ex;
+  if (2 * tid + 1 < n_fine) start_t[2 * tid + 1] = ex + c0;
+  if (coarse == n_coarse - 1 && tid == 0) start_t[n_fine] = end;   // end sentinel (= nt)
+  // the same row relative to the bin's first slot, 16 bits per entry (what the search stages; a bin of >= 65536
+  // points saturates and is searched through the absolute table instead)
+  unsigned short* rel = reinterpret_cast<unsigned short*>(ws + a.w.start_rel) + (size_t)coarse * HROW;
+  {
+    const int r0 = ex - begin, r1 = ex + c0 - begin;
+    if (2 * tid < n_fine) rel[2 * tid] = (unsigned short)(r0 < 65535 ? r0 : 65535);
+    if (2 * tid + 1 < n_fine) rel[2 * tid + 1] = (unsigned short)(r1 < 65535 ? r1 : 65535);
+    if (tid == 0) { const int re = end - begin; rel[n_fine] = (unsigned short)(re < 65535 ? re : 65535); }
   }
   __syncthreads();
-  if (set == 0) {
-    const float4* t1_pre = reinterpret_cast<const float4*>(ws + a.w.t1_pre);
-    float4* tree_pre = reinterpret_cast<float4*>(ws + a.w.tree_rec);
-    int* tree_idx = reinterpret_cast<int*>(ws + a.w.tree_idx);
-    for (int i = begin + tid; i < end; i += 256) {
-      const int2 m = t1_meta[i];
-      const int pos = atomicAdd(&s_cnt[m.y], 1);
-      tree_pre[pos] = t1_pre[i];
-      tree_idx[pos] = m.x;
-    }
-  } else {
-    float4* qry_rec = reinterpret_cast<float4*>(ws + a.w.qry_rec);
-    const float4* src = reinterpret_cast<const float4*>(q1_rec);
-    for (int i = begin + tid; i < end; i += 256) {
-      const float4 r0 = src[3 * (size_t)i], r1 = src[3 * (size_t)i + 1], r2 = src[3 * (size_t)i + 2];
-      const int pos = atomicAdd(&s_cnt[__float_as_int(r2.w)], 1);
-      qry_rec[3 * (size_t)pos] = r0; qry_rec[3 * (size_t)pos + 1] = r1; qry_rec[3 * (size_t)pos + 2] = r2;
-    }
+  const float4* t1_pre = reinterpret_cast<const float4*>(ws + a.w.t1_pre);
+  float4* tree_pre = reinterpret_cast<float4*>(ws + a.w.tree_rec);
+  int* tree_idx = reinterpret_cast<int*>(ws + a.w.tree_idx);
+  for (int i = begin + tid; i < end; i += 256) {
+    const int2 m = t1_meta[i];
+    const int pos = atomicAdd(&s_cnt[m.y], 1);
+    tree_pre[pos] = t1_pre[i];
+    tree_idx[pos] = m.x;
   }
 }
 
 // MODE 0: best match per query (bestMatchFull);  MODE 1 / 2: count / write ALL tree points with d2 < r2
 // (fullSearch, eigen_kdtree.h:56-71 + bruteForceSearch, brute_force_search.h:3-20)
+// One workgroup serves a STRIP of CS_NB coarse bins (c0, c1f .. c1f + CS_NB - 1): their queries are contiguous in
+// q1_idx, and their neighbourhoods overlap -- 3 x (CS_NB + 2) staged bins instead of 9 per bin.
+constexpr int CS_PLANES = 3 * (CS_NB + 2);
+constexpr int CS_STRIPS = (HNC + CS_NB - 1) / CS_NB;     // strips per c0 row, at most
 template <int MODE>
-__global__ __launch_bounds__(256) void cell_search_kernel(CellArgs a) {
-  const int f = blockIdx.z;
+__global__ __launch_bounds__(CS_THREADS) void cell_search_kernel(CellArgs a) {
+  int f, blk;
+  if (!xcd_frame_block(HNC * CS_STRIPS, a.n_frames, f, blk)) return;
   char* ws = a.ws + f * a.ws_stride;
+  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
+  const int n0 = cp.nc[0], n1 = cp.nc[1], n2 = cp.nc[2], n3 = cp.nc[3];
+  const int n_fine = n2 * n3;
+  const int c0 = blk / CS_STRIPS, c1f = (blk - c0 * CS_STRIPS) * CS_NB;
+  if (c0 >= n0 || c1f >= n1) return;
+  const int nb_here = n1 - c1f < CS_NB ? n1 - c1f : CS_NB;
+  const int coarse0 = c0 * n1 + c1f;
+  const int* __restrict__ cstart_t = reinterpret_cast<const int*>(ws + a.w.coarse_start);
+  const int* __restrict__ cstart_q = cstart_t + (HCPAD + 1);
+  const int qb = cstart_q[coarse0], qe = cstart_q[coarse0 + nb_here];
+  if (qb >= qe) return;                                   // no query lives here: nothing to stage
   const int* __restrict__ start_t = reinterpret_cast<const int*>(ws + a.w.start_t);
   const float4* __restrict__ tree_pre = reinterpret_cast<const float4*>(ws + a.w.tree_rec);
   const int* __restrict__ tree_idx = reinterpret_cast<const int*>(ws + a.w.tree_idx);
+  const int* __restrict__ q1_idx = reinterpret_cast<const int*>(ws + a.w.q1_idx);
   const float* __restrict__ tree = a.tree + f * a.tree_stride;
-  const float4* __restrict__ qry_rec = reinterpret_cast<const float4*>(ws + a.w.qry_rec);
-  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
+  const float* __restrict__ qry = a.qry + f * a.qry_stride;
   unsigned long long* best = a.best + f * a.best_stride;
-  const int qi = blockIdx.x * 256 + threadIdx.x;
-  const bool live = qi < a.nq;
-  const float4* qr = qry_rec + 3 * (size_t)(live ? qi : a.nq - 1);
-  const float4 qa = qr[0], qb = qr[1], qc = qr[2];
-  const float q[10] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};
-  const int qorig = __float_as_int(qc.z);
-  int c_lo[HK], c_hi[HK];
-#pragma unroll
-  for (int j = 0; j < HK; ++j) {
-    const float x = pick10(q, cp.dim[j]);
-    c_lo[j] = cell_of(x - cp.R, cp.lo[j], cp.scale[j], cp.nc[j]);
-    c_hi[j] = live ? cell_of(x + cp.R, cp.lo[j], cp.scale[j], cp.nc[j]) : c_lo[j] - 1;   // dead lanes: empty box
+  const int tid = threadIdx.x;
+
+  __shared__ float4 s_pre[CS_CAP];
+  __shared__ int s_idx[CS_CAP];
+  __shared__ __attribute__((aligned(16))) unsigned short s_start[CS_PLANES][HROW];   // cell starts of the staged bins, relative to each bin's first slot
+  __shared__ int s_gbase[CS_PLANES], s_lbase[CS_PLANES + 1], s_len[CS_PLANES];   // per bin: first slot in the sorted tree, in LDS, length
+  __shared__ unsigned short s_surv[CS_SURV][CS_THREADS];  // parked filter survivors (LDS slots), lane-private columns
+  // staged bin `s` = (row, col): coarse bin (c0 - 1 + row, c1f - 1 + col); bins outside the grid have length 0
+  if (tid < CS_PLANES) {
+    const int p0 = c0 - 1 + tid / (CS_NB + 2), p1 = c1f - 1 + tid % (CS_NB + 2);
+    int gb = 0, len = 0;
+    if (p0 >= 0 && p0 < n0 && p1 >= 0 && p1 < n1) { gb = cstart_t[p0 * n1 + p1]; len = cstart_t[p0 * n1 + p1 + 1] - gb; }
+    s_gbase[tid] = gb; s_len[tid] = len;
   }
-  float bd = a.r2, thr = a.r2 * PREFIX_SLACK;
-  int bi = -1;
-  int n_hit = 0;
-  int out_at = 0;
-  if (MODE == 2 && live) out_at = a.rs_offsets[qorig];
-  auto consider = [&](int p) {
-    const float4 ta = tree_pre[p];
-    // conservative filter (fused, 4 terms): see PREFIX_SLACK
-    const float d0 = ta.x - q[0], d1 = ta.y - q[1], d2 = ta.z - q[2], d3 = ta.w - q[3];
-    const float s4 = __builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0)));
-    if (s4 <= thr) {                                     // <=: an exact tie with a lower original index must still be seen
-      // the decision itself: the reference's unfused left-to-right sum (brute_force_search.h:34)
-      const int ti = tree_idx[p];
-      const float2* row = reinterpret_cast<const float2*>(tree + 10 * (size_t)ti);
-      const float2 r2v = row[2], r3v = row[3], r4v = row[4];
-      const float4 tb4 = make_float4(r2v.x, r2v.y, r3v.x, r3v.y);
-      const float2 tc = r4v;
+  // the first batch of queries: their (dependent) loads are in flight during the set-up and the staging
+  int qi = qb + tid;
+  int qorig = qi < qe ? q1_idx[qi] : q1_idx[qb];
+  float q[10];
+  load10(qry + 10 * (size_t)qorig, q);
+  __syncthreads();
+  int total = 0, longest = 0;
+  if (tid == 0) s_lbase[0] = 0;
+#pragma unroll
+  for (int s = 0; s < CS_PLANES; ++s) {
+    const int len = s_len[s];
+    total += len;
+    longest = len > longest ? len : longest;
+    if (tid == 0) s_lbase[s + 1] = total;
+  }
+  const bool staged = total <= CS_CAP && longest < 65535;
+  __syncthreads();
+  if (staged) {
+    // flattened over the staged bins: every thread's loads are independent, several in flight at once
+#pragma unroll 4
+    for (int i = tid; i < total; i += CS_THREADS) {
+      int s = 0;
+#pragma unroll
+      for (int j = 1; j < CS_PLANES; ++j) s += (i >= s_lbase[j]) ? 1 : 0;   // empty bins share a base: the last one wins,
+      const int g = s_gbase[s] + (i - s_lbase[s]);                          // and only a bin with points can own slot i
+      s_pre[i] = tree_pre[g];
+      s_idx[i] = tree_idx[g];
+    }
+    // the bins' rows of the 16-bit start table, eight entries per load
+    const uint4* rel = reinterpret_cast<const uint4*>(ws + a.w.start_rel);
+    const int vec_per_row = (n_fine + 1 + 7) / 8;
+#pragma unroll 2
+    for (int i = tid; i < CS_PLANES * (HROW / 8); i += CS_THREADS) {
+      const int s = i / (HROW / 8), v = i - s * (HROW / 8);
+      if (s_len[s] > 0 && v < vec_per_row) {
+        const int cb = (c0 - 1 + s / (CS_NB + 2)) * n1 + (c1f - 1 + s % (CS_NB + 2));
+        reinterpret_cast<uint4*>(&s_start[s][0])[v] = rel[(size_t)cb * (HROW / 8) + v];
+      }
+    }
+  }
+  __syncthreads();
+
+  for (; qi < qe; qi += CS_THREADS) {
+    if (qi >= qb + CS_THREADS) { qorig = q1_idx[qi]; load10(qry + 10 * (size_t)qorig, q); }   // later batches (rare)
+    int c_lo[HK], c_hi[HK];
+#pragma unroll
+    for (int j = 0; j < HK; ++j) {
+      // component cp.dim[j] of q, selected with wave-uniform bit masks (an indexed read would put q[] into scratch memory)
+      unsigned xb = 0;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) xb |= __float_as_uint(q[k]) & (cp.dim[j] == k ? 0xffffffffu : 0u);
+      const float x = __uint_as_float(xb);
+      c_lo[j] = cell_of(x - cp.R, cp.lo[j], cp.scale[j], cp.nc[j]);
+      const int h = cell_of(x + cp.R, cp.lo[j], cp.scale[j], cp.nc[j]);
+      c_hi[j] = h < c_lo[j] + 2 ? h : c_lo[j] + 2;
+    }
+    float bd = a.r2, thr = a.r2 * PREFIX_SLACK;
+    int bi = -1;
+    int n_hit = 0;
+    int out_at = 0;
+    if (MODE == 2) out_at = a.rs_offsets[qorig];
+    // the decision itself: the reference's unfused left-to-right sum (brute_force_search.h:34) over the whole row
+    auto decide = [&](const float4 ta, const int ti, const float2 r2v, const float2 r3v, const float2 r4v) {
       float d = ta.x - q[0];
       float s = d * d;
       d = ta.y - q[1]; s += d * d;
       d = ta.z - q[2]; s += d * d;
       d = ta.w - q[3]; s += d * d;
-      d = tb4.x - q[4]; s += d * d;
-      d = tb4.y - q[5]; s += d * d;
-      d = tb4.z - q[6]; s += d * d;
-      d = tb4.w - q[7]; s += d * d;
-      d = tc.x - q[8]; s += d * d;
-      d = tc.y - q[9]; s += d * d;
+      d = r2v.x - q[4]; s += d * d;
+      d = r2v.y - q[5]; s += d * d;
+      d = r3v.x - q[6]; s += d * d;
+      d = r3v.y - q[7]; s += d * d;
+      d = r4v.x - q[8]; s += d * d;
+      d = r4v.y - q[9]; s += d * d;
       if (MODE == 0) {
         if (s < bd || (s == bd && bi >= 0 && ti < bi)) { bd = s; thr = s * PREFIX_SLACK; bi = ti; }
       } else if (s < bd) {                               // bd stays radius^2: every point inside the ball
         if (MODE == 2 && out_at + n_hit < a.rs_capacity) a.rs_indices[out_at + n_hit] = ti;
         ++n_hit;
       }
-    }
-  };
-  // <= 3 cells per component (cell width >= R).  One (c0, c1) plane at a time: its three runs' bounds are
-  // six independent loads; the runs are then walked two points per trip.
-  for (int i0 = 0; i0 < 3; ++i0)
-    for (int i1 = 0; i1 < 3; ++i1) {
-      const int c0 = c_lo[0] + i0, c1 = c_lo[1] + i1;
-      const bool in01 = c0 <= c_hi[0] && c1 <= c_hi[1] && c_lo[3] <= c_hi[3];
-      if (!__ballot(in01)) continue;
-      int rp[3], re[3];
-#pragma unroll
-      for (int i2 = 0; i2 < 3; ++i2) {
-        const int c2 = c_lo[2] + i2;
-        const bool in = in01 && c2 <= c_hi[2];
-        const int key0 = ((c0 * cp.nc[1] + c1) * cp.nc[2] + c2) * cp.nc[3];
-        const int ka = in ? key0 + c_lo[3] : 0, kb = in ? key0 + c_hi[3] + 1 : 0;
-        const int sa = start_t[ka], sb = start_t[kb];
-        rp[i2] = in ? sa : 0; re[i2] = in ? sb : 0;
+    };
+    // conservative filter (fused, 4 terms): see PREFIX_SLACK.  <=: an exact tie with a lower original index must be seen
+    auto passes = [&](const float4 ta) {
+      const float d0 = ta.x - q[0], d1 = ta.y - q[1], d2 = ta.z - q[2], d3 = ta.w - q[3];
+      return __builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0))) <= thr;
+    };
+    auto consider = [&](const float4 ta, const int ti) {
+      if (passes(ta)) {
+        const float2* row = reinterpret_cast<const float2*>(tree + 10 * (size_t)ti);
+        decide(ta, ti, row[2], row[3], row[4]);
       }
-#pragma unroll
-      for (int i2 = 0; i2 < 3; ++i2) {
-        int p = rp[i2];
-        const int e = re[i2];
-        while (__ballot(p < e)) {
-          if (p < e) consider(p);
-          if (p + 1 < e) consider(p + 1);
-          p += 2;
+    };
+    // the query's box in staged-bin coordinates
+    const int row_lo = c_lo[0] - (c0 - 1), row_hi = c_hi[0] - (c0 - 1);
+    const int col_lo = c_lo[1] - (c1f - 1), col_hi = c_hi[1] - (c1f - 1);
+    if (staged && row_lo >= 0 && row_hi <= 2 && col_lo >= 0 && col_hi <= CS_NB + 1) {
+      // Walk first, decide afterwards.  A survivor of the filter needs the rest of its row from global memory (a
+      // miss of ~1 us); deciding it on the spot would stall the whole wave once per lane.  The walk therefore only
+      // PARKS survivors (their LDS slot); the rows of all lanes' k-th survivors are then fetched together.  The
+      // filter runs against radius^2 throughout (it cannot tighten before a decision): a few more survivors
+      // (~2.5 per query on uniform data), no different result -- every decision is order-independent
+      // (minimum of (d2, index)).  A lane whose list is full decides that survivor on the spot.
+      int n_surv = 0;
+      // <= 3 x 3 staged bins per lane; per bin the lane's three runs (c2 = lo..lo+2, contiguous along c3) are walked
+      // as ONE flattened sequence: the trip count of the wave is the largest sum of three run lengths among its
+      // lanes, not the sum of three maxima.  The next candidate is fetched while the current one is filtered.
+      for (int i0 = 0; i0 < 3; ++i0)
+        for (int i1 = 0; i1 < 3; ++i1) {
+          const bool in01 = row_lo + i0 <= row_hi && col_lo + i1 <= col_hi;
+          const int s = in01 ? (row_lo + i0) * (CS_NB + 2) + col_lo + i1 : 0;
+          // the three runs as plain scalars, and no lambda that captures them by reference: the compiler otherwise
+          // parks them in scratch memory and selects among their ADDRESSES
+          const bool in_s = in01 && s_len[s] > 0;
+          const int lb = s_lbase[s];
+          const int c2a = c_lo[2], c2b = c_lo[2] + 1, c2c = c_lo[2] + 2;
+          const bool ina = in_s && c2a <= c_hi[2], inb = in_s && c2b <= c_hi[2], inc = in_s && c2c <= c_hi[2];
+          const int sa0 = s_start[s][ina ? c2a * n3 + c_lo[3] : 0], sb0 = s_start[s][ina ? c2a * n3 + c_hi[3] + 1 : 0];
+          const int sa1 = s_start[s][inb ? c2b * n3 + c_lo[3] : 0], sb1 = s_start[s][inb ? c2b * n3 + c_hi[3] + 1 : 0];
+          const int sa2 = s_start[s][inc ? c2c * n3 + c_lo[3] : 0], sb2 = s_start[s][inc ? c2c * n3 + c_hi[3] + 1 : 0];
+          const int ln0 = ina ? sb0 - sa0 : 0, ln1 = inb ? sb1 - sa1 : 0, ln2 = inc ? sb2 - sa2 : 0;
+          const int l01 = ln0 + ln1, tot = l01 + ln2;
+          const int b0 = lb + sa0, b1 = lb + sa1 - ln0, b2 = lb + sa2 - l01;     // slot(k) = k + (b0 | b1 | b2)
+          int pos = b0;
+          pos = 0 >= ln0 ? b1 : pos;
+          pos = 0 >= l01 ? b2 : pos;
+          pos = tot > 0 ? pos : 0;
+          float4 ta = s_pre[pos];
+          for (int k = 0; k < tot; ++k) {
+            int base_n = b0;
+            base_n = k + 1 >= ln0 ? b1 : base_n;
+            base_n = k + 1 >= l01 ? b2 : base_n;
+            const int pos_n = k + 1 < tot ? base_n + k + 1 : pos;       // (always a valid slot: one unconditional read)
+            const float4 ta_n = s_pre[pos_n];
+            if (passes(ta)) {
+              if (n_surv < CS_SURV) { s_surv[n_surv][tid] = (unsigned short)pos; ++n_surv; }
+              else consider(ta, s_idx[pos]);
+            }
+            pos = pos_n; ta = ta_n;
+          }
         }
+      for (int k = 0; k < n_surv; k += 3) {               // three rows per lane in flight
+        const bool h1 = k + 1 < n_surv, h2 = k + 2 < n_surv;
+        const int pa = s_surv[k][tid], pb = s_surv[h1 ? k + 1 : k][tid], pc = s_surv[h2 ? k + 2 : k][tid];
+        const float4 fa = s_pre[pa], fb = s_pre[pb], fc = s_pre[pc];
+        const int ia = s_idx[pa], ib = s_idx[pb], ic = s_idx[pc];
+        const float2* ra = reinterpret_cast<const float2*>(tree + 10 * (size_t)ia);
+        const float2* rb = reinterpret_cast<const float2*>(tree + 10 * (size_t)ib);
+        const float2* rc = reinterpret_cast<const float2*>(tree + 10 * (size_t)ic);
+        const float2 a2 = ra[2], a3 = ra[3], a4 = ra[4], b2 = rb[2], b3 = rb[3], b4 = rb[4], c2 = rc[2], c3 = rc[3], c4 = rc[4];
+        decide(fa, ia, a2, a3, a4);
+        if (h1) decide(fb, ib, b2, b3, b4);
+        if (h2) decide(fc, ic, c2, c3, c4);
       }
+    } else {
+      // the same walk on global memory (segments beyond the LDS budget, or a box beyond the staged bins)
+      for (int x0 = c_lo[0]; x0 <= c_hi[0]; ++x0)
+        for (int x1 = c_lo[1]; x1 <= c_hi[1]; ++x1)
+          for (int x2 = c_lo[2]; x2 <= c_hi[2]; ++x2) {
+            const int key0 = ((x0 * n1 + x1) * n2 + x2) * n3;
+            const int e = start_t[key0 + c_hi[3] + 1];
+            for (int p = start_t[key0 + c_lo[3]]; p < e; ++p) consider(tree_pre[p], tree_idx[p]);
+          }
     }
-  if (MODE == 0 && live)
-    best[qorig] = bi >= 0 ? (((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(unsigned)bi)
-                          : (((unsigned long long)__float_as_uint(a.r2) << 32) | 0xffffffffull);
-  if (MODE == 1 && live) a.rs_offsets[qorig] = n_hit;
+    if (MODE == 0)
+      best[qorig] = bi >= 0 ? (((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(unsigned)bi)
+                            : (((unsigned long long)__float_as_uint(a.r2) << 32) | 0xffffffffull);
+    if (MODE == 1) a.rs_offsets[qorig] = n_hit;
+  }
 }
 
 static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tree, int nt, const float* qry, int nq,
                                     float radius, float r2, unsigned long long* d_best, void* ws, int n_frames,
                                     size_t tree_stride, size_t qry_stride, size_t best_stride) {
   a.tree = tree; a.qry = qry; a.nt = nt; a.nq = nq;
-  a.mm = static_cast<const unsigned*>(ws);
-  a.ws = static_cast<char*>(ws) + align256(128 * (size_t)n_frames);
+  a.ws = static_cast<char*>(ws);
   a.w = cell_ws_layout(nt, nq);
   a.ws_stride = a.w.total; a.tree_stride = tree_stride; a.qry_stride = qry_stride; a.best_stride = best_stride;
-  a.mm_stride = 128;
+  a.n_frames = n_frames;
   a.radius = radius; a.r2 = r2; a.best = d_best;
   a.rs_offsets = nullptr; a.rs_indices = nullptr; a.rs_capacity = 0;
   const unsigned Z = (unsigned)n_frames;
-  hipError_t e = hipMemsetAsync(ws, 0xff, 128 * (size_t)n_frames, st);
-  if (e != hipSuccess) return e;
-  MatchStrides ms;
-  ms.tree = tree_stride; ms.qry = qry_stride; ms.best = best_stride; ms.ws = 0; ms.mm = 128;
-  int g = (nt + nq + 255) / 256;
-  hipLaunchKernelGGL(match_minmax_kernel, dim3(g > 256 ? 256 : g, 1, Z), dim3(256), 0, st, tree, nt, qry, nq,
-                     static_cast<unsigned*>(ws), ms);
-  hipLaunchKernelGGL(cell_coarse_hist_kernel, dim3(SORT_BLOCKS, 1, Z), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_bounds_kernel, dim3(Z), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(cell_coarse_hist_kernel, dim3(xcd_grid(SORT_BLOCKS, n_frames)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(cell_coarse_offsets_kernel, dim3(2, 1, Z), dim3(HCPAD), 0, st, a);
-  hipLaunchKernelGGL(cell_coarse_place_kernel, dim3(SORT_BLOCKS, 1, Z), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(cell_fine_kernel, dim3(HCOARSE, 2, Z), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_coarse_place_kernel, dim3(xcd_grid(SORT_BLOCKS, n_frames)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_fine_kernel, dim3(xcd_grid(HCOARSE, n_frames)), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -1000,7 +1180,7 @@ static hipError_t launch_match_cells(hipStream_t st, const float* tree, int nt, 
   hipError_t e = launch_cells_sort(st, a, tree, nt, qry, nq, radius, r2, d_best, ws, n_frames, tree_stride, qry_stride,
                                    best_stride);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(cell_search_kernel<0>, dim3((nq + 255) / 256, 1, (unsigned)n_frames), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_search_kernel<0>, dim3(xcd_grid(HNC * CS_STRIPS, n_frames)), dim3(CS_THREADS), 0, st, a);
   return hipGetLastError();
 }
 
@@ -1013,10 +1193,10 @@ hipError_t launch_radius_search(hipStream_t st, const float* d_tree, int nt, con
   hipError_t e = launch_cells_sort(st, a, d_tree, nt, d_qry, nq, radius, radius * radius, nullptr, ws, 1, 0, 0, 0);
   if (e != hipSuccess) return e;
   a.rs_offsets = d_offsets; a.rs_indices = d_indices; a.rs_capacity = capacity;
-  hipLaunchKernelGGL(cell_search_kernel<1>, dim3((nq + 255) / 256, 1, 1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_search_kernel<1>, dim3(xcd_grid(HNC * CS_STRIPS, 1)), dim3(CS_THREADS), 0, st, a);
   e = launch_scan(st, d_offsets, nq, d_offsets + nq, nullptr, 1, 0);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(cell_search_kernel<2>, dim3((nq + 255) / 256, 1, 1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_search_kernel<2>, dim3(xcd_grid(HNC * CS_STRIPS, 1)), dim3(CS_THREADS), 0, st, a);
   return hipGetLastError();
 }
 
