@@ -677,11 +677,13 @@ __device__ CellParams make_cell_params(const float* lo_in, const float* hi_in, f
   return cp;
 }
 
+// component k of v (k is wave-uniform), selected with bit masks: an indexed read -- which is what the compiler makes
+// of a chain of selects -- would put v[] into scratch memory
 __device__ __forceinline__ float pick10(const float* v, int k) {
-  float x = v[0];
+  unsigned x = 0;
 #pragma unroll
-  for (int j = 1; j < 10; ++j) if (k == j) x = v[j];
-  return x;
+  for (int j = 0; j < 10; ++j) x |= __float_as_uint(v[j]) & (k == j ? 0xffffffffu : 0u);
+  return __uint_as_float(x);
 }
 
 // per-frame workspace of the cell variant (bytes, every block 256-aligned)
@@ -696,7 +698,7 @@ static CellWs cell_ws_layout(int nt, int nq) {
   w.t1_pre = o; o += align256(sizeof(float) * 4 * (size_t)nt);        // level 1 (coarse order): tree prefix,
   w.t1_meta = o; o += align256(sizeof(int) * 2 * (size_t)nt);         //   (original index, fine bin)
   w.q1_idx = o; o += align256(sizeof(int) * (size_t)nq);              //   query indices grouped by coarse bin
-  w.block_hist = o; o += align256(sizeof(int) * (size_t)SORT_BLOCKS * 2 * HCPAD);
+  w.block_hist = o; o += align256(sizeof(int) * (size_t)36 * 2 * HCPAD);   // CELL_ROWS rows
   w.coarse_start = o; o += align256(sizeof(int) * 2 * (HCPAD + 1));
   w.start_t = o; o += align256(sizeof(int) * (size_t)HBINS);          // first tree slot of every cell (+ end sentinel)
   w.start_rel = o; o += align256(sizeof(unsigned short) * (size_t)HCOARSE * HROW);   // the same per coarse bin, relative to
@@ -788,36 +790,40 @@ __global__ __launch_bounds__(1024) void cell_bounds_kernel(CellArgs a) {
   }
 }
 
-// level 1, histogram: SORT_BLOCKS workgroups per frame, each a contiguous slice of [0,nt) tree + [nt,nt+nq) queries
-__device__ __forceinline__ void cell_slice(int blk, int nt, int nq, int& lo, int& hi) {
-  const int total = nt + nq;
-  const int per = (total + SORT_BLOCKS - 1) / SORT_BLOCKS;
-  lo = blk * per;
-  hi = lo + per < total ? lo + per : total;
+// level 1: CELL_TB workgroups per frame take contiguous slices of the tree, CELL_QB of the queries (a row of
+// block_hist each; only the row's own half is non-zero)
+constexpr int CELL_TB = 28, CELL_QB = 8, CELL_ROWS = CELL_TB + CELL_QB;
+constexpr int PL_TCAP = 1920;            // tree points a placement workgroup can order in LDS (24 B each)
+constexpr int PL_QCAP = 6400;            // queries (6 B each)
+__device__ __forceinline__ void cell_slice(int blk, int nt, int nq, bool& is_t, int& lo, int& hi) {
+  is_t = blk < CELL_TB;
+  const int n = is_t ? nt : nq, parts = is_t ? CELL_TB : CELL_QB, b = is_t ? blk : blk - CELL_TB;
+  const int per = (n + parts - 1) / parts;
+  lo = b * per < n ? b * per : n;
+  hi = lo + per < n ? lo + per : n;
 }
 
 __global__ __launch_bounds__(256) void cell_coarse_hist_kernel(CellArgs a) {
   int f, blk;
-  if (!xcd_frame_block(SORT_BLOCKS, a.n_frames, f, blk)) return;
-  const float* tree = a.tree + f * a.tree_stride; const float* qry = a.qry + f * a.qry_stride;
+  if (!xcd_frame_block(CELL_ROWS, a.n_frames, f, blk)) return;
   char* ws = a.ws + f * a.ws_stride;
-  __shared__ int s_h[2 * HCPAD];
-  for (int k = threadIdx.x; k < 2 * HCPAD; k += 256) s_h[k] = 0;
+  __shared__ int s_h[HCPAD];
+  for (int k = threadIdx.x; k < HCPAD; k += 256) s_h[k] = 0;
   const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
   __syncthreads();
-  int lo, hi;
-  cell_slice(blk, a.nt, a.nq, lo, hi);
+  bool is_t; int lo, hi;
+  cell_slice(blk, a.nt, a.nq, is_t, lo, hi);
+  const float* src = is_t ? a.tree + f * a.tree_stride : a.qry + f * a.qry_stride;
   for (int i = lo + threadIdx.x; i < hi; i += 256) {
-    const bool is_t = i < a.nt;
     float v[10];
-    load10(is_t ? tree + 10 * (size_t)i : qry + 10 * (size_t)(i - a.nt), v);
+    load10(src + 10 * (size_t)i, v);
     int coarse, fine;
     cell_bins(v, cp, coarse, fine);
-    atomicAdd(&s_h[(is_t ? 0 : HCPAD) + coarse], 1);
+    atomicAdd(&s_h[coarse], 1);
   }
   __syncthreads();
-  int* block_hist = reinterpret_cast<int*>(ws + a.w.block_hist);
-  for (int k = threadIdx.x; k < 2 * HCPAD; k += 256) block_hist[(size_t)blk * 2 * HCPAD + k] = s_h[k];
+  int* row = reinterpret_cast<int*>(ws + a.w.block_hist) + (size_t)blk * 2 * HCPAD;
+  for (int k = threadIdx.x; k < HCPAD; k += 256) { row[(is_t ? 0 : HCPAD) + k] = s_h[k]; row[(is_t ? HCPAD : 0) + k] = 0; }
 }
 
 // level 1, offsets: grid 2 (tree half, query half) x HCPAD threads (one coarse bin each): exclusive scan over the
@@ -829,8 +835,9 @@ __global__ __launch_bounds__(HCPAD) void cell_coarse_offsets_kernel(CellArgs a) 
   int* starts = reinterpret_cast<int*>(ws + a.w.coarse_start);
   __shared__ int s_w[HCPAD / 64];
   const int half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b_lo = half ? CELL_TB : 0, b_hi = half ? CELL_ROWS : CELL_TB;      // the rows that hold this set
   int v = 0;
-  for (int b = 0; b < SORT_BLOCKS; ++b) v += block_hist[(size_t)b * 2 * HCPAD + half * HCPAD + tid];
+  for (int b = b_lo; b < b_hi; ++b) v += block_hist[(size_t)b * 2 * HCPAD + half * HCPAD + tid];
   int incl = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
@@ -842,7 +849,7 @@ __global__ __launch_bounds__(HCPAD) void cell_coarse_offsets_kernel(CellArgs a) 
   int run = woff + incl - v;
   starts[half * (HCPAD + 1) + tid] = run;
   if (tid == 0) starts[half * (HCPAD + 1) + HCPAD] = tot;
-  for (int b = 0; b < SORT_BLOCKS; ++b) {
+  for (int b = b_lo; b < b_hi; ++b) {
     int* slot = &block_hist[(size_t)b * 2 * HCPAD + half * HCPAD + tid];
     const int h = *slot;
     *slot = run;
@@ -850,35 +857,93 @@ __global__ __launch_bounds__(HCPAD) void cell_coarse_offsets_kernel(CellArgs a) 
   }
 }
 
-// level 1, placement in coarse order.  Tree: filter prefix + (original index, fine bin); queries: the index alone
+// level 1, placement in coarse order.  Tree: filter prefix + (original index, fine bin); queries: the index alone.
+// A workgroup's records land in ~400 bins, four or so per bin: written straight from the registers that is one
+// scattered 16/8/4-byte store per lane, and the L2 channels take those one request at a time (0.28 of the kernel's
+// 0.43 ms per 200 frames).  The workgroup therefore ORDERS its records by bin in LDS first (its own counts per bin are
+// the differences of consecutive rows of offsets) and then copies LDS -> global in that order: consecutive lanes write
+// consecutive addresses inside a bin's run, and the frame's workgroups share one XCD, whose L2 merges the runs.
 __global__ __launch_bounds__(256) void cell_coarse_place_kernel(CellArgs a) {
   int f, blk;
-  if (!xcd_frame_block(SORT_BLOCKS, a.n_frames, f, blk)) return;
-  const float* tree = a.tree + f * a.tree_stride; const float* qry = a.qry + f * a.qry_stride;
+  if (!xcd_frame_block(CELL_ROWS, a.n_frames, f, blk)) return;
   char* ws = a.ws + f * a.ws_stride;
+  bool is_t; int lo, hi;
+  cell_slice(blk, a.nt, a.nq, is_t, lo, hi);
+  const float* src = is_t ? a.tree + f * a.tree_stride : a.qry + f * a.qry_stride;
+  const int half = is_t ? 0 : HCPAD, set = is_t ? 0 : 1;
   const int* block_off = reinterpret_cast<const int*>(ws + a.w.block_hist);
+  const int* cstart = reinterpret_cast<const int*>(ws + a.w.coarse_start) + set * (HCPAD + 1);
   float4* t1_pre = reinterpret_cast<float4*>(ws + a.w.t1_pre);
   int2* t1_meta = reinterpret_cast<int2*>(ws + a.w.t1_meta);
   int* q1_idx = reinterpret_cast<int*>(ws + a.w.q1_idx);
-  __shared__ int s_off[2 * HCPAD];
-  for (int k = threadIdx.x; k < 2 * HCPAD; k += 256) s_off[k] = block_off[(size_t)blk * 2 * HCPAD + k];
+  __shared__ int s_off[HCPAD];           // first global slot of this workgroup's records, per bin
+  __shared__ int s_cur[HCPAD];           // LDS cursor per bin (starts at the bin's first LDS slot)
+  __shared__ int s_delta[HCPAD];         // global slot - LDS slot, per bin
+  __shared__ int s_w[4];
+  __shared__ __attribute__((aligned(16))) unsigned char s_rec[PL_TCAP * 24];   // tree: float4 prefix[PL_TCAP] + int2 meta[PL_TCAP];
+                                                                               // queries: int idx[PL_QCAP] + ushort bin[PL_QCAP]
+  static_assert(PL_QCAP * 6 <= PL_TCAP * 24, "query staging must fit the tree staging");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool last_row = is_t ? blk == CELL_TB - 1 : blk == CELL_ROWS - 1;
+  // this workgroup's count per bin = next row's offset (or the bin's end) - its own offset; two bins per thread
+  int off[2], cnt[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = 2 * tid + j;
+    off[j] = block_off[(size_t)blk * 2 * HCPAD + half + k];
+    const int nxt = last_row ? (k + 1 <= HCPAD ? cstart[k + 1] : off[j]) : block_off[(size_t)(blk + 1) * 2 * HCPAD + half + k];
+    cnt[j] = nxt - off[j];
+  }
+  const int v = cnt[0] + cnt[1];
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+  if (lane == 63) s_w[wave] = incl;
   __syncthreads();
+  int woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { const int c = s_w[w]; if (w < wave) woff += c; total += c; }
+  const int ex = woff + incl - v;
+  s_off[2 * tid] = off[0]; s_off[2 * tid + 1] = off[1];
+  s_cur[2 * tid] = ex; s_cur[2 * tid + 1] = ex + cnt[0];
+  s_delta[2 * tid] = off[0] - ex; s_delta[2 * tid + 1] = off[1] - (ex + cnt[0]);
   const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
-  int lo, hi;
-  cell_slice(blk, a.nt, a.nq, lo, hi);
-  for (int i = lo + threadIdx.x; i < hi; i += 256) {
-    const bool is_t = i < a.nt;
-    const int idx = is_t ? i : i - a.nt;
-    float v[10];
-    load10((is_t ? tree : qry) + 10 * (size_t)idx, v);
+  const bool ordered = total == hi - lo && total <= (is_t ? PL_TCAP : PL_QCAP);     // else: straight stores
+  __syncthreads();
+  float4* r_pre = reinterpret_cast<float4*>(s_rec);
+  int2* r_meta = reinterpret_cast<int2*>(s_rec + (size_t)PL_TCAP * 16);
+  int* r_qidx = reinterpret_cast<int*>(s_rec);
+  unsigned short* r_qbin = reinterpret_cast<unsigned short*>(s_rec + (size_t)PL_QCAP * 4);
+  for (int i = lo + tid; i < hi; i += 256) {
+    float v10[10];
+    load10(src + 10 * (size_t)i, v10);
     int coarse, fine;
-    cell_bins(v, cp, coarse, fine);
-    const int pos = atomicAdd(&s_off[(is_t ? 0 : HCPAD) + coarse], 1);
-    if (is_t) {
-      t1_pre[pos] = make_float4(v[0], v[1], v[2], v[3]);
-      t1_meta[pos] = make_int2(idx, fine);
+    cell_bins(v10, cp, coarse, fine);
+    if (ordered) {
+      const int slot = atomicAdd(&s_cur[coarse], 1);
+      if (is_t) {
+        r_pre[slot] = make_float4(v10[0], v10[1], v10[2], v10[3]);
+        r_meta[slot] = make_int2(i, fine | (coarse << 16));
+      } else {
+        r_qidx[slot] = i;
+        r_qbin[slot] = (unsigned short)coarse;
+      }
     } else {
-      q1_idx[pos] = idx;
+      const int pos = atomicAdd(&s_off[coarse], 1);
+      if (is_t) { t1_pre[pos] = make_float4(v10[0], v10[1], v10[2], v10[3]); t1_meta[pos] = make_int2(i, fine); }
+      else q1_idx[pos] = i;
+    }
+  }
+  if (!ordered) return;
+  __syncthreads();
+  for (int i = tid; i < total; i += 256) {
+    if (is_t) {
+      const int2 m = r_meta[i];
+      const int dest = i + s_delta[m.y >> 16];
+      t1_pre[dest] = r_pre[i];
+      t1_meta[dest] = make_int2(m.x, m.y & 0xffff);
+    } else {
+      q1_idx[i + s_delta[r_qbin[i]]] = r_qidx[i];
     }
   }
 }
@@ -1031,11 +1096,7 @@ __global__ __launch_bounds__(CS_THREADS) void cell_search_kernel(CellArgs a) {
     int c_lo[HK], c_hi[HK];
 #pragma unroll
     for (int j = 0; j < HK; ++j) {
-      // component cp.dim[j] of q, selected with wave-uniform bit masks (an indexed read would put q[] into scratch memory)
-      unsigned xb = 0;
-#pragma unroll
-      for (int k = 0; k < 10; ++k) xb |= __float_as_uint(q[k]) & (cp.dim[j] == k ? 0xffffffffu : 0u);
-      const float x = __uint_as_float(xb);
+      const float x = pick10(q, cp.dim[j]);
       c_lo[j] = cell_of(x - cp.R, cp.lo[j], cp.scale[j], cp.nc[j]);
       const int h = cell_of(x + cp.R, cp.lo[j], cp.scale[j], cp.nc[j]);
       c_hi[j] = h < c_lo[j] + 2 ? h : c_lo[j] + 2;
@@ -1166,9 +1227,9 @@ static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tr
   a.rs_offsets = nullptr; a.rs_indices = nullptr; a.rs_capacity = 0;
   const unsigned Z = (unsigned)n_frames;
   hipLaunchKernelGGL(cell_bounds_kernel, dim3(Z), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(cell_coarse_hist_kernel, dim3(xcd_grid(SORT_BLOCKS, n_frames)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_coarse_hist_kernel, dim3(xcd_grid(CELL_ROWS, n_frames)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(cell_coarse_offsets_kernel, dim3(2, 1, Z), dim3(HCPAD), 0, st, a);
-  hipLaunchKernelGGL(cell_coarse_place_kernel, dim3(xcd_grid(SORT_BLOCKS, n_frames)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_coarse_place_kernel, dim3(xcd_grid(CELL_ROWS, n_frames)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(cell_fine_kernel, dim3(xcd_grid(HCOARSE, n_frames)), dim3(256), 0, st, a);
   return hipGetLastError();
 }
