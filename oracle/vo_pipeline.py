@@ -149,27 +149,30 @@ class Map:
                 self.pts.append(p); self.app.append(a)
 
 
-def run_vo_complete(data_dir, rounds=100, o: Oracle | None = None, X0=None):
-    """X0: first relative pose to start the chain from (default: the epipolar initialisation below)."""
+def run_sequence(frames, K, rows, cols, zn, zf, rounds=100, o: Oracle | None = None, X0=None, kdtree=False,
+                 keep_map=True):
+    """The frame loop of vo_complete.cpp:97-181 on measurement sets held in memory: frames = list of (pts (n,2), app
+    (n,10)).  X0: first relative pose to start the chain from (default: the epipolar initialisation).  kdtree: match
+    with the reference's own PCA kd-tree restatement (oracle/vo_kdtree.c) instead of the double loop -- same pairs,
+    usable at 50k points.  Returns trajectory, per-frame (matches, joined, inliers) and, with keep_map, the map."""
     o = o or Oracle(32)
-    files = sorted(f for f in os.listdir(data_dir) if re.search(r"^meas-\d.*\.dat$", f))
-    K, H, ints = read_camera(os.path.join(data_dir, "camera.dat"))
-    rows, cols, zn, zf = ints["height"], ints["width"], ints["z_near"], ints["z_far"]
-    ref_pts, ref_app, _ = read_meas(os.path.join(data_dir, files[0]))
-    cur_pts, cur_app, _ = read_meas(os.path.join(data_dir, files[1]))
-    corr = o.match(ref_app, cur_app)
+    match = (lambda a, b: o.match_kdtree(a, b)) if kdtree else (lambda a, b: o.match(a, b))
+    ref_pts, ref_app = frames[0]
+    cur_pts, cur_app = frames[1]
+    corr = match(ref_app, cur_app)
     X = estimate_transform(o, K, corr, ref_pts, cur_pts) if X0 is None else np.asarray(X0, np.float32).reshape(4, 4).copy()
     tri, corr_world, tri_app = o.triangulate(K, X, corr, ref_pts, cur_pts, cur_app)
     traj = [np.eye(4, dtype=np.float32), X.copy()]
-    m = Map(); m.update(tri, tri_app)
+    m = Map()
+    if keep_map:
+        m.update(tri, tri_app)
     history = iso_inv(X.astype(np.float64)).astype(np.float32)
     X_curr = X
     ref_pts, ref_app = cur_pts, cur_app
-    stats = []
-    for f in files[2:]:
-        cur_pts, cur_app, _ = read_meas(os.path.join(data_dir, f))
-        corr = o.match(ref_app, cur_app)
-        corr_world = o.join(corr, corr_world)
+    stats, tri_counts = [], [len(tri)]
+    for cur_pts, cur_app in frames[2:]:
+        corr = match(ref_app, cur_app)
+        corr_world = o.join(corr, corr_world, linear=kdtree)      # (the O(C) form gives the same pairs; asserted in test_oracle)
         moved = o.transform_points(X_curr, tri)
         r = o.picp_solve(Camera(rows, cols, zn, zf, K, np.eye(4)), moved, cur_pts, corr_world, rounds, 10000.0, False,
                          trace=False)
@@ -177,11 +180,26 @@ def run_vo_complete(data_dir, rounds=100, o: Oracle | None = None, X0=None):
         traj.append(X_curr.copy())
         stats.append((len(corr), len(corr_world), r["num_inliers"]))
         tri, corr_world, tri_app = o.triangulate(K, X_curr, corr, ref_pts, cur_pts, cur_app)
-        m.update(o.transform_points(history, tri) if len(tri) else tri, tri_app)
+        tri_counts.append(len(tri))
+        if keep_map:
+            m.update(o.transform_points(history, tri) if len(tri) else tri, tri_app)
         history = (history.astype(np.float64) @ iso_inv(X_curr.astype(np.float64))).astype(np.float32)
         ref_pts, ref_app = cur_pts, cur_app
+    return dict(trajectory=traj, stats=stats, tri_counts=tri_counts, map=m)
+
+
+def run_vo_complete(data_dir, rounds=100, o: Oracle | None = None, X0=None):
+    """X0: first relative pose to start the chain from (default: the epipolar initialisation below)."""
+    o = o or Oracle(32)
+    files = sorted(f for f in os.listdir(data_dir) if re.search(r"^meas-\d.*\.dat$", f))
+    K, H, ints = read_camera(os.path.join(data_dir, "camera.dat"))
+    rows, cols, zn, zf = ints["height"], ints["width"], ints["z_near"], ints["z_far"]
+    frames = [read_meas(os.path.join(data_dir, f))[:2] for f in files]
+    res = run_sequence(frames, K, rows, cols, zn, zf, rounds, o, X0)
+    m = res["map"]
     map_pts = o.transform_points(H, np.array(m.pts, np.float32).reshape(-1, 3))
-    return dict(trajectory=traj, map=map_pts, map_app=np.array(m.app, np.float32).reshape(-1, 10), H=H, stats=stats)
+    return dict(trajectory=res["trajectory"], map=map_pts, map_app=np.array(m.app, np.float32).reshape(-1, 10), H=H,
+                stats=res["stats"])
 
 
 def robot_trajectory(traj, H):

@@ -1,0 +1,104 @@
+"""BASELINE configs[2] and [3] at their FULL sizes inside the -m gpu suite.
+
+ * config 4's per-GPU share: ONE vo_frames_batch_dev call over 200 frame pairs x 50 000 points x 50 rounds
+   (gridDim over 200 frames, 200 MB of packed correspondences, the cell-hash matcher picked by the auto rule): every
+   frame against the generator's ground truth, three frames stage by stage against the oracle (its matcher is the
+   reference's own PCA kd-tree: the double loop would take minutes).
+ * config 3: the device-resident sequence at 40 frames x ~50k landmarks in view x 100 rounds, solver in reference-order
+   arithmetic: every count and every pose of the chain against the oracle-side run of the same loop, bit for bit.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import vo_pipeline as P
+from oracle.oracle import Camera as OCam
+
+pytestmark = pytest.mark.gpu
+N, F, ITERS = 50000, 200, 50
+
+
+def test_batched_frames_200x50k(vo, ctx, o32):
+    distinct = [vo.synth.frame_pair(N, seed=4000 + p) for p in range(8)]        # config 4's seeds; values repeat every
+    fps = [distinct[i % 8] for i in range(F)]                                  # 8 frames, all 200 are separate copies
+    bp = vo.BatchPipeline(ctx, lambda lo, hi: fps[lo:hi], n_iters=ITERS, n_frames=F, upload_block=40)
+    bp.run()
+    ctx.synchronize()
+    c, T, st = bp.counts(), bp.poses(), bp.stats()
+    # every frame: all matches, all joins, all inliers, the generator's pose
+    assert np.all(c[0] == N) and np.all(c[1] == N) and np.all(st[:, 2] == N)
+    assert np.all(c[2] > 0.5 * N) and np.all(c[2] <= N)
+    err = np.abs(T - bp.X_gt).reshape(F, -1).max(axis=1)
+    assert err.max() < 1e-3, (int(err.argmax()), float(err.max()))
+    for f in range(F):                                                         # copies of one pair: identical results
+        assert np.array_equal(T[f], T[f % 8]) and np.array_equal(c[:, f], c[:, f % 8])
+    # three frames stage by stage against the oracle
+    for f in (0, 101, 199):
+        fp = fps[f]
+        m = bp.fetch("match", f)
+        m_o = o32.match_kdtree(fp["ref_app"], fp["cur_app"])
+        assert np.array_equal(m, m_o)
+        assert np.array_equal(m, fp["gt_matches"])                             # = the generator's permutation
+        j = bp.fetch("join", f)
+        j_o = o32.join(m_o, fp["model_pairs"], linear=True)
+        assert np.array_equal(j, j_o)
+        r = o32.picp_solve(OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4)), fp["model"],
+                           fp["cur_pts"], j_o, ITERS, 10000.0, False, trace=False)
+        assert np.abs(T[f] - r["T"]).max() < 1e-4 and int(st[f, 2]) == r["num_inliers"]
+        assert abs(st[f, 0] - r["chi_inliers"]) <= 1e-4 * r["chi_inliers"]
+        xyz, pairs, app = bp.fetch("tri_xyz", f), bp.fetch("tri_pairs", f), bp.fetch("tri_app", f)
+        xo, po, ao = o32.triangulate(fp["K"], T[f], m_o, fp["ref_pts"], fp["cur_pts"], fp["cur_app"])
+        assert np.array_equal(pairs, po) and np.array_equal(app, ao)
+        assert np.array_equal(xyz, xo)                                         # same pose in, same operations: bit for bit
+    bp.close()
+
+
+def test_batched_frames_reference_order_form(vo, ctx, o32):
+    """the same call with the solver stage in reference-order arithmetic (vo_picp_batch_set_form(3)): poses and
+    statistics of every frame equal ref32 bit for bit (12 frames x 6 000 points: the form is ~1 ms per 50k-round)"""
+    fps = [vo.synth.frame_pair(6000, seed=4100 + p, drop=0.0) for p in range(12)]
+    assert ctx.lib.vo_picp_batch_set_form(ctx.h, 3) == 0
+    try:
+        bp = vo.BatchPipeline(ctx, fps, n_iters=20)
+        bp.run()
+        ctx.synchronize()
+        T, st, c = bp.poses(), bp.stats(), bp.counts()
+        for f, fp in enumerate(fps):
+            j = bp.fetch("join", f)
+            r = o32.picp_solve_raw(OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4)), fp["model"],
+                                   fp["cur_pts"], j, 20, 10000.0, False)
+            assert np.array_equal(T[f], r["T"][-1]) and np.array_equal(st[f, :3], r["stats"][-1])
+        bp.close()
+    finally:
+        ctx.lib.vo_picp_batch_set_form(ctx.h, 0)
+
+
+def test_sequence_40x50k_is_bit_identical_to_ref32(vo, ctx, o32):
+    seq = vo.synth.sequence(seed=3000, n_frames=40, n_visible=N)
+    n = [len(f["pts"]) for f in seq["frames"]]
+    assert min(n) > 45000
+    sp = vo.SequencePipeline(ctx, seq, n_iters=100)
+    assert sp.lib.vo_picp_set_exact(sp.solver, 1) == 0
+    sp.run()
+    traj, counts = sp.trajectory(), sp.counts()
+    n_in = sp.stats()[2]
+    sp.close()
+    frames = [(f["pts"], f["app"]) for f in seq["frames"]]
+    res = P.run_sequence(frames, seq["K"], seq["rows"], seq["cols"], seq["z_near"], seq["z_far"], rounds=100, o=o32,
+                         X0=traj[1], kdtree=True, keep_map=False)
+    exp = np.array(res["stats"], dtype=int)
+    assert np.array_equal(counts[2:, 0], exp[:, 0]) and np.array_equal(counts[2:, 1], exp[:, 1])    # matches, joins
+    assert np.array_equal(counts[1:, 2], np.array(res["tri_counts"]))                              # triangulated points
+    assert n_in == exp[-1, 2] and exp[:, 1].min() > 35000
+    assert np.array_equal(np.array(traj), np.array(res["trajectory"], dtype=np.float32))           # every pose, bit for bit
+    # and the default (fast) arithmetic stays within rounding of it
+    sp = vo.SequencePipeline(ctx, seq, n_iters=100)
+    sp.run()
+    t_fast, c_fast = sp.trajectory(), sp.counts()
+    sp.close()
+    assert np.array_equal(c_fast[:, 0], counts[:, 0])                       # matches do not depend on the pose
+    # joined pairs follow the previous frame's triangulation, whose cheirality test sees a pose that differs in the
+    # last bits: a borderline point may flip
+    assert np.abs(c_fast[:, 1:] - counts[:, 1:]).max() <= 8
+    assert np.abs(np.array(t_fast) - np.array(traj)).max() < 5e-4

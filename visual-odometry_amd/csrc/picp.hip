@@ -75,6 +75,10 @@ __device__ __forceinline__ float block_reduce_acc(float acc[NACC], float* s_red)
 // instead of ~180 for DPP + LDS.   s_acc: 256*36 floats, s_part: 8*32 floats.
 // Returns the sum of slot tid in threads 0..31 (fixed order).
 constexpr int ACC_STRIDE = 36;
+constexpr int PICP_PARTS = PICP_BLOCK / 32;          // 32-row parts of the first reduction stage
+constexpr int PICP_GROUPS = PICP_BLOCK / 8;          // row groups of the partial-row fetch (8 threads per 128-B row)
+constexpr int STG_STRIDE = PICP_GROUPS + 4;          // floats per slot of the transposed staging (conflict-free 16-B reads)
+constexpr int PICP_SACC = PICP_BLOCK * ACC_STRIDE > 32 * STG_STRIDE ? PICP_BLOCK * ACC_STRIDE : 32 * STG_STRIDE;
 __device__ __forceinline__ float block_reduce_lds256(const float acc[NACC], float* s_acc, float* s_part) {
   const int tid = threadIdx.x;
   float4* row = reinterpret_cast<float4*>(s_acc + tid * ACC_STRIDE);
@@ -98,7 +102,7 @@ __device__ __forceinline__ float block_reduce_lds256(const float acc[NACC], floa
   float out = 0.f;
   if (tid < 32) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) out += s_part[g * 32 + tid];
+    for (int g = 0; g < PICP_PARTS; ++g) out += s_part[g * 32 + tid];
   }
   return out;
 }
@@ -237,8 +241,8 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     pk.base += p * 5 * rb.cap;
     partials += p * rb.partials_stride;
   }
-  __shared__ __attribute__((aligned(16))) float s_acc[PICP_BLOCK * ACC_STRIDE];   // also the staging of the partial rows
-  __shared__ float s_part[8 * 32];
+  __shared__ __attribute__((aligned(16))) float s_acc[PICP_SACC];   // also the staging of the partial rows
+  __shared__ float s_part[PICP_PARTS * 32];
   __shared__ float s_sys[PICP_BLOCK / 64][48];
   __shared__ float s_stat[4];
   const int tid = threadIdx.x;
@@ -266,12 +270,14 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     const int nb_pad = (nb + 255) & ~255;
     const float* prev = partials + (size_t)((it - 1) & 1) * nb_pad * PICP_PSTRIDE;
     const float4* src = reinterpret_cast<const float4*>(prev + (size_t)(tid >> 3) * PICP_PSTRIDE) + (tid & 7);
+    constexpr int NJ = 256 / PICP_GROUPS;              // loads per thread and pass of 256 rows
     for (int b0 = 0; b0 < nb; b0 += 256) {
-      float4 r[8];
+      float4 r[NJ];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = src[(size_t)(b0 + 32 * j) * (PICP_PSTRIDE / 4)];
+      for (int j = 0; j < NJ; ++j)
+        r[j] = src[(size_t)(b0 + PICP_GROUPS * j) * (PICP_PSTRIDE / 4)];      // (rows >= nb read as zero)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { psum.x += r[j].x; psum.y += r[j].y; psum.z += r[j].z; psum.w += r[j].w; }
+      for (int j = 0; j < NJ; ++j) { psum.x += r[j].x; psum.y += r[j].y; psum.z += r[j].z; psum.w += r[j].w; }
     }
   }
 
@@ -304,10 +310,10 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     // values are eight conflict-free 16-B reads.
     {
       const int g32 = tid >> 3, q4 = (tid & 7) * 4;
-      s_acc[(q4 + 0) * ACC_STRIDE + g32] = psum.x;
-      s_acc[(q4 + 1) * ACC_STRIDE + g32] = psum.y;
-      s_acc[(q4 + 2) * ACC_STRIDE + g32] = psum.z;
-      s_acc[(q4 + 3) * ACC_STRIDE + g32] = psum.w;
+      s_acc[(q4 + 0) * STG_STRIDE + g32] = psum.x;
+      s_acc[(q4 + 1) * STG_STRIDE + g32] = psum.y;
+      s_acc[(q4 + 2) * STG_STRIDE + g32] = psum.z;
+      s_acc[(q4 + 3) * STG_STRIDE + g32] = psum.w;
     }
     __syncthreads();
     // (4) Every wave finishes the sums it needs and runs the (uniform) 6x6 solve on its own:
@@ -328,10 +334,10 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
       } else {
         slot = 21 + (lane - 36);                             // 21..26 b, 27..29 chi_in, chi_out, n_in
       }
-      const float4* row = reinterpret_cast<const float4*>(s_acc + slot * ACC_STRIDE);
+      const float4* row = reinterpret_cast<const float4*>(s_acc + slot * STG_STRIDE);
       float tsum = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { const float4 t4 = row[k]; tsum += t4.x; tsum += t4.y; tsum += t4.z; tsum += t4.w; }
+      for (int k = 0; k < PICP_GROUPS / 4; ++k) { const float4 t4 = row[k]; tsum += t4.x; tsum += t4.y; tsum += t4.z; tsum += t4.w; }
       if (lane < 36) {
         const float hv = diag ? tsum + 1.f * damping : tsum;
         sys[lane] = hv;

@@ -10,7 +10,10 @@
 namespace vo {
 
 // ---- PICP ------------------------------------------------------------------
-constexpr int PICP_BLOCK = 256;       // threads per workgroup of the single-problem kernels
+#ifndef VO_PICP_BLOCK
+#define VO_PICP_BLOCK 256
+#endif
+constexpr int PICP_BLOCK = VO_PICP_BLOCK;   // threads per workgroup of the single-problem kernels (256, 512 or 1024: DESIGN.md section 4.1)
 constexpr int PICP_PSTRIDE = 32;      // floats per workgroup partial (NACC padded)
 constexpr int PICP_MAX_BLOCKS = 2048; // grid cap (grid-stride beyond it)
 constexpr int PICP_BATCH_BLOCK = 768;   // 12 waves: 3 per SIMD, 168 VGPRs each (room for load double-buffering)
