@@ -72,4 +72,4 @@ def test_frame_through_cpp_facade(tmp_path, vo, o32):
     assert abs(chi_in - ro["chi_inliers"]) <= 1e-3 * max(1.0, ro["chi_inliers"]) and chi_out == ro["chi_outliers"] == 0
     xo, po, ao = o32.triangulate(fp["K"], T, m_o, fp["ref_pts"], fp["cur_pts"], fp["cur_app"])
     assert np.array_equal(tri_pairs, po) and np.array_equal(tri_app, ao)
-    assert np.all(np.abs(tri - xo) <= 1e-4 * np.maximum(1, np.abs(xo)))
+    assert np.array_equal(tri, xo)                           # same pose in: bit for bit

@@ -128,7 +128,7 @@ def test_frame_pipeline_device_resident(vo, ctx, o32):
     xyz, pairs, app = pipe.fetch("tri_xyz"), pipe.fetch("tri_pairs"), pipe.fetch("tri_app")
     xo, po, ao = o32.triangulate(fp["K"], T, m_o, fp["ref_pts"], fp["cur_pts"], fp["cur_app"])
     assert np.array_equal(pairs, po) and np.array_equal(app, ao)
-    assert np.all(np.abs(xyz - xo) <= 1e-4 * np.maximum(1, np.abs(xo)))
+    assert np.array_equal(xyz, xo)                          # same pose in, same operations: bit for bit
     pipe.close()
 
 
@@ -181,7 +181,7 @@ def test_batched_frames_equal_single_frames(vo, o32, n, F):
         assert np.abs(poses[i] - r["T"]).max() < 1e-4 and int(stats[i, 2]) == r["num_inliers"]
         xo, po, ao = o32.triangulate(f["K"], poses[i], m_o, f["ref_pts"], f["cur_pts"], f["cur_app"])
         assert np.array_equal(bp.fetch("tri_pairs", i), po) and np.array_equal(bp.fetch("tri_app", i), ao)
-        assert np.all(np.abs(bp.fetch("tri_xyz", i) - xo) <= 1e-4 * np.maximum(1, np.abs(xo)))
+        assert np.array_equal(bp.fetch("tri_xyz", i), xo)    # same pose in: bit for bit
     bp.close(); c.close()
 
 
@@ -226,7 +226,6 @@ def test_handles_do_not_leak_device_memory():
     assert [k for k, _ in rows] == ["ctx", "event", "match", "frame", "capture", "all"], r.stdout
     for kind, vals in rows:
         drift = [float(x) for x in vals.split()]
-        # a handle that is not released grows the figure on EVERY cycle; the HIP runtime's own pools move it in a
-        # step or two (observed: +8 / +50 MiB once, then flat)
-        steps = sum(1 for a, b in zip(drift, drift[1:]) if b > a + 0.5)
-        assert len(drift) == 10 and steps <= 3 and max(drift) < 256.0, (kind, drift)
+        # a handle that is not released grows the figure on EVERY cycle: after two cycles (the HIP runtime's own pools
+        # may still settle in those) the figure must be flat, and it must stay small (measured: 0.00 throughout)
+        assert len(drift) == 10 and max(drift[2:]) - min(drift[2:]) < 0.5 and max(drift) < 64.0, (kind, drift)

@@ -64,7 +64,7 @@ def test_golden_frame_pipeline(vo, ctx, name):
     xyz, pairs, app = vo.triangulate_points(g["K"], T, m, g["ref_pts"], g["cur_pts"], g["cur_app"], ctx=ctx)
     assert np.array_equal(pairs, g["exp_tri_pairs"])
     assert np.array_equal(app, g["exp_tri_app"])
-    assert np.all(np.abs(xyz - g["exp_tri_xyz"]) <= 1e-4 * np.maximum(1, np.abs(g["exp_tri_xyz"])))
+    assert np.array_equal(xyz, g["exp_tri_xyz"])            # same pose in, reference operation order, no FMA: bit-exact
     xt = vo.transform_points(T, g["model"], ctx=ctx)
     assert np.array_equal(xt, g["exp_transform"])           # same operation order, no FMA: bit-exact
 
