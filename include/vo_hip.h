@@ -174,7 +174,9 @@ int vo_picp_get_system(vo_picp *s, float H[36], float b[6]);
  * points, points, pairs) and n_pairs[p] pairs.  All share rows/cols/z/K/thr.
  * d_T0: n_problems initial poses (16 floats each) or NULL for identity;
  * d_T_out: n_problems final poses; d_stats_out (may be NULL): per problem
- * {chi_inliers, chi_outliers, (float)num_inliers, 0}. */
+ * {chi_inliers, chi_outliers, (float)num_inliers, (float)n_bad} -- n_bad = pairs of the problem whose
+ * index lies outside its point arrays: they are dropped (the single-problem entry points report the same
+ * condition as VO_ERR_BAD_INDEX from their getters). */
 /* Two forms, same results up to the summation order of H and b: one workgroup per problem with all rounds
  * inside one launch (many problems: HBM-bound streaming), or one launch per round with many workgroups per
  * problem (a few problems: the single-problem kernels with the problem as a grid dimension; 4x faster at 4
@@ -298,7 +300,7 @@ typedef struct vo_frame_batch {
   int32_t *joined;                  /* [n_frames][q][2]  (cur index, model index) */
   float *model_moved;               /* [n_frames][n_model][3]  X_prev * model (also the solver's world points) */
   float *poses;                     /* [n_frames][16] */
-  float *stats;                     /* [n_frames][4]: chi_inliers, chi_outliers, num_inliers, 0 (may be NULL) */
+  float *stats;                     /* [n_frames][4]: chi_inliers, chi_outliers, num_inliers, bad-index pairs dropped (may be NULL) */
   float *tri_xyz;                   /* [n_frames][q][3] */
   int32_t *tri_pairs;               /* [n_frames][q][2]  (cur index, slot) */
   float *tri_app;                   /* [n_frames][q][10] or NULL */

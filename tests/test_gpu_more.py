@@ -229,3 +229,38 @@ def test_handles_do_not_leak_device_memory():
         # a handle that is not released grows the figure on EVERY cycle: after two cycles (the HIP runtime's own pools
         # may still settle in those) the figure must be flat, and it must stay small (measured: 0.00 throughout)
         assert len(drift) == 10 and max(drift[2:]) - min(drift[2:]) < 0.5 and max(drift) < 64.0, (kind, drift)
+
+
+@pytest.mark.parametrize("form", [1, 2, 3])
+def test_batched_solver_reports_bad_indices(vo, ctx, o32, form):
+    """a pair whose index lies outside the point arrays is dropped AND counted (stats_out[4p + 3]) by every form of
+    the batched solver -- the single-problem entry points report the same input as VO_ERR_BAD_INDEX"""
+    P, n = 3, 1500
+    fps = [vo.synth.frame_pair(n, seed=5100 + p) for p in range(P)]
+    pairs = [_corr(f).copy() for f in fps]
+    pairs[1][[5, 700, 1400], 1] = [n + 7, -3, 2 ** 30]       # three bad model indices in problem 1
+    pairs[2][11, 0] = n                                       # one bad measurement index in problem 2
+    world = np.stack([f["model"] for f in fps]); meas = np.stack([f["cur_pts"] for f in fps])
+    pbuf = np.stack(pairs).astype(np.int32); npairs = np.full(P, n, np.int32)
+    d = [ctx.to_device(a) for a in (world, meas, pbuf, npairs)]
+    d_T = ctx.alloc(P * 64); d_stats = ctx.alloc(P * 16)
+    K = np.ascontiguousarray(fps[0]["K"].T).ravel()
+    lib = ctx.lib
+    assert lib.vo_picp_batch_set_form(ctx.h, form) == 0
+    try:
+        rc = lib.vo_picp_solve_batch_dev(ctx.h, P, 480, 640, 0, 10, K.ctypes.data_as(C.c_void_p), C.c_float(10000.0), 0,
+                                         C.c_void_p(d[0]), C.c_size_t(n), C.c_void_p(d[1]), C.c_size_t(n), C.c_void_p(d[2]),
+                                         C.c_size_t(n), C.c_void_p(d[3]), None, 8, C.c_void_p(d_T), C.c_void_p(d_stats))
+        assert rc == 0, lib.vo_last_error()
+        T = np.zeros((P, 16), np.float32); st = np.zeros((P, 4), np.float32)
+        ctx.d2h(T, d_T); ctx.d2h(st, d_stats)
+    finally:
+        lib.vo_picp_batch_set_form(ctx.h, 0)
+        for x in d + [d_T, d_stats]:
+            ctx.free(x)
+    assert st[:, 3].tolist() == [0.0, 3.0, 1.0]
+    for p in range(P):
+        ok = (pairs[p][:, 0] >= 0) & (pairs[p][:, 0] < n) & (pairs[p][:, 1] >= 0) & (pairs[p][:, 1] < n)
+        r = o32.picp_solve(OCam(480, 640, 0, 10, fps[p]["K"], np.eye(4)), fps[p]["model"], fps[p]["cur_pts"], pairs[p][ok],
+                           8, 10000.0, False, trace=False)
+        assert int(st[p, 2]) == r["num_inliers"] and np.abs(T[p].reshape(4, 4).T - r["T"]).max() < 1e-4

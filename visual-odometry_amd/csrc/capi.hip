@@ -76,6 +76,7 @@ struct vo_ctx {
   DevBuf out[3];
   DevBuf counts;      // small device ints
   DevBuf batch_pack;  // packed correspondences of the batched solver
+  DevBuf batch_bad;   // its per-problem bad-index counters
   DevBuf batch_states, batch_partials;   // launch-per-round form of the batched solver: per-problem state + partial rows
   PicpParams batch_params_host{};        //   its parameter block as last uploaded, and where
   const PicpParams* batch_params_dev = nullptr;
@@ -165,7 +166,7 @@ int vo_ctx_destroy(vo_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   c->scratch.release(); c->best.release(); c->table.release(); c->counts.release();
-  c->batch_pack.release(); c->prune_ws.release(); c->batch_states.release(); c->batch_partials.release();
+  c->batch_pack.release(); c->batch_bad.release(); c->prune_ws.release(); c->batch_states.release(); c->batch_partials.release();
   for (auto& b : c->in) b.release();
   for (auto& b : c->out) b.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -750,6 +751,12 @@ int vo_picp_solve_batch_dev(vo_ctx* c, int n_problems, int rows, int cols, int z
   a.n_world = (int)world_stride; a.n_meas = (int)meas_stride;
   VO_HIP_CHECK(c->batch_pack.ensure(sizeof(float) * 5 * a.cap * (size_t)n_problems, c->stream));
   a.packed = c->batch_pack.as<float>();
+  a.n_bad = nullptr;
+  if (d_stats_out) {
+    VO_HIP_CHECK(c->batch_bad.ensure(sizeof(int) * (size_t)n_problems, c->stream));
+    VO_HIP_CHECK(hipMemsetAsync(c->batch_bad.p, 0, sizeof(int) * (size_t)n_problems, c->stream));
+    a.n_bad = c->batch_bad.as<int>();
+  }
   a.states = nullptr; a.partials = nullptr; a.params = nullptr; a.grid = 0; a.exact = 0;
   static const int env_form = [] { const char* e = getenv("VO_PICP_BATCH_FORM"); return e ? atoi(e) : 0; }();
   const int form = c->batch_form ? c->batch_form : env_form;

@@ -506,9 +506,17 @@ __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
     if (m >= 0 && m < a.n_meas && w >= 0 && w < a.n_world) {
       x = world[3 * (size_t)w]; y = world[3 * (size_t)w + 1]; z = world[3 * (size_t)w + 2];
       u = meas[2 * (size_t)m]; v = meas[2 * (size_t)m + 1];
+    } else if (a.n_bad) {
+      atomicAdd(&a.n_bad[p], 1);        // dropped (NaN marker) and counted: reported in stats_out[4p + 3]
     }
     dst[i] = x; dst[a.cap + i] = y; dst[2 * a.cap + i] = z; dst[3 * a.cap + i] = u; dst[4 * a.cap + i] = v;
   }
+}
+
+// after the solver: the number of correspondences dropped for an index outside the point arrays, per problem
+__global__ void picp_batch_bad_kernel(BatchArgs a) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < a.n_problems) a.stats_out[4 * (size_t)p + 3] = (float)a.n_bad[p];
 }
 
 // zero rounds in the launch-per-round form: T_out = T0 (or identity), statistics zero
@@ -819,12 +827,23 @@ bool picp_batch_prefers_rounds(int n_problems, size_t cap, int n_iters, int n_cu
   return t_rounds < t_onewg;
 }
 
+static hipError_t launch_picp_batch_solve(hipStream_t st, const BatchArgs& a);
+
 hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a) {
   if (a.n_problems <= 0) return hipSuccess;
   int gx = (int)((a.cap + 255) / 256);
   if (gx > 64) gx = 64;
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(picp_batch_pack_kernel, dim3(gx, a.n_problems), dim3(256), 0, st, a);
+  hipError_t e = launch_picp_batch_solve(st, a);
+  if (e == hipSuccess && a.stats_out && a.n_bad) {
+    hipLaunchKernelGGL(picp_batch_bad_kernel, dim3((a.n_problems + 255) / 256), dim3(256), 0, st, a);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+static hipError_t launch_picp_batch_solve(hipStream_t st, const BatchArgs& a) {
   if (a.exact) return launch_picp_exact_batch(st, a);
   const bool ph = is_pinhole(a.cam.K), keep = a.keep_outliers != 0;
   if (a.states) {

@@ -92,6 +92,7 @@ struct BatchArgs {
   float* partials;     // n_problems x 2 x round_up(grid,256) x PICP_PSTRIDE floats, zero-padded rows
   const PicpParams* params;   // device copy of (cam, thr, damping, keep_outliers); n_corr unused
   int grid;            // workgroups per problem
+  int* n_bad;          // n_problems counters (zeroed by the caller): correspondences dropped for a bad index, or null
   int exact;           // reference-order form (picp_exact_kernel): one workgroup per problem, sequential sums
 };
 hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a);
