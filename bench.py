@@ -218,21 +218,37 @@ def main():
         dist.destroy_process_group()
 
 
+def _pmc_file():
+    """the newest committed PMC summary (profiles/rNN_pmc_fetch_write*.json)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_fetch_write*.json")))
+    return files[-1] if files else None
+
+
 def _pmc_traffic(kernel, grid_threads):
-    """HBM bytes per launch from the committed PMC summary (profiles/r01_pmc_fetch_write_v3.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very script), for the launch
-    geometry `grid_threads`.  Returns (bytes, note) or (None, reason)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_v3.json")
+    """HBM bytes per launch from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this very script, tools/collect_profiles.sh), for the launch geometry `grid_threads`.  Returns (bytes, note) or
+    (None, reason)."""
+    path = _pmc_file()
     try:
         k = json.load(open(path))["kernels"][kernel]
         g = k["by_grid"][str(grid_threads)]
         fetch_kb, write_kb = g["FETCH_SIZE_KB_max"], g["WRITE_SIZE_KB_max"]
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, TypeError):
         return None, "no committed PMC summary for this kernel and launch geometry"
     wide = k.get("wide_16B_loads", False)
     b = (2.0 * fetch_kb if wide else fetch_kb) * 1024.0 + write_kb * 1024.0
     return b, ("FETCH_SIZE x2 (gfx950 counts half of 16-B/lane coalesced reads) + WRITE_SIZE" if wide else
                "FETCH_SIZE + WRITE_SIZE as reported (4-B/lane loads: uncalibrated width)") + ", from " + os.path.basename(path)
+
+
+def _pmc_frames_call():
+    """HBM bytes of one whole vo_frames_batch_dev call (200 x 50k), summed over its kernels, from the same summary"""
+    try:
+        c = json.load(open(_pmc_file()))["batched_frames_call"]
+        return c["bytes_corrected"], c["note"] + ", from " + os.path.basename(_pmc_file())
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, "no committed PMC summary of the batched call"
 
 
 def _chk(lib, rc):
@@ -342,6 +358,8 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
             "seeds": f"4000+p, p = {frames * rank}..{frames * rank + frames - 1} on this rank",
             "roofline": {"bound": "hbm", "scope": "whole frame (all stages of one vo_frames_batch_dev call)", "achieved": gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": _pmc_frames_call()[0] if (frames, args.points, args.iters) == (200, 50000, 50) else None,
+                         "traffic_note": _pmc_frames_call()[1],
                          "algorithmic_bytes_per_call": alg,
                          "note": "SURVEY 8(d) frame bytes (match 4.4 + join 1.2 + transform 1.2 + gather 2.4 + rounds x 1.0 + "
                                  "triangulate-v3 6.2 MB at 50k) x frames / wall time of the call, per GPU"},

@@ -4,6 +4,7 @@
 #include "context.hpp"
 #include "epipolar.hpp"
 #include "evaluation.hpp"
+#include "kdtree.hpp"
 #include "files.hpp"
 #include "picp_solver.hpp"
 #include "point_cloud.hpp"

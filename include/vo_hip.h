@@ -215,13 +215,39 @@ int vo_match_appearances_dev(vo_ctx *ctx, const float *d_a1, int n1, const float
  * in `indices`; *n_total = hits found.  If n_total > capacity the call fails with VO_ERR_INVALID_ARG and
  * offsets/n_total tell the caller how much room to bring.  Unlike the matcher the roles are explicit: the
  * first set is searched whatever the sizes.  The approximate modes of the reference (fastSearch,
- * bestMatchFast: descend one side of each PCA split) depend on its tree and are not reproduced; their
+ * bestMatchFast: descend one side of each PCA split) depend on its tree: vo_kdtree_* below; their
  * answers are subsets of this call's / of vo_match_appearances'. */
 int vo_radius_search(vo_ctx *ctx, const float *tree_app, int n_tree, const float *query_app, int n_q,
                      float radius, int32_t *offsets, int32_t *indices, int capacity, int *n_total);
 /* device form: d_offsets[n_q + 1]; d_offsets[n_q] = hits found (also when > capacity: the surplus is dropped) */
 int vo_radius_search_dev(vo_ctx *ctx, const float *d_tree_app, int n_tree, const float *d_query_app,
                          int n_q, float radius, int32_t *d_offsets, int32_t *d_indices, int capacity);
+
+/* ---- TreeNode_ in its approximate modes (eigen_kdtree.h:18-52,75-85) ------------------------ */
+/* bestMatchFast and fastSearch descend ONE side of every PCA split plane and brute-force the leaf they reach: their
+ * answers depend on the tree (split directions, order of the points inside a leaf), so the tree is a handle.
+ * vo_kdtree_create builds it on the host like the TreeNode_ constructor (:18-38; mean/covariance in float in array
+ * order, eigen_covariance.h:5-43 with a double Jacobi for the eigen-solver, the two-pointer partition of split.h:8-34,
+ * recursion while a node holds >= max_points_in_leaf points; a node whose points all fall on one side becomes a leaf --
+ * the reference recurses forever there) and uploads it; queries run on the GPU, one lane per query.  points: host
+ * float[10n] (the reference's 11-vectors carry the index in slot 0; here the index is implicit).  Neither mode is used
+ * by an executable of the reference; the exact modes are vo_match_appearances (bestMatchFull) and vo_radius_search
+ * (fullSearch), whose answers do not depend on any tree. */
+typedef struct vo_kdtree vo_kdtree;
+int vo_kdtree_create(vo_ctx *ctx, const float *points_app, int n, int max_points_in_leaf, vo_kdtree **out);
+int vo_kdtree_destroy(vo_kdtree *tree);       /* before the context it was made on */
+int vo_kdtree_info(vo_kdtree *tree, int *n_points, int *n_nodes, int *n_leaves);
+/* bestMatchFast (:75-85) for every query: out_index[i] = index (in points_app) of the closest point OF THE QUERY'S LEAF
+ * with squared distance < radius*radius (strict; the first minimum in leaf order), or -1 */
+int vo_kdtree_best_match_fast(vo_kdtree *tree, const float *query_app, int n_q, float radius, int32_t *out_index);
+int vo_kdtree_best_match_fast_dev(vo_kdtree *tree, const float *d_query_app, int n_q, float radius, int32_t *d_out_index);
+/* fastSearch (:40-52) for every query, CSR like vo_radius_search: query i owns indices[offsets[i] .. offsets[i+1]), the
+ * points of its leaf within the radius IN LEAF ORDER (the order bruteForceSearch pushes them, brute_force_search.h:3-20);
+ * n_total > capacity: VO_ERR_INVALID_ARG with offsets / n_total filled in */
+int vo_kdtree_fast_search(vo_kdtree *tree, const float *query_app, int n_q, float radius, int32_t *offsets,
+                          int32_t *indices, int capacity, int *n_total);
+int vo_kdtree_fast_search_dev(vo_kdtree *tree, const float *d_query_app, int n_q, float radius, int32_t *d_offsets,
+                              int32_t *d_indices, int capacity);
 
 /* ---- extract_correspondences_world (vo_complete.cpp:52-66) ------------- */
 /* For each image pair (ref,cur) in order, the FIRST world pair (ref',w) with

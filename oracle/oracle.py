@@ -275,6 +275,26 @@ class Oracle:
             cap = total
         return [np.sort(idx[off[i]:off[i + 1]]) for i in range(len(q))]
 
+    def kdtree_fast(self, tree_app, query_app, radius=0.1, max_leaf=20):
+        """The approximate modes of the reference's tree (float32): (bestMatchFast index per query or -1,
+        fastSearch lists per query IN LEAF ORDER, number of tree nodes)."""
+        t = np.ascontiguousarray(tree_app, dtype=np.float32).reshape(-1, 10)
+        q = np.ascontiguousarray(query_app, dtype=np.float32).reshape(-1, 10)
+        best = np.zeros(max(len(q), 1), dtype=np.int32)
+        off = np.zeros(len(q) + 1, dtype=np.int32)
+        n_nodes = C.c_int()
+        f = self.L.vo32_kdtree_fast
+        f.restype = C.c_int
+        cap = max(4 * len(q), 16)
+        while True:
+            idx = np.zeros(cap, dtype=np.int32)
+            total = f(self._p(t), C.c_int(len(t)), self._p(q), C.c_int(len(q)), C.c_float(radius), C.c_int(max_leaf),
+                      self._p(best), self._p(off), self._p(idx), C.c_int(cap), C.byref(n_nodes))
+            if total <= cap:
+                break
+            cap = total
+        return best[:len(q)].copy(), [idx[off[i]:off[i + 1]].copy() for i in range(len(q))], n_nodes.value
+
     def join(self, img_pairs, world_pairs, linear=False):
         a = self._pairs(img_pairs)
         b = self._pairs(world_pairs)

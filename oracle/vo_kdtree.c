@@ -228,3 +228,47 @@ int vo32_radius_search(const float *tree_app, int nt, const float *query_app, in
   free(pts);
   return total;
 }
+
+/* ---- the approximate modes: bestMatchFast (eigen_kdtree.h:75-85) and fastSearch (:40-52) ---- */
+/* Both descend one side of every split plane (distance < 0 -> left) and brute-force the leaf.  Their answers depend on
+ * the tree: on the split directions (here: the Jacobi stand-in for Eigen's eigen-solver) and on the order split()
+ * leaves the points in.  out_index[i] = stored index of the best leaf point within the radius, or -1. */
+static const KdNode *leaf_of(const KdNode *n, const float *query) {
+  while (n->left || n->right) n = plane_dist(query, n->mean, n->normal) < 0.f ? n->left : n->right;   /* :47-51, :80-84 */
+  return n;
+}
+
+int vo32_kdtree_fast(const float *tree_app, int nt, const float *query_app, int nq, float radius, int max_leaf,
+                     int *out_best, int *offsets, int *indices, int cap, int *n_nodes_out) {
+  float *pts = (float *)malloc(sizeof(float) * DIM * (size_t)(nt > 0 ? nt : 1));
+  for (int i = 0; i < nt; ++i) { pts[(size_t)i * DIM] = (float)i; memcpy(pts + (size_t)i * DIM + 1, tree_app + (size_t)i * AD, sizeof(float) * AD); }
+  KdNode *root = build(pts, 0, nt, max_leaf);
+  int total = 0;
+  float q[DIM];
+  for (int i = 0; i < nq; ++i) {
+    q[0] = (float)i;
+    memcpy(q + 1, query_app + (size_t)i * AD, sizeof(float) * AD);
+    const KdNode *lf = leaf_of(root, q);
+    if (out_best) {
+      float *m = leaf_best(pts, lf->begin, lf->end, q, radius);                  /* bestMatchFast */
+      out_best[i] = m ? (int)m[0] : -1;
+    }
+    if (offsets) {                                                               /* fastSearch */
+      offsets[i] = total;
+      const float sq = radius * radius;
+      for (int j = lf->begin; j < lf->end; ++j)
+        if (sqdist(pts + (size_t)j * DIM, q) < sq) { if (total < cap) indices[total] = (int)pts[(size_t)j * DIM]; ++total; }
+    }
+  }
+  if (offsets) offsets[nq] = total;
+  if (n_nodes_out) {                      /* node count, for a structural comparison with the product's tree */
+    int count = 0;
+    const KdNode *stack[256]; int sp = 0;
+    stack[sp++] = root;
+    while (sp) { const KdNode *n = stack[--sp]; ++count; if (n->left) stack[sp++] = n->left; if (n->right) stack[sp++] = n->right; }
+    *n_nodes_out = count;
+  }
+  free_tree(root);
+  free(pts);
+  return total;
+}

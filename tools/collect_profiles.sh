@@ -1,15 +1,18 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel trace + separate PMC passes of bench.py.
-# Output: gpurun_out/prof_<tag>/{stats,FETCH_SIZE,WRITE_SIZE}/...
+# Output: gpurun_out/prof_<tag>/{stats,FETCH_SIZE,WRITE_SIZE}/...   then: python tools/summarize_pmc.py gpurun_out/prof_<tag> profiles/<tag>
+# The config-4 pairs are generated in-process (--gen-workers 1: no forked helpers under the profiler).
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 50 --warmup 5 --cpu-seconds 0 > $OUT/stats.log 2>&1
+echo "stats pass"; date
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 50 --warmup 5 --cpu-seconds 0 --strong-pairs 0 --gen-workers 1 > $OUT/stats.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-seconds 0 --frame-steps 3 --seq-frames 6 --seq-points 5000 > $OUT/$C.log 2>&1
+  echo "$C pass"; date
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-seconds 0 --frame-steps 3 --seq-frames 6 --seq-points 5000 --strong-pairs 0 --gen-workers 1 > $OUT/$C.log 2>&1
 done
 cd $R
-echo done; ls $OUT
+echo done; date; ls $OUT

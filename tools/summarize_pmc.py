@@ -26,13 +26,36 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
         d[C + "_KB_max"] = max(x[0] for x in v)     # bench.py also launches the batch kernel with 0 rounds (gather-pass timing)
         d["launches_" + C] = len(v)
         d["dur_us_under_pmc"] = sum(x[1] for x in v) / len(v) / 1e3
-json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 5 "
-                      "--warmup 1 --cpu-seconds 0 --frame-steps 3 --seq-frames 6 --seq-points 5000   (one pass per counter; tools/collect_profiles.sh)",
+# one whole vo_frames_batch_dev call (config 4's per-GPU share): the kernels from cell_bounds_kernel over 200 frames to
+# the tri_scatter_kernel that ends the call, summed (last complete call of the pass)
+call = {}
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"{src}/{C}/*/*counter_collection.csv")[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
+    cur, last = None, None
+    for r in rows:
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if name == "vo::cell_bounds_kernel" and int(r["Grid_Size"]) == 200 * 1024:
+            cur = collections.OrderedDict()
+        if cur is not None and name.startswith("vo::"):
+            cur[name] = cur.get(name, 0.0) + float(r["Counter_Value"])
+            if name == "vo::tri_scatter_kernel":
+                last, cur = cur, None
+    if last:
+        call[C + "_KB_by_kernel"] = last
+        call[C + "_KB"] = sum(last.values())
+if call:
+    wide_fetch = call.get("FETCH_SIZE_KB_by_kernel", {}).get("vo::picp_batch_kernel<true, false>", 0.0)
+    call["bytes_corrected"] = (call.get("FETCH_SIZE_KB", 0.0) + wide_fetch + call.get("WRITE_SIZE_KB", 0.0)) * 1024.0
+    call["note"] = ("sum over the kernels of one vo_frames_batch_dev call (200 frames x 50k); FETCH_SIZE doubled for the "
+                    "batched solver (16-B/lane streaming loads), counted as reported for the rest (mixed widths: uncalibrated)")
+json.dump({"batched_frames_call": call, "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 5 "
+                      "--warmup 1 --cpu-seconds 0 --frame-steps 3 --seq-frames 6 --seq-points 5000 --strong-pairs 0 --gen-workers 1   (one pass per counter; tools/collect_profiles.sh)",
            "units": "FETCH_SIZE / WRITE_SIZE are KB.  gfx950: FETCH_SIZE counts exactly half the bytes of wide (16 B/lane) "
                     "coalesced streaming reads (MI355X_MICROARCH.md, HBM) -> doubled where wide_16B_loads is true; other "
                     "access widths are uncalibrated and reported as counted",
-           "kernels": out}, open(dst + "_pmc_fetch_write_v3.json", "w"), indent=1, sort_keys=True)
-shutil.copy(glob.glob(f"{src}/stats/*/*kernel_stats.csv")[0], dst + "_bench_kernel_stats_v3.csv")
+           "kernels": out}, open(dst + "_pmc_fetch_write.json", "w"), indent=1, sort_keys=True)
+shutil.copy(glob.glob(f"{src}/stats/*/*kernel_stats.csv")[0], dst + "_bench_kernel_stats.csv")
 for k in ("vo::picp_batch_kernel<true, false>", "vo::picp_round_kernel<true, false, true, false>"):
     if k in out:
         print(k, json.dumps(out[k]))

@@ -11,6 +11,7 @@ from .api import (  # noqa: F401
     Camera,
     Context,
     Event,
+    KdTree,
     PICPSolver,
     VoError,
     compute_correspondences_images,

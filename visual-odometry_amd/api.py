@@ -383,3 +383,57 @@ def radius_search(tree_appearances, query_appearances, radius=0.1, ctx: Context 
         _chk(rc)
         break
     return [np.sort(idx[offsets[i]:offsets[i + 1]]) for i in range(len(q))]
+
+
+class KdTree:
+    """The reference's PCA kd-tree in its approximate modes (eigen_kdtree.h:18-52,75-85; vo_kdtree_*): built on the
+    host like the TreeNode_ constructor, queried on the GPU.  bestMatchFull / fullSearch are tree-independent:
+    compute_correspondences_images / radius_search."""
+
+    def __init__(self, points_appearances, max_points_in_leaf=20, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        p = _f32(points_appearances, (-1, 10))
+        h = C.c_void_p()
+        _chk(self.lib.vo_kdtree_create(self.ctx.h, _ptr(p), C.c_int(len(p)), C.c_int(max_points_in_leaf), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vo_kdtree_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        n, nodes, leaves = C.c_int(), C.c_int(), C.c_int()
+        _chk(self.lib.vo_kdtree_info(self.h, C.byref(n), C.byref(nodes), C.byref(leaves)))
+        return n.value, nodes.value, leaves.value
+
+    def bestMatchFast(self, queries, norm=0.1):
+        """index of the best point of each query's leaf within `norm`, or -1 (eigen_kdtree.h:75-85)"""
+        q = _f32(queries, (-1, 10))
+        out = np.full(max(len(q), 1), -1, dtype=np.int32)
+        _chk(self.lib.vo_kdtree_best_match_fast(self.h, _ptr(q), C.c_int(len(q)), C.c_float(norm), _ptr(out)))
+        return out[:len(q)].copy()
+
+    def fastSearch(self, queries, norm=0.1):
+        """per query the points of its leaf within `norm`, in leaf order (eigen_kdtree.h:40-52)"""
+        q = _f32(queries, (-1, 10))
+        offsets = np.zeros(len(q) + 1, dtype=np.int32)
+        cap = max(2 * len(q), 16)
+        while True:
+            idx = np.zeros(cap, dtype=np.int32)
+            n_total = C.c_int()
+            rc = self.lib.vo_kdtree_fast_search(self.h, _ptr(q), C.c_int(len(q)), C.c_float(norm), _ptr(offsets), _ptr(idx),
+                                                C.c_int(cap), C.byref(n_total))
+            if rc == -1 and n_total.value > cap:
+                cap = n_total.value
+                continue
+            _chk(rc)
+            break
+        return [idx[offsets[i]:offsets[i + 1]].copy() for i in range(len(q))]

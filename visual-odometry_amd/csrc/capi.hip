@@ -27,6 +27,7 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+void set_error_v(const char* fmt, va_list ap) { vsnprintf(g_err, sizeof(g_err), fmt, ap); }
 
 #define VO_HIP_CHECK(expr)                                                              \
   do {                                                                                  \
@@ -62,6 +63,14 @@ struct DevBuf {
 };
 
 }  // namespace
+
+int vo_fail(int code, const char* fmt, ...) {        // for the other translation units (vo_internal.h)
+  va_list ap;
+  va_start(ap, fmt);
+  set_error_v(fmt, ap);
+  va_end(ap);
+  return code;
+}
 
 struct vo_ctx {
   int device = 0;

@@ -7,6 +7,9 @@
 
 #include "vo_math.h"
 
+// records the message vo_last_error() returns on this thread and hands `code` back (capi.hip)
+int vo_fail(int code, const char* fmt, ...);
+
 namespace vo {
 
 // ---- PICP ------------------------------------------------------------------
