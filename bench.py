@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--seq-iters", type=int, default=100, help="PICP rounds per frame in the sequence leg (vo_complete.cpp:163)")
     ap.add_argument("--strong-pairs", type=int, default=1600,
                     help="frame pairs of the strong-scaling config-4 leg, sharded over the ranks (0: skip)")
-    ap.add_argument("--strong-per-call", type=int, default=400, help="frames per vo_frames_batch_dev call in that leg")
+    ap.add_argument("--strong-per-call", type=int, default=1600, help="frames per vo_frames_batch_dev call in that leg")
     ap.add_argument("--gen-workers", type=int, default=None, help="host processes generating the config-4 pairs (default: CPU share, <= 16)")
     return ap.parse_args()
 
