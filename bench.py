@@ -86,7 +86,8 @@ def launch_ranks(args):
 
 def main():
     args = parse()
-    if args.gpus > 1 and "RANK" not in os.environ:
+    # VO_BENCH_FORCE_LAUNCH=1: take the self-launch route with one rank too (rehearsal of the N-rank path on a 1-GPU box)
+    if (args.gpus > 1 or os.environ.get("VO_BENCH_FORCE_LAUNCH") == "1") and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))
     vo = graft.load_package()
     from importlib import import_module
