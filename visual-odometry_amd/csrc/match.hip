@@ -628,8 +628,10 @@ constexpr int CELL_SAMPLE = 2048;        // points per set that define the grid'
 #endif
 constexpr int CS_NB = VO_CS_NB;          // coarse bins per search workgroup (a strip along c1)
 constexpr int CS_THREADS = CS_NB == 1 ? 192 : (CS_NB == 2 ? 320 : 448);   // a coarse bin holds ~140 queries at 50k points
-constexpr int CS_SURV = 8;               // filter survivors a lane parks before it evaluates them
-constexpr int CS_CAP = 576 * (CS_NB + 2);   // tree points a search workgroup can stage (20 B each; ~140 per bin at 50k)
+constexpr int CS_SURV = 4;               // filter survivors a lane parks before it evaluates them
+constexpr int CS_CAP = CS_NB == 3 ? 2296 : 576 * (CS_NB + 2);   // tree points a search workgroup can stage (16 B each; ~140 per bin
+                                                                //   at 50k): with NB = 3 three workgroups share a CU's LDS
+static_assert(CS_CAP < 4096 && 3 * (CS_NB + 2) <= 16, "a parked survivor is (staged bin : 4 bits, LDS slot : 12 bits)");
 
 struct CellParams {
   int dim[HK];
@@ -1037,8 +1039,8 @@ __global__ __launch_bounds__(CS_THREADS) void cell_search_kernel(CellArgs a) {
   unsigned long long* best = a.best + f * a.best_stride;
   const int tid = threadIdx.x;
 
-  __shared__ float4 s_pre[CS_CAP];
-  __shared__ int s_idx[CS_CAP];
+  __shared__ float4 s_pre[CS_CAP];                        // filter prefixes of the staged tree points (their indices stay in
+                                                          //   global memory: only the ~3 survivors per query need one)
   __shared__ __attribute__((aligned(16))) unsigned short s_start[CS_PLANES][HROW];   // cell starts of the staged bins, relative to each bin's first slot
   __shared__ int s_gbase[CS_PLANES], s_lbase[CS_PLANES + 1], s_len[CS_PLANES];   // per bin: first slot in the sorted tree, in LDS, length
   __shared__ unsigned short s_surv[CS_SURV][CS_THREADS];  // parked filter survivors (LDS slots), lane-private columns
@@ -1075,7 +1077,6 @@ __global__ __launch_bounds__(CS_THREADS) void cell_search_kernel(CellArgs a) {
       for (int j = 1; j < CS_PLANES; ++j) s += (i >= s_lbase[j]) ? 1 : 0;   // empty bins share a base: the last one wins,
       const int g = s_gbase[s] + (i - s_lbase[s]);                          // and only a bin with points can own slot i
       s_pre[i] = tree_pre[g];
-      s_idx[i] = tree_idx[g];
     }
     // the bins' rows of the 16-bit start table, eight entries per load
     const uint4* rel = reinterpret_cast<const uint4*>(ws + a.w.start_rel);
@@ -1179,17 +1180,20 @@ __global__ __launch_bounds__(CS_THREADS) void cell_search_kernel(CellArgs a) {
             const int pos_n = k + 1 < tot ? base_n + k + 1 : pos;       // (always a valid slot: one unconditional read)
             const float4 ta_n = s_pre[pos_n];
             if (passes(ta)) {
-              if (n_surv < CS_SURV) { s_surv[n_surv][tid] = (unsigned short)pos; ++n_surv; }
-              else consider(ta, s_idx[pos]);
+              if (n_surv < CS_SURV) { s_surv[n_surv][tid] = (unsigned short)(pos | (s << 12)); ++n_surv; }
+              else consider(ta, tree_idx[s_gbase[s] + pos - lb]);
             }
             pos = pos_n; ta = ta_n;
           }
         }
       for (int k = 0; k < n_surv; k += 3) {               // three rows per lane in flight
         const bool h1 = k + 1 < n_surv, h2 = k + 2 < n_surv;
-        const int pa = s_surv[k][tid], pb = s_surv[h1 ? k + 1 : k][tid], pc = s_surv[h2 ? k + 2 : k][tid];
+        const int ka = s_surv[k][tid], kb = s_surv[h1 ? k + 1 : k][tid], kc = s_surv[h2 ? k + 2 : k][tid];
+        const int pa = ka & 4095, pb = kb & 4095, pc = kc & 4095;            // LDS slots; bits 15:12 = the staged bin
         const float4 fa = s_pre[pa], fb = s_pre[pb], fc = s_pre[pc];
-        const int ia = s_idx[pa], ib = s_idx[pb], ic = s_idx[pc];
+        const int ia = tree_idx[s_gbase[ka >> 12] + pa - s_lbase[ka >> 12]];
+        const int ib = tree_idx[s_gbase[kb >> 12] + pb - s_lbase[kb >> 12]];
+        const int ic = tree_idx[s_gbase[kc >> 12] + pc - s_lbase[kc >> 12]];
         const float2* ra = reinterpret_cast<const float2*>(tree + 10 * (size_t)ia);
         const float2* rb = reinterpret_cast<const float2*>(tree + 10 * (size_t)ib);
         const float2* rc = reinterpret_cast<const float2*>(tree + 10 * (size_t)ic);
