@@ -129,3 +129,16 @@ def test_beyond_benchmark_size_300k(vo, ctx, o32, o64):
     xo, po, _ = o32.triangulate(fp["K"], T, m, fp["ref_pts"], fp["cur_pts"])
     assert np.array_equal(pairs, po) and np.array_equal(xyz, xo)
     s.close()
+
+
+@pytest.mark.parametrize("n,drop", [(70000, 0.05), (100000, 0.0)])
+def test_cell_hash_matcher_beyond_the_staging_budgets(vo, o32, n, drop):
+    """matcher mode 3 on sets larger than the LDS budgets of its placement (more level-1 workgroups at 70k; at 100k a
+    slice no longer fits and the placement writes straight) -- against the reference's kd-tree restatement"""
+    c = vo.Context(0)
+    assert c.lib.vo_match_set_mode(c.h, 3) == 0
+    fp = vo.synth.frame_pair(n, seed=77, drop=drop, distractors=200 if drop else 0)
+    m = vo.compute_correspondences_images(fp["ref_app"], fp["cur_app"], ctx=c)
+    m_o = o32.match_kdtree(fp["ref_app"], fp["cur_app"])
+    assert np.array_equal(m, m_o) and len(m) > 0.85 * n
+    c.close()

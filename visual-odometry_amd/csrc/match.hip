@@ -622,6 +622,7 @@ constexpr int HCOARSE = HNC * HNC;       // coarse bins (c0, c1) / fine bins (c2
 constexpr int HCPAD = 512;               // HCOARSE rounded up to a power of two (scan width)
 constexpr int HBINS = HNC * HNC * HNC * HNC + 1;   // every key + the end sentinel
 constexpr int HROW = 408;                // u16 entries per row of the relative start table (>= HCOARSE + 1, 16-byte rows)
+constexpr int CELL_MAX_TB = 48, CELL_MAX_QB = 16, CELL_MAX_ROWS = CELL_MAX_TB + CELL_MAX_QB;   // level-1 workgroups per frame, at most
 constexpr int CELL_SAMPLE = 2048;        // points per set that define the grid's bounds
 #ifndef VO_CS_NB
 #define VO_CS_NB 3
@@ -700,7 +701,7 @@ static CellWs cell_ws_layout(int nt, int nq) {
   w.t1_pre = o; o += align256(sizeof(float) * 4 * (size_t)nt);        // level 1 (coarse order): tree prefix,
   w.t1_meta = o; o += align256(sizeof(int) * 2 * (size_t)nt);         //   (original index, fine bin)
   w.q1_idx = o; o += align256(sizeof(int) * (size_t)nq);              //   query indices grouped by coarse bin
-  w.block_hist = o; o += align256(sizeof(int) * (size_t)36 * 2 * HCPAD);   // CELL_ROWS rows
+  w.block_hist = o; o += align256(sizeof(int) * (size_t)CELL_MAX_ROWS * 2 * HCPAD);
   w.coarse_start = o; o += align256(sizeof(int) * 2 * (HCPAD + 1));
   w.start_t = o; o += align256(sizeof(int) * (size_t)HBINS);          // first tree slot of every cell (+ end sentinel)
   w.start_rel = o; o += align256(sizeof(unsigned short) * (size_t)HCOARSE * HROW);   // the same per coarse bin, relative to
@@ -719,6 +720,7 @@ struct CellArgs {
   CellWs w;
   size_t ws_stride, tree_stride, qry_stride, best_stride;
   int n_frames;
+  int tb, qb;               // level-1 workgroups per frame over the tree / over the queries
   float radius, r2;
   unsigned long long* best;
   int* rs_offsets;          // radius search: [nq + 1] counts, then (after the scan) offsets
@@ -792,14 +794,18 @@ __global__ __launch_bounds__(1024) void cell_bounds_kernel(CellArgs a) {
   }
 }
 
-// level 1: CELL_TB workgroups per frame take contiguous slices of the tree, CELL_QB of the queries (a row of
-// block_hist each; only the row's own half is non-zero)
-constexpr int CELL_TB = 28, CELL_QB = 8, CELL_ROWS = CELL_TB + CELL_QB;
+// level 1: a.tb workgroups per frame take contiguous slices of the tree, a.qb of the queries (a row of block_hist each;
+// only the row's own half is non-zero).  The counts follow the set sizes (cell_level1_blocks) so that a slice fits the
+// LDS staging of the placement: 28 + 9 at 50k x 50k; beyond 48 x 1920 tree points the placement writes straight.
 constexpr int PL_TCAP = 1920;            // tree points a placement workgroup can order in LDS (24 B each)
 constexpr int PL_QCAP = 6400;            // queries (6 B each)
-__device__ __forceinline__ void cell_slice(int blk, int nt, int nq, bool& is_t, int& lo, int& hi) {
-  is_t = blk < CELL_TB;
-  const int n = is_t ? nt : nq, parts = is_t ? CELL_TB : CELL_QB, b = is_t ? blk : blk - CELL_TB;
+static void cell_level1_blocks(int nt, int nq, int& tb, int& qb) {
+  tb = (nt + 1799) / 1800; tb = tb < 4 ? 4 : (tb > CELL_MAX_TB ? CELL_MAX_TB : tb);
+  qb = (nq + 5999) / 6000; qb = qb < 2 ? 2 : (qb > CELL_MAX_QB ? CELL_MAX_QB : qb);
+}
+__device__ __forceinline__ void cell_slice(int blk, int nt, int nq, int tb, int qb, bool& is_t, int& lo, int& hi) {
+  is_t = blk < tb;
+  const int n = is_t ? nt : nq, parts = is_t ? tb : qb, b = is_t ? blk : blk - tb;
   const int per = (n + parts - 1) / parts;
   lo = b * per < n ? b * per : n;
   hi = lo + per < n ? lo + per : n;
@@ -807,14 +813,14 @@ __device__ __forceinline__ void cell_slice(int blk, int nt, int nq, bool& is_t, 
 
 __global__ __launch_bounds__(256) void cell_coarse_hist_kernel(CellArgs a) {
   int f, blk;
-  if (!xcd_frame_block(CELL_ROWS, a.n_frames, f, blk)) return;
+  if (!xcd_frame_block(a.tb + a.qb, a.n_frames, f, blk)) return;
   char* ws = a.ws + f * a.ws_stride;
   __shared__ int s_h[HCPAD];
   for (int k = threadIdx.x; k < HCPAD; k += 256) s_h[k] = 0;
   const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
   __syncthreads();
   bool is_t; int lo, hi;
-  cell_slice(blk, a.nt, a.nq, is_t, lo, hi);
+  cell_slice(blk, a.nt, a.nq, a.tb, a.qb, is_t, lo, hi);
   const float* src = is_t ? a.tree + f * a.tree_stride : a.qry + f * a.qry_stride;
   for (int i = lo + threadIdx.x; i < hi; i += 256) {
     float v[10];
@@ -837,7 +843,7 @@ __global__ __launch_bounds__(HCPAD) void cell_coarse_offsets_kernel(CellArgs a) 
   int* starts = reinterpret_cast<int*>(ws + a.w.coarse_start);
   __shared__ int s_w[HCPAD / 64];
   const int half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b_lo = half ? CELL_TB : 0, b_hi = half ? CELL_ROWS : CELL_TB;      // the rows that hold this set
+  const int b_lo = half ? a.tb : 0, b_hi = half ? a.tb + a.qb : a.tb;          // the rows that hold this set
   int v = 0;
   for (int b = b_lo; b < b_hi; ++b) v += block_hist[(size_t)b * 2 * HCPAD + half * HCPAD + tid];
   int incl = v;
@@ -867,10 +873,10 @@ __global__ __launch_bounds__(HCPAD) void cell_coarse_offsets_kernel(CellArgs a) 
 // consecutive addresses inside a bin's run, and the frame's workgroups share one XCD, whose L2 merges the runs.
 __global__ __launch_bounds__(256) void cell_coarse_place_kernel(CellArgs a) {
   int f, blk;
-  if (!xcd_frame_block(CELL_ROWS, a.n_frames, f, blk)) return;
+  if (!xcd_frame_block(a.tb + a.qb, a.n_frames, f, blk)) return;
   char* ws = a.ws + f * a.ws_stride;
   bool is_t; int lo, hi;
-  cell_slice(blk, a.nt, a.nq, is_t, lo, hi);
+  cell_slice(blk, a.nt, a.nq, a.tb, a.qb, is_t, lo, hi);
   const float* src = is_t ? a.tree + f * a.tree_stride : a.qry + f * a.qry_stride;
   const int half = is_t ? 0 : HCPAD, set = is_t ? 0 : 1;
   const int* block_off = reinterpret_cast<const int*>(ws + a.w.block_hist);
@@ -886,7 +892,7 @@ __global__ __launch_bounds__(256) void cell_coarse_place_kernel(CellArgs a) {
                                                                                // queries: int idx[PL_QCAP] + ushort bin[PL_QCAP]
   static_assert(PL_QCAP * 6 <= PL_TCAP * 24, "query staging must fit the tree staging");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool last_row = is_t ? blk == CELL_TB - 1 : blk == CELL_ROWS - 1;
+  const bool last_row = is_t ? blk == a.tb - 1 : blk == a.tb + a.qb - 1;
   // this workgroup's count per bin = next row's offset (or the bin's end) - its own offset; two bins per thread
   int off[2], cnt[2];
 #pragma unroll
@@ -1227,13 +1233,14 @@ static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tr
   a.w = cell_ws_layout(nt, nq);
   a.ws_stride = a.w.total; a.tree_stride = tree_stride; a.qry_stride = qry_stride; a.best_stride = best_stride;
   a.n_frames = n_frames;
+  cell_level1_blocks(nt, nq, a.tb, a.qb);
   a.radius = radius; a.r2 = r2; a.best = d_best;
   a.rs_offsets = nullptr; a.rs_indices = nullptr; a.rs_capacity = 0;
   const unsigned Z = (unsigned)n_frames;
   hipLaunchKernelGGL(cell_bounds_kernel, dim3(Z), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(cell_coarse_hist_kernel, dim3(xcd_grid(CELL_ROWS, n_frames)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_coarse_hist_kernel, dim3(xcd_grid(a.tb + a.qb, n_frames)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(cell_coarse_offsets_kernel, dim3(2, 1, Z), dim3(HCPAD), 0, st, a);
-  hipLaunchKernelGGL(cell_coarse_place_kernel, dim3(xcd_grid(CELL_ROWS, n_frames)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_coarse_place_kernel, dim3(xcd_grid(a.tb + a.qb, n_frames)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(cell_fine_kernel, dim3(xcd_grid(HCOARSE, n_frames)), dim3(256), 0, st, a);
   return hipGetLastError();
 }
