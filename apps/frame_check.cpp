@@ -3,8 +3,10 @@
 // triangulate_points (point-cloud overload).  Reads a binary frame written by
 // tests/test_gpu_facade.py, writes the results for the test to compare with the
 // oracle.    usage: frame_check <in.bin> <out.bin>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "vo/vo.hpp"
@@ -64,6 +66,30 @@ int main(int argc, char** argv) {
     wr(o, triangulated_transformed.points().data(), triangulated_transformed.size());
     fclose(o);
     std::printf("frame_check: %d matches, %d joined, %d inliers, %d triangulated\n", counts[0], counts[1], n_in, n_tri);
+    if (argc > 3 && std::string(argv[3]) == "extras") {
+      // TreeNode_ facade (eigen_kdtree.h): the approximate answers must be answers of the exact modes
+      KdTree tree(reference_pc.appearances(), 10);
+      const std::vector<int> full = tree.bestMatchFull(current_pc.appearances(), 0.1f), fast = tree.bestMatchFast(current_pc.appearances(), 0.1f);
+      const std::vector<std::vector<int>> all = tree.fullSearch(current_pc.appearances(), 0.1f), some = tree.fastSearch(current_pc.appearances(), 0.1f);
+      int same = 0, bad = 0;
+      for (size_t i = 0; i < full.size(); ++i) {
+        same += fast[i] == full[i];
+        if (fast[i] >= 0 && std::find(all[i].begin(), all[i].end(), fast[i]) == all[i].end()) ++bad;
+        for (int j : some[i]) if (std::find(all[i].begin(), all[i].end(), j) == all[i].end()) ++bad;
+        if (full[i] >= 0 && std::find(all[i].begin(), all[i].end(), full[i]) == all[i].end()) ++bad;
+      }
+      std::printf("kdtree: bestMatchFast == bestMatchFull for %d of %zu queries, %d inconsistent answers\n", same, full.size(), bad);
+      // PICPSolver is copyable like the reference's: a copy carries the settings, and after its own init() runs the same rounds
+      PICPSolver copy = solver;
+      cam.setWorldInCameraPose(Isometry3f::Identity());
+      copy.init(cam, triangulated_transformed.points(), current_pc.points());
+      for (int i = 0; i < n_iters; i++) copy.oneRound(correspondences_world, false);
+      const Isometry3f a = copy.camera().worldInCameraPose(), b = solver.camera().worldInCameraPose();
+      bool equal = copy.kernelThreshold() == solver.kernelThreshold();
+      for (int i = 0; i < 16; ++i) equal = equal && a.m[i] == b.m[i];
+      std::printf("solver copy: %s\n", equal ? "identical result" : "DIFFERENT result");
+      if (bad || !equal) return 4;
+    }
     return 0;
   } catch (const vo::Error& e) {
     std::fprintf(stderr, "frame_check: %s\n", e.what());

@@ -44,8 +44,13 @@ def test_frame_through_cpp_facade(tmp_path, vo, o32):
         for a in (fp["ref_pts"], fp["ref_app"], fp["cur_pts"], fp["cur_app"], model_prev):
             f.write(np.ascontiguousarray(a, np.float32).tobytes())
         f.write(np.ascontiguousarray(fp["model_pairs"], np.int32).tobytes())
-    r = subprocess.run([os.path.join(BIN, "frame_check"), str(inp), str(outp)], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([os.path.join(BIN, "frame_check"), str(inp), str(outp), "extras"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+    # the extras: vo::KdTree (TreeNode_ facade) answers are consistent, a copied PICPSolver gives the identical result
+    import re
+    km = re.search(r"kdtree: bestMatchFast == bestMatchFull for (\d+) of (\d+) queries, (\d+) inconsistent", r.stdout)
+    assert km and int(km.group(3)) == 0 and int(km.group(1)) > 0.9 * int(km.group(2)), r.stdout
+    assert "solver copy: identical result" in r.stdout
     raw = open(outp, "rb").read()
     off = 0
 
