@@ -601,10 +601,11 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
 // workgroup per coarse bin, ordering its points by the <= 400 fine bins (c2, c3) and writing that bin's slice
 // of the start table.  The queries are only grouped by coarse bin (level 1 writes their indices).
 //
-// Search: one workgroup per coarse bin (c0, c1).  Every query of the bin can only meet tree points of the
-// 3 x 3 coarse bins around it, i.e. nine CONTIGUOUS segments of the sorted tree (~125 points each on 50k
-// uniform points) and nine rows of the start table: the workgroup stages both in LDS with coalesced loads
-// and every lane then walks its own <= 27 runs (3 x 3 x 3 cells in c0, c1, c2; contiguous along c3) out of LDS.
+// Search: one workgroup per STRIP of CS_NB coarse bins (c0, c1 .. c1 + CS_NB - 1).  Every query of a bin can only meet
+// tree points of the 3 x 3 coarse bins around it, i.e. nine CONTIGUOUS segments of the sorted tree (~140 points each
+// on 50k uniform points) and nine rows of the start table: the workgroup stages the 3 x (CS_NB + 2) bins of its strip in
+// LDS with coalesced loads (filter prefixes and 16-bit relative starts; the points' original indices stay in global
+// memory) and every lane then walks its own <= 27 runs (3 x 3 x 3 cells in c0, c1, c2; contiguous along c3) out of LDS.
 // (Per-lane gathers from global memory -- 54 table reads and ~25 16-byte candidate reads per query, each
 // its own cache line -- made the first version L1-request-bound: 1.41 ms per 200 x 50k frames.)  A query
 // visits, per component, the cells [cell(q - R), cell(q - R) + 2] clipped to cell(q + R): any tree value t
