@@ -193,17 +193,20 @@ __device__ __forceinline__ float ord2f(unsigned o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
-// mm[0..9] = ord(min), mm[10..19] = ~ord(max): both merge with atomicMin, one 0xff memset initialises all
-__global__ __launch_bounds__(256) void match_minmax_kernel(const float* __restrict__ a, int na,
-                                                           const float* __restrict__ b, int nb, unsigned* mm,
+// mm[0..9] = ord(min), mm[10..19] = ~ord(max): both merge with atomicMin, one 0xff memset initialises all.
+// Every sa-th row of a and every sb-th row of b is looked at: the bounds only place the buckets (bucket_of is monotone
+// and clamps, so ANY bounds give a correct search), and a sample of a few thousand rows places them as well as all rows.
+__global__ __launch_bounds__(256) void match_minmax_kernel(const float* __restrict__ a, int na, int sa,
+                                                           const float* __restrict__ b, int nb, int sb, unsigned* mm,
                                                            MatchStrides ms) {
   a += blockIdx.z * ms.tree; b += blockIdx.z * ms.qry; mm = frame_ptr(mm, blockIdx.z * ms.mm);
   __shared__ float s_lo[4][10], s_hi[4][10];
   float lo[10], hi[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < na + nb; i += gridDim.x * 256) {
-    const float2* p = reinterpret_cast<const float2*>(i < na ? a + 10 * (size_t)i : b + 10 * (size_t)(i - na));
+  const int ma = (na + sa - 1) / sa, mb = (nb + sb - 1) / sb;      // sampled rows
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < ma + mb; i += gridDim.x * 256) {
+    const float2* p = reinterpret_cast<const float2*>(i < ma ? a + 10 * (size_t)i * sa : b + 10 * (size_t)(i - ma) * sb);
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
       const float2 v = p[k];
@@ -572,8 +575,9 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
   const unsigned Z = (unsigned)n_frames;
   hipError_t e = hipMemsetAsync(mm, 0xff, 128 * (size_t)n_frames, st);
   if (e != hipSuccess) return e;
-  int g = (nt + nq + 255) / 256;
-  hipLaunchKernelGGL(match_minmax_kernel, dim3(g > 256 ? 256 : g, 1, Z), dim3(256), 0, st, tree, nt, qry, nq, mm, ms);
+  const int st_t = (nt + 4095) / 4096 > 0 ? (nt + 4095) / 4096 : 1, st_q = (nq + 4095) / 4096 > 0 ? (nq + 4095) / 4096 : 1;   // <= 4096 rows per set
+  const int g = ((nt + st_t - 1) / st_t + (nq + st_q - 1) / st_q + 255) / 256;
+  hipLaunchKernelGGL(match_minmax_kernel, dim3(g > 0 ? g : 1, 1, Z), dim3(256), 0, st, tree, nt, st_t, qry, nq, st_q, mm, ms);
   hipLaunchKernelGGL(match_bucket_hist_kernel, dim3(SORT_BLOCKS, 1, Z), dim3(256), 0, st, tree, nt, qry, nq, mm, radius,
                      bp, block_hist, ms);
   hipLaunchKernelGGL(match_bucket_offsets_kernel, dim3(2, 1, Z), dim3(NBUCKET), 0, st, block_hist, starts, ms);
