@@ -44,18 +44,21 @@ class PointCloudVector {
   void update(const PointCloudVector<dim>& cloud) {
     if (_index_size != _appearances.size()) {
       _index.clear();
-      for (size_t j = 0; j < _appearances.size(); ++j) _index.emplace(key(_appearances[j]), j);
+      for (size_t j = 0; j < _appearances.size(); ++j)
+        if (!has_nan(_appearances[j])) _index.emplace(key(_appearances[j]), j);
       _index_size = _appearances.size();
     }
     for (size_t i = 0; i < cloud.size(); i++) {
-      const auto k = key(cloud.appearances()[i]);
-      auto it = _index.find(k);
+      const Vector10f& a = cloud.appearances()[i];
+      // the reference compares with operator== (PointCloud.h:56): an appearance with a NaN equals nothing, not even itself
+      const bool nan = has_nan(a);
+      auto it = nan ? _index.end() : _index.find(key(a));
       if (it != _index.end()) {
         _points[it->second] = cloud.points()[i];
       } else {
-        _index.emplace(k, _points.size());
+        if (!nan) _index.emplace(key(a), _points.size());
         _points.push_back(cloud.points()[i]);
-        _appearances.push_back(cloud.appearances()[i]);
+        _appearances.push_back(a);
         _index_size = _appearances.size();
       }
     }
@@ -66,10 +69,15 @@ class PointCloudVector {
   const Vector10fVector& appearances() const { return _appearances; }
 
  protected:
+  static bool has_nan(const Vector10f& a) {
+    for (int k = 0; k < 10; ++k) if (a.v[k] != a.v[k]) return true;
+    return false;
+  }
   static std::string key(const Vector10f& a) {
-    // operator== on floats treats -0 == +0 and NaN != NaN; appearances are copied bit for bit
-    // from the measurement files, so the byte image is the same equivalence in practice
-    return std::string(reinterpret_cast<const char*>(a.v), sizeof(a.v));
+    // the equivalence of operator== on floats: -0 == +0 (both keyed as +0), NaN != NaN (never keyed: has_nan)
+    float c[10];
+    for (int k = 0; k < 10; ++k) c[k] = a.v[k] == 0.f ? 0.f : a.v[k];
+    return std::string(reinterpret_cast<const char*>(c), sizeof(c));
   }
   PointsVec _points;
   Vector10fVector _appearances;

@@ -171,3 +171,14 @@ def test_exact_mode_arithmetic_is_the_oracles_bit_for_bit(hc, o32, vo, thr, keep
     assert np.array_equal(tT.reshape(n_it, 4, 4).transpose(0, 2, 1), r["T"])
     if keep == 0 and thr < 100:
         assert 0 < ts[0, 2] < len(j) and ts[0, 1] > 0       # both branches of the chi test taken
+
+
+def test_point_cloud_update_follows_operator_equal(tmp_path):
+    """the facade's map upsert uses a hash index; its key must be the equivalence of the reference's operator==
+    (PointCloud.h:56): -0 == +0, an appearance holding a NaN equals nothing (appended every time)"""
+    exe = str(tmp_path / "pc_update")
+    root = os.path.join(HERE, "..")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "include", "vo"),
+                           os.path.join(HERE, "hostcheck", "point_cloud_update.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split() == ["4", "2"], r.stdout
