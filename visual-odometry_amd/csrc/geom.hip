@@ -260,13 +260,14 @@ struct TriArgs {
   int32_t* out_pairs;
   float* out_app;
   int* counts;
-  // batched use: frame f = blockIdx.y; strides in pairs / points (0 for a single frame)
+  // batched use: strides in pairs / points per frame (0 for a single frame); nb workgroups for each of n_frames frames
   size_t pairs_stride, p1_stride, p2_stride, out_stride, counts_stride;
+  int nb, n_frames;
 };
 
-// shifts every per-frame pointer of `a` to frame blockIdx.y
-__device__ __forceinline__ TriArgs tri_frame(TriArgs a) {
-  const size_t f = blockIdx.y;
+// shifts every per-frame pointer of `a` to frame f
+__device__ __forceinline__ TriArgs tri_frame(TriArgs a, int frame) {
+  const size_t f = (size_t)frame;
   if (a.d_X16) a.d_X16 += 16 * f;
   a.pairs += 2 * f * a.pairs_stride;
   if (a.d_n) a.d_n += f;
@@ -309,26 +310,30 @@ __device__ __forceinline__ bool tri_eval(const TriArgs& a, const TriConst& c, in
 }
 
 __global__ __launch_bounds__(CB) void tri_count_kernel(TriArgs a0) {
-  const TriArgs a = tri_frame(a0);
+  const FrameBlock fb = frame_block(a0.nb, a0.n_frames);
+  if (!fb.live) return;
+  const TriArgs a = tri_frame(a0, fb.f);
   __shared__ TriConst s_c;
   __shared__ int s_wave[CB / 64];
   tri_setup(a, &s_c);
   const int n = clamp_count(a.d_n, a.n_max);
-  const int k = blockIdx.x * CB + threadIdx.x;
+  const int k = fb.b * CB + threadIdx.x;
   bool ok = false;
   if (k < n) { int i2; float p[3]; ok = tri_eval(a, s_c, k, i2, p); }
   int total;
   block_rank(ok, s_wave, total);
-  if (threadIdx.x == 0) a.counts[blockIdx.x] = total;
+  if (threadIdx.x == 0) a.counts[fb.b] = total;
 }
 
 __global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a0) {
-  const TriArgs a = tri_frame(a0);
+  const FrameBlock fb = frame_block(a0.nb, a0.n_frames);
+  if (!fb.live) return;
+  const TriArgs a = tri_frame(a0, fb.f);
   __shared__ TriConst s_c;
   __shared__ int s_wave[CB / 64];
   tri_setup(a, &s_c);
   const int n = clamp_count(a.d_n, a.n_max);
-  const int k = blockIdx.x * CB + threadIdx.x;
+  const int k = fb.b * CB + threadIdx.x;
   bool ok = false;
   int i2 = 0;
   float p[3] = {0.f, 0.f, 0.f};
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a0) {
   int total;
   const int r = block_rank(ok, s_wave, total);
   if (ok) {
-    const size_t dst = (size_t)a.counts[blockIdx.x] + r;
+    const size_t dst = (size_t)a.counts[fb.b] + r;
     a.out_xyz[3 * dst] = p[0]; a.out_xyz[3 * dst + 1] = p[1]; a.out_xyz[3 * dst + 2] = p[2];
     if (a.out_pairs) { a.out_pairs[2 * dst] = i2; a.out_pairs[2 * dst + 1] = (int)dst; }   // utils.cpp:97
   }
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a0) {
     if (ok) s_src[r] = i2;
     __syncthreads();
     const float2* app = reinterpret_cast<const float2*>(a.app2);
-    float2* o = reinterpret_cast<float2*>(a.out_app) + 5 * (size_t)a.counts[blockIdx.x];
+    float2* o = reinterpret_cast<float2*>(a.out_app) + 5 * (size_t)a.counts[fb.b];
     for (int j = threadIdx.x; j < 5 * total; j += CB) {
       const int pt = j / 5;
       o[j] = app[5 * (size_t)s_src[pt] + (j - 5 * pt)];
@@ -376,10 +381,11 @@ hipError_t launch_triangulate_batch(hipStream_t st, const float K[9], const Pose
   a.p2_stride = batched ? p2_stride : 0; a.out_stride = batched ? out_stride : 0;
   a.counts_stride = batched ? compaction_scratch_ints(n) : 0;
   const int nb = (n + CB - 1) / CB;
-  if (nb > 0) hipLaunchKernelGGL(tri_count_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);
+  a.nb = nb; a.n_frames = n_frames;
+  if (nb > 0) hipLaunchKernelGGL(tri_count_kernel, frame_grid(nb, n_frames), dim3(CB), 0, st, a);
   hipError_t e = launch_scan(st, d_scratch, nb, d_n_out, nullptr, n_frames, a.counts_stride);
   if (e != hipSuccess) return e;
-  if (nb > 0) hipLaunchKernelGGL(tri_scatter_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);
+  if (nb > 0) hipLaunchKernelGGL(tri_scatter_kernel, frame_grid(nb, n_frames), dim3(CB), 0, st, a);
   return hipGetLastError();
 }
 
@@ -417,11 +423,12 @@ struct JoinArgs {
   const int* table;
   int32_t* out;
   int* counts;
-  size_t img_stride, world_stride, out_stride, counts_stride;   // per frame (blockIdx.y), in pairs / ints
+  size_t img_stride, world_stride, out_stride, counts_stride;   // per frame, in pairs / ints
+  int nb, n_frames;                                             // workgroups per frame, frames
 };
 
-__device__ __forceinline__ JoinArgs join_frame(JoinArgs a) {
-  const size_t f = blockIdx.y;
+__device__ __forceinline__ JoinArgs join_frame(JoinArgs a, int frame) {
+  const size_t f = (size_t)frame;
   a.img += 2 * f * a.img_stride;
   if (a.d_n) a.d_n += f;
   a.world += 2 * f * a.world_stride;
@@ -442,29 +449,33 @@ __device__ __forceinline__ bool join_eval(const JoinArgs& a, int i, int& cur, in
 }
 
 __global__ __launch_bounds__(CB) void join_count_kernel(JoinArgs a0) {
-  const JoinArgs a = join_frame(a0);
+  const FrameBlock fb = frame_block(a0.nb, a0.n_frames);
+  if (!fb.live) return;
+  const JoinArgs a = join_frame(a0, fb.f);
   __shared__ int s_wave[CB / 64];
   const int n = clamp_count(a.d_n, a.n_max);
-  const int i = blockIdx.x * CB + threadIdx.x;
+  const int i = fb.b * CB + threadIdx.x;
   bool ok = false;
   if (i < n) { int c, w; ok = join_eval(a, i, c, w); }
   int total;
   block_rank(ok, s_wave, total);
-  if (threadIdx.x == 0) a.counts[blockIdx.x] = total;
+  if (threadIdx.x == 0) a.counts[fb.b] = total;
 }
 
 __global__ __launch_bounds__(CB) void join_scatter_kernel(JoinArgs a0) {
-  const JoinArgs a = join_frame(a0);
+  const FrameBlock fb = frame_block(a0.nb, a0.n_frames);
+  if (!fb.live) return;
+  const JoinArgs a = join_frame(a0, fb.f);
   __shared__ int s_wave[CB / 64];
   const int n = clamp_count(a.d_n, a.n_max);
-  const int i = blockIdx.x * CB + threadIdx.x;
+  const int i = fb.b * CB + threadIdx.x;
   bool ok = false;
   int c = 0, w = 0;
   if (i < n) ok = join_eval(a, i, c, w);
   int total;
   const int r = block_rank(ok, s_wave, total);
   if (ok) {
-    const size_t dst = (size_t)a.counts[blockIdx.x] + r;
+    const size_t dst = (size_t)a.counts[fb.b] + r;
     a.out[2 * dst] = c;        // vo_complete.cpp:59
     a.out[2 * dst + 1] = w;
   }
@@ -489,14 +500,14 @@ hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, co
     hipLaunchKernelGGL(join_build_kernel, dim3(grid, n_frames), dim3(256), 0, st, d_world, n_world, d_n_world, n_ref,
                        d_table, batched ? world_stride : 0);
   }
+  const int nb = (n_img + CB - 1) / CB;
   JoinArgs a{d_img, n_img, d_n_img, d_world, n_ref, d_table, d_out, d_scratch,
              batched ? img_stride : 0, batched ? world_stride : 0, batched ? out_stride : 0,
-             batched ? compaction_scratch_ints(n_img) : 0};
-  const int nb = (n_img + CB - 1) / CB;
-  if (nb > 0) hipLaunchKernelGGL(join_count_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);
+             batched ? compaction_scratch_ints(n_img) : 0, nb, n_frames};
+  if (nb > 0) hipLaunchKernelGGL(join_count_kernel, frame_grid(nb, n_frames), dim3(CB), 0, st, a);
   e = launch_scan(st, d_scratch, nb, d_n_out, nullptr, n_frames, a.counts_stride);
   if (e != hipSuccess) return e;
-  if (nb > 0) hipLaunchKernelGGL(join_scatter_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);
+  if (nb > 0) hipLaunchKernelGGL(join_scatter_kernel, frame_grid(nb, n_frames), dim3(CB), 0, st, a);
   return hipGetLastError();
 }
 

@@ -484,7 +484,9 @@ hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpSt
 
 // ---- batched solver -----------------------------------------------------------
 __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
-  const int p = blockIdx.y;
+  const FrameBlock fb = frame_block(a.pack_gx, a.n_problems);
+  if (!fb.live) return;
+  const int p = fb.f;
   int n = a.n_pairs[p];
   if (n < 0) n = 0;
   if ((size_t)n > a.cap) n = (int)a.cap;
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
   const float* world = a.world + 3 * (size_t)p * a.world_stride;
   const float* meas = a.meas + 2 * (size_t)p * a.meas_stride;
   float* dst = a.packed + (size_t)p * 5 * a.cap;
-  if (a.states && blockIdx.x == 0 && threadIdx.x < 12) {       // launch-per-round form: the problem's starting pose
+  if (a.states && fb.b == 0 && threadIdx.x < 12) {       // launch-per-round form: the problem's starting pose
     const int k = threadIdx.x;
     float v;
     if (a.T0) v = k < 9 ? a.T0[16 * (size_t)p + (k % 3) + 4 * (k / 3)] : a.T0[16 * (size_t)p + 12 + (k - 9)];
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
     a.states[p].pose[0][k] = v;
   }
   const float qnan = __int_as_float(0x7fc00000);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (int i = fb.b * 256 + threadIdx.x; i < n; i += fb.nb * 256) {
     const int m = pairs[2 * i], w = pairs[2 * i + 1];
     float x = qnan, y = 0.f, z = 0.f, u = 0.f, v = 0.f;
     if (m >= 0 && m < a.n_meas && w >= 0 && w < a.n_world) {
@@ -834,7 +836,9 @@ hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a) {
   int gx = (int)((a.cap + 255) / 256);
   if (gx > 64) gx = 64;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(picp_batch_pack_kernel, dim3(gx, a.n_problems), dim3(256), 0, st, a);
+  BatchArgs ap = a;
+  ap.pack_gx = gx;
+  hipLaunchKernelGGL(picp_batch_pack_kernel, frame_grid(gx, a.n_problems), dim3(256), 0, st, ap);
   hipError_t e = launch_picp_batch_solve(st, a);
   if (e == hipSuccess && a.stats_out && a.n_bad) {
     hipLaunchKernelGGL(picp_batch_bad_kernel, dim3((a.n_problems + 255) / 256), dim3(256), 0, st, a);

@@ -95,12 +95,36 @@ struct BatchArgs {
   float* partials;     // n_problems x 2 x round_up(grid,256) x PICP_PSTRIDE floats, zero-padded rows
   const PicpParams* params;   // device copy of (cam, thr, damping, keep_outliers); n_corr unused
   int grid;            // workgroups per problem
+  int pack_gx;         // workgroups per problem of the gather pass
   int* n_bad;          // n_problems counters (zeroed by the caller): correspondences dropped for a bad index, or null
   int exact;           // reference-order form (picp_exact_kernel): one workgroup per problem, sequential sums
 };
 hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a);
 // when is the launch-per-round form the faster one?  (measured: DESIGN.md section 4.1)
 bool picp_batch_prefers_rounds(int n_problems, size_t cap, int n_iters, int n_cu);
+
+// ---- frame-major grids ------------------------------------------------------------------------------
+// A batched kernel runs `nb` workgroups for each of `n_frames` frames.  Launched as grid (nb, n_frames) consecutive
+// workgroups of one frame are dealt round-robin over the 8 XCDs, so the frame's gather targets (its points, appearances,
+// index tables: 0.2 .. 2 MB) are pulled into every XCD's L2.  From 8 frames on the launch is 1-D instead
+// (frame_grid) and frame_block() maps blockIdx.x so that all workgroups of a frame share blockIdx.x mod 8, i.e. one XCD
+// and its L2 (observed placement; speed only, nothing depends on it).
+struct FrameBlock { int f, b, nb; bool live; };
+#if defined(__HIPCC__)
+__device__ __forceinline__ FrameBlock frame_block(int nb, int n_frames) {
+  FrameBlock r;
+  if (n_frames < 8) { r.f = (int)blockIdx.y; r.b = (int)blockIdx.x; r.nb = nb; r.live = true; return r; }
+  const unsigned L = blockIdx.x, s = L >> 3;
+  r.f = (int)(s / (unsigned)nb) * 8 + (int)(L & 7u);
+  r.b = (int)(s % (unsigned)nb);
+  r.nb = nb;
+  r.live = r.f < n_frames;
+  return r;
+}
+#endif
+inline dim3 frame_grid(int nb, int n_frames) {
+  return n_frames < 8 ? dim3((unsigned)nb, (unsigned)n_frames) : dim3(8u * (unsigned)((n_frames + 7) / 8) * (unsigned)nb);
+}
 
 // ---- geometry / matcher / join (geom.hip, match.hip) -------------------------
 struct Workspace;  // scratch owned by the context
