@@ -1,0 +1,96 @@
+"""Every operator of the path against the oracle at set sizes around the edges the kernels tile on: wave (64), workgroup
+(256), float4 groups (4), LDS tiles (128), compaction blocks, the matcher's mode switch-overs.  Integer outputs, survivor
+order, projection / transform / triangulation (same pose in) and the reference-order solver are compared bit for bit;
+the fast solver within the tolerances of test_gpu_parity.py.  Sizes are small: the whole file runs in seconds."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Camera as OCam
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 767, 769, 1023, 1025, 2047, 2049, 4097]
+
+
+def _frame(vo, n, seed):
+    # dropped detections, distractor points and holes in the model: ragged sets, unmatched queries, unjoined pairs
+    return vo.synth.frame_pair(n, seed=seed, drop=0.1 if n > 8 else 0.0, distractors=n // 16, model_drop=0.1 if n > 8 else 0.0)
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_operators_at_tile_edges(vo, ctx, o32, n):
+    fp = _frame(vo, n, 7000 + n)
+    cam_o = OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4))
+    # matcher, all three forms of the search, both argument orders (the larger set is the tree)
+    exp_m = o32.match(fp["ref_app"], fp["cur_app"])
+    exp_m_rev = o32.match(fp["cur_app"], fp["ref_app"])
+    for mode in (1, 2, 3):
+        assert ctx.lib.vo_match_set_mode(ctx.h, mode) == 0
+        assert np.array_equal(vo.compute_correspondences_images(fp["ref_app"], fp["cur_app"], ctx=ctx), exp_m), mode
+        assert np.array_equal(vo.compute_correspondences_images(fp["cur_app"], fp["ref_app"], ctx=ctx), exp_m_rev), mode
+    assert ctx.lib.vo_match_set_mode(ctx.h, 0) == 0
+    m = vo.compute_correspondences_images(fp["ref_app"], fp["cur_app"], ctx=ctx)
+    assert np.array_equal(m, exp_m)
+    # join
+    j = vo.extract_correspondences_world(m, fp["model_pairs"], ctx=ctx)
+    assert np.array_equal(j, o32.join(m, fp["model_pairs"]))
+    assert np.array_equal(j, o32.join(m, fp["model_pairs"], linear=True))
+    # rigid transform and projection: bit-exact
+    xt = vo.transform_points(fp["X_gt"], fp["model"], ctx=ctx)
+    assert np.array_equal(xt, o32.transform_points(fp["X_gt"], fp["model"]))
+    cam = vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], fp["X_gt"], ctx=ctx)
+    cam_gt = OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], fp["X_gt"])
+    for keep in (True, False):
+        uv, n_in = cam.projectPoints(fp["model"], keep_indices=keep)
+        e_uv, e_in = o32.project_points(cam_gt, fp["model"], keep_indices=keep)
+        assert n_in == e_in and np.array_equal(uv, e_uv)
+    # triangulation with the appearances carried along: survivors, order, points bit-exact
+    xyz, pairs, app = vo.triangulate_points(fp["K"], fp["X_gt"], m, fp["ref_pts"], fp["cur_pts"], fp["cur_app"], ctx=ctx)
+    e_xyz, e_pairs, e_app = o32.triangulate(fp["K"], fp["X_gt"], m, fp["ref_pts"], fp["cur_pts"], fp["cur_app"])
+    assert np.array_equal(pairs, e_pairs) and np.array_equal(app, e_app) and np.array_equal(xyz, e_xyz)
+    # solver: reference-order arithmetic bit for bit, fast mode within tolerance; both chi^2 branches (threshold 60)
+    if len(j) == 0:
+        return
+    for thr, keep in ((10000.0, False), (60.0, True)):
+        r = o32.picp_solve_raw(cam_o, fp["model"], fp["cur_pts"], j, 6, thr, keep)
+        for exact in (True, False):
+            s = vo.PICPSolver(ctx)
+            s.setExact(exact)
+            s.setKernelThreshold(thr)
+            s.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx), fp["model"], fp["cur_pts"])
+            s.solve(j, keep, 6)
+            T = s.camera().worldInCameraPose()
+            H, b = s.system()
+            if exact:
+                assert np.array_equal(T, r["T"][-1]) and np.array_equal(H, r["H"][-1]) and np.array_equal(b, r["b"][-1])
+                assert s.numInliers() == int(r["stats"][-1, 2])
+                assert np.float32(s.chiInliers()) == r["stats"][-1, 0] and np.float32(s.chiOutliers()) == r["stats"][-1, 1]
+            elif len(j) >= 16:      # below that the normal equations are near-singular: rounding is amplified without bound
+                assert np.abs(T - r["T"][-1]).max() < 1e-4 * max(1.0, float(np.abs(r["T"][-1]).max()))
+            s.close()
+
+
+@pytest.mark.parametrize("n,F", [(700, 1), (700, 2), (700, 7), (700, 8), (2500, 8), (2500, 15), (2500, 17), (700, 24)])
+def test_batched_frames_at_frame_count_edges(vo, o32, n, F):
+    """vo_frames_batch_dev maps (frame, workgroup) onto a plain 2-D grid below 8 frames and onto an XCD-aware 1-D grid from
+    8 frames on, with idle padding workgroups when F is not a multiple of 8: every frame must equal the oracle's frame."""
+    c = vo.Context(0)
+    fps = []
+    for i in range(F):
+        f = vo.synth.frame_pair(n, seed=7600 + 33 * i + n, distractors=13)      # 33: same seed % 3, same set sizes
+        keep = np.random.default_rng(100 + i).permutation(n)[: n - n // 8]
+        f["model_pairs"] = np.ascontiguousarray(f["model_pairs"][np.sort(keep)])
+        fps.append(f)
+    bp = vo.BatchPipeline(c, fps, n_iters=7, kernel_threshold=10000.0)
+    bp.run()
+    poses, stats, counts = bp.poses(), bp.stats(), bp.counts()
+    for i, f in enumerate(fps):
+        m_o = o32.match(f["ref_app"], f["cur_app"]); j_o = o32.join(m_o, f["model_pairs"])
+        assert np.array_equal(bp.fetch("match", i), m_o) and np.array_equal(bp.fetch("join", i), j_o), i
+        assert counts[0, i] == len(m_o) and counts[1, i] == len(j_o)
+        r = o32.picp_solve(OCam(480, 640, 0, 10, f["K"], np.eye(4)), f["model"], f["cur_pts"], j_o, 7, 10000.0, False, trace=False)
+        assert np.abs(poses[i] - r["T"]).max() < 1e-4 and int(stats[i, 2]) == r["num_inliers"], i
+        xo, po, ao = o32.triangulate(f["K"], poses[i], m_o, f["ref_pts"], f["cur_pts"], f["cur_app"])
+        assert np.array_equal(bp.fetch("tri_pairs", i), po) and np.array_equal(bp.fetch("tri_app", i), ao), i
+        assert np.array_equal(bp.fetch("tri_xyz", i), xo), i
+    bp.close(); c.close()
