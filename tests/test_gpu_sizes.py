@@ -94,3 +94,30 @@ def test_batched_frames_at_frame_count_edges(vo, o32, n, F):
         assert np.array_equal(bp.fetch("tri_pairs", i), po) and np.array_equal(bp.fetch("tri_app", i), ao), i
         assert np.array_equal(bp.fetch("tri_xyz", i), xo), i
     bp.close(); c.close()
+
+
+@pytest.mark.parametrize("n", [300, 3000, 9000])
+def test_matcher_with_non_finite_rows_and_radius_sweep(vo, ctx, o32, n):
+    """Rows holding NaN or +-inf can never satisfy d2 < r^2 (brute_force_search.h:22-41 read literally) and must not
+    disturb the bucketing of the finite rows, whatever the search form; the radius is a parameter, not a constant."""
+    fp = vo.synth.frame_pair(n, seed=8100 + n, distractors=n // 10)
+    a, b = fp["ref_app"].copy(), fp["cur_app"].copy()
+    rng = np.random.default_rng(n)
+    for arr in (a, b):
+        rows = rng.permutation(len(arr))[:45]
+        arr[rows[:15], rng.integers(0, 10, 15)] = np.nan
+        arr[rows[15:30], rng.integers(0, 10, 15)] = np.inf
+        arr[rows[30:40], rng.integers(0, 10, 10)] = -np.inf
+        arr[rows[40:45]] = np.nan                                  # whole rows
+    for radius in (0.1, 0.02, 0.45):
+        exp = o32.match(a, b, radius)
+        assert 0 < len(exp) < min(len(a), len(b))
+        for mode in (0, 1, 2, 3):
+            assert ctx.lib.vo_match_set_mode(ctx.h, mode) == 0
+            got = vo.compute_correspondences_images(a, b, radius, ctx=ctx)
+            assert np.array_equal(got, exp), (mode, radius, len(got), len(exp))
+    assert ctx.lib.vo_match_set_mode(ctx.h, 0) == 0
+    # fullSearch (all points inside the radius) on the same data
+    got = vo.radius_search(a, b, 0.1, ctx=ctx)
+    exp = o32.radius_search(a, b, 0.1, brute=True)
+    assert len(got) == len(exp) == len(b) and all(np.array_equal(g, e) for g, e in zip(got, exp))
