@@ -149,19 +149,40 @@ class Map:
                 self.pts.append(p); self.app.append(a)
 
 
+def id_correspondences(ids_ref, ids_cur):
+    """extract_correspondences_images of the known-association programs (vo_daKnown.cpp:20-35,
+    initialization_real_data.cpp:20-35): pairs (ref_idx, cur_idx) with equal landmark id, in ref order; both id lists are
+    ascending (the scan of the current frame stops at the first larger id), first hit wins."""
+    out = []
+    for i, a in enumerate(ids_ref):
+        for j, b in enumerate(ids_cur):
+            if b > a:
+                break
+            if b == a:
+                out.append((i, j))
+                break
+    return np.array(out, np.int32).reshape(-1, 2)
+
+
 def run_sequence(frames, K, rows, cols, zn, zf, rounds=100, o: Oracle | None = None, X0=None, kdtree=False,
-                 keep_map=True):
+                 keep_map=True, by_id=False):
     """The frame loop of vo_complete.cpp:97-181 on measurement sets held in memory: frames = list of (pts (n,2), app
     (n,10)).  X0: first relative pose to start the chain from (default: the epipolar initialisation).  kdtree: match
     with the reference's own PCA kd-tree restatement (oracle/vo_kdtree.c) instead of the double loop -- same pairs,
-    usable at 50k points.  Returns trajectory, per-frame (matches, joined, inliers) and, with keep_map, the map."""
+    usable at 50k points.  by_id: frames = list of (pts, ids) and the association is the known one (the loop of
+    vo_daKnown.cpp:96-160, which is the same loop with ids in place of appearances).  Returns trajectory, per-frame
+    (matches, joined, inliers) and, with keep_map, the map."""
     o = o or Oracle(32)
     match = (lambda a, b: o.match_kdtree(a, b)) if kdtree else (lambda a, b: o.match(a, b))
+    if by_id:
+        match = id_correspondences
+        keep_map = False
     ref_pts, ref_app = frames[0]
     cur_pts, cur_app = frames[1]
     corr = match(ref_app, cur_app)
     X = estimate_transform(o, K, corr, ref_pts, cur_pts) if X0 is None else np.asarray(X0, np.float32).reshape(4, 4).copy()
-    tri, corr_world, tri_app = o.triangulate(K, X, corr, ref_pts, cur_pts, cur_app)
+    app_of = (lambda a: None) if by_id else (lambda a: a)         # vo_daKnown triangulates without appearances
+    tri, corr_world, tri_app = o.triangulate(K, X, corr, ref_pts, cur_pts, app_of(cur_app))
     traj = [np.eye(4, dtype=np.float32), X.copy()]
     m = Map()
     if keep_map:
@@ -179,7 +200,7 @@ def run_sequence(frames, K, rows, cols, zn, zf, rounds=100, o: Oracle | None = N
         X_curr = r["T"]
         traj.append(X_curr.copy())
         stats.append((len(corr), len(corr_world), r["num_inliers"]))
-        tri, corr_world, tri_app = o.triangulate(K, X_curr, corr, ref_pts, cur_pts, cur_app)
+        tri, corr_world, tri_app = o.triangulate(K, X_curr, corr, ref_pts, cur_pts, app_of(cur_app))
         tri_counts.append(len(tri))
         if keep_map:
             m.update(o.transform_points(history, tri) if len(tri) else tri, tri_app)
@@ -200,6 +221,80 @@ def run_vo_complete(data_dir, rounds=100, o: Oracle | None = None, X0=None):
     map_pts = o.transform_points(H, np.array(m.pts, np.float32).reshape(-1, 3))
     return dict(trajectory=res["trajectory"], map=map_pts, map_app=np.array(m.app, np.float32).reshape(-1, 10), H=H,
                 stats=res["stats"])
+
+
+# ---- the reference's known-association programs (src/tests/) ------------------------------------
+def _dataset(data_dir):
+    files = sorted(f for f in os.listdir(data_dir) if re.search(r"^meas-\d.*\.dat$", f))
+    K, H, ints = read_camera(os.path.join(data_dir, "camera.dat"))
+    return files, K, H, (ints["height"], ints["width"], ints["z_near"], ints["z_far"])
+
+
+def run_picp_known_real(data_dir, rounds=1000, o: Oracle | None = None):
+    """picp_real_data_allKnown.cpp:64-89: landmark positions (world.dat) and association (the ids of the measurement files)
+    known.  Per frame: the world points are moved IN PLACE by the last estimate (first by H^-1), the solver starts from
+    the identity and runs `rounds` rounds on the pairs (measurement i, landmark id_i).  Returns the relative poses, H and
+    per-frame (correspondences, inliers)."""
+    o = o or Oracle(32)
+    files, K, H, (rows, cols, zn, zf) = _dataset(data_dir)
+    world, _ = read_world(os.path.join(data_dir, "world.dat"))
+    X = iso_inv(H.astype(np.float64)).astype(np.float32)
+    pts = world.copy()
+    traj, stats = [], []
+    for f in files:
+        meas, _, ids = read_meas(os.path.join(data_dir, f))
+        pts = o.transform_points(X, pts)
+        corr = np.stack([np.arange(len(ids)), ids], axis=1).astype(np.int32)
+        r = o.picp_solve(Camera(rows, cols, zn, zf, K, np.eye(4)), pts, meas, corr, rounds, 10000.0, False, trace=False)
+        X = r["T"]
+        traj.append(X.copy())
+        stats.append((len(corr), r["num_inliers"]))
+    return dict(trajectory=traj, H=H, stats=stats)
+
+
+def run_real_init(data_dir, o: Oracle | None = None):
+    """initialization_real_data.cpp:78-99: relative pose of the first two frames from the known association, the
+    triangulated points mapped by H.  Returns X, the pairs, the points and the landmark id of every point."""
+    o = o or Oracle(32)
+    files, K, H, _ = _dataset(data_dir)
+    p0, _, id0 = read_meas(os.path.join(data_dir, files[0]))
+    p1, _, id1 = read_meas(os.path.join(data_dir, files[1]))
+    corr = id_correspondences(id0, id1)
+    X = estimate_transform(o, K, corr, p0, p1)
+    xyz, pairs, _ = o.triangulate(K, X, corr, p0, p1)
+    return dict(X=X, corr=corr, points=o.transform_points(H, xyz), ids=id1[pairs[:, 0]], H=H, K=K, p0=p0, p1=p1)
+
+
+def run_vo_da_known(data_dir, rounds=1000, o: Oracle | None = None, X0=None):
+    """vo_daKnown.cpp:54-167: the whole loop with the association taken from the landmark ids."""
+    o = o or Oracle(32)
+    files, K, H, (rows, cols, zn, zf) = _dataset(data_dir)
+    frames = []
+    for f in files:
+        pts, _, ids = read_meas(os.path.join(data_dir, f))
+        frames.append((pts, ids))
+    res = run_sequence(frames, K, rows, cols, zn, zf, rounds, o, X0, by_id=True)
+    return dict(trajectory=res["trajectory"], H=H, stats=res["stats"], tri_counts=res["tri_counts"])
+
+
+def gt_errors(data_dir, trajectory, H, up_to_scale=False):
+    """robot trajectory of the estimate against trajectory.dat: per-pose max abs difference (4x4), after the evaluation's
+    median-ratio scale correction when the estimate is only defined up to scale (evaluate.cpp:40-60)."""
+    gt = read_gt(os.path.join(data_dir, "trajectory.dat"))
+    est = robot_trajectory(trajectory, H)
+    scale = 1.0
+    if up_to_scale:
+        ratio = []
+        for i in range(1, len(gt)):
+            Xr = np.linalg.inv(est[i - 1]) @ est[i]; Xg = np.linalg.inv(gt[i - 1]) @ gt[i]
+            if np.linalg.norm(Xg[:3, 3]) > 0:
+                ratio.append(np.linalg.norm(Xr[:3, 3]) / np.linalg.norm(Xg[:3, 3]))
+        scale = 1.0 / sorted(ratio)[len(ratio) // 2]
+    out = []
+    for g, e in zip(gt, est):
+        e = e.copy(); e[:3, 3] *= scale
+        out.append(float(np.abs(g - e).max()))
+    return np.array(out), scale
 
 
 def robot_trajectory(traj, H):
