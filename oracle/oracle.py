@@ -3,9 +3,11 @@
 TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and the
 cpu_baseline leg of bench.py; never by the product package.
 
-PARITY UNPINNED at kernel level (see vo_oracle_impl.h): the reference has no
-golden vectors for this path and needs Eigen3, which the image lacks.  Pinned
-end to end by the README metrics on example_data (oracle/vo_pipeline.py).
+PARITY PINNED BY KNOWN ANSWERS, UNPINNED AT THE BIT LEVEL (see vo_oracle_impl.h): the
+reference has no golden vectors and needs Eigen3, which the image lacks, so there is
+no reference build to compare bits with; its data directory carries the ground truth,
+and the oracle reproduces it through the reference's own known-association scenarios
+and the README metrics (oracle/vo_pipeline.py, tests/test_known_answers_cpu.py).
 
 All matrices cross this interface as numpy arrays in the usual mathematical
 (row, col) indexing; they are flattened column-major (Eigen's default layout)

@@ -7,9 +7,9 @@
  * cpu_baseline leg of bench.py.  The product (libvo_hip.so) never links,
  * loads or calls anything in this directory.
  *
- * PARITY UNPINNED (kernel level): see vo_oracle_impl.h.  The only numbers the
- * reference publishes for this path are the end-to-end README metrics on
- * example_data (README.md:74-79); oracle/vo_pipeline.py reproduces them.
+ * PARITY PINNED BY KNOWN ANSWERS, UNPINNED AT THE BIT LEVEL: see vo_oracle_impl.h.
+ * The reference's data directory holds the ground truth and its README the
+ * end-to-end metrics (README.md:74-79); oracle/vo_pipeline.py reproduces both.
  *
  * Build: make -C oracle   (gcc -O3 -ffp-contract=off, no -march: mirrors the
  * reference's "-O3 -DNDEBUG" x86-64 baseline build, CMakeLists.txt:6-7)
