@@ -74,8 +74,11 @@ inline IsometryPair essential2transformPair(const Matrix3f& E) {
   linalg::Mat3d U, V; double s[3];
   linalg::svd3(Ed, U, s, V);
   linalg::Mat3d R1 = V * w * U.transpose();
-  if (R1.det() < 0) {                                        // :154-159
-    linalg::svd3(-Ed, U, s, V);
+  // :154-159 -- the reference decomposes -E when det(R1) < 0.  -E = (-U) S V^T, so that second decomposition yields
+  // exactly -R1 (and -R2 below); negating U says the same without depending on how an SVD routine signs the vector
+  // of the (near-)zero singular value, which for an exactly rank-2 E is free.
+  if (R1.det() < 0) {
+    U = -U;
     R1 = V * w * U.transpose();
   }
   auto make = [&](const linalg::Mat3d& R) {

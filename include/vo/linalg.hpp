@@ -73,21 +73,46 @@ struct Mat3d {
 };
 
 // M = U diag(s) V^T, s descending, U and V orthogonal (full 3x3).
+// One-sided (Hestenes) Jacobi: plane rotations applied from the right make the columns of A = M V mutually orthogonal;
+// their norms are the singular values, the normalised columns the left singular vectors.  Unlike the eigen-decomposition of
+// M^T M this keeps small singular values and their vectors accurate RELATIVE to their own size -- the essential matrix has
+// one (near-)zero singular value, and its left singular vector enters the rotation candidates (epipolar_utils.cpp:154).
+// Columns whose norm vanishes against the largest get their left vector by orthogonal completion.
 inline void svd3(const Mat3d& M, Mat3d& U, double s[3], Mat3d& V) {
-  const Mat3d MtM = M.transpose() * M;
-  std::vector<double> a(9), ev, evec;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a[(size_t)i * 3 + j] = MtM.m[i][j];
-  jacobi_eigen_sym(3, a, ev, evec);
-  for (int c = 0; c < 3; ++c) {            // descending order
-    const int src = 2 - c;
-    s[c] = std::sqrt(std::max(0.0, ev[(size_t)src]));
-    for (int r = 0; r < 3; ++r) V.m[r][c] = evec[(size_t)r * 3 + src];
+  double A[3][3], W[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = M.m[i][j];
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double app = 0, aqq = 0, apq = 0;
+        for (int i = 0; i < 3; ++i) { app += A[i][p] * A[i][p]; aqq += A[i][q] * A[i][q]; apq += A[i][p] * A[i][q]; }
+        if (std::fabs(apq) <= 1e-17 * std::sqrt(app * aqq) || apq == 0.0) continue;
+        rotated = true;
+        const double zeta = (aqq - app) / (2.0 * apq);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+        for (int i = 0; i < 3; ++i) {
+          const double x = A[i][p], y = A[i][q];
+          A[i][p] = c * x - sn * y; A[i][q] = sn * x + c * y;
+          const double vx = W[i][p], vy = W[i][q];
+          W[i][p] = c * vx - sn * vy; W[i][q] = sn * vx + c * vy;
+        }
+      }
+    if (!rotated) break;
   }
-  const double tol = 1e-12 * std::max(s[0], 1e-300);
+  double nrm[3];
+  int order[3] = {0, 1, 2};
+  for (int j = 0; j < 3; ++j) nrm[j] = std::sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+  for (int i = 0; i < 2; ++i) for (int j = i + 1; j < 3; ++j) if (nrm[order[j]] > nrm[order[i]]) std::swap(order[i], order[j]);   // descending, stable
+  const double tol = 1e-13 * std::max(nrm[order[0]], 1e-300);
   int have = 0;
   for (int c = 0; c < 3; ++c) {
-    if (s[c] > tol) {
-      for (int r = 0; r < 3; ++r) U.m[r][c] = (M.m[r][0] * V.m[0][c] + M.m[r][1] * V.m[1][c] + M.m[r][2] * V.m[2][c]) / s[c];
+    const int j = order[c];
+    s[c] = nrm[j];
+    for (int r = 0; r < 3; ++r) V.m[r][c] = W[r][j];
+    if (nrm[j] > tol && have == c) {
+      for (int r = 0; r < 3; ++r) U.m[r][c] = A[r][j] / nrm[j];
       have = c + 1;
     }
   }

@@ -182,3 +182,74 @@ def test_point_cloud_update_follows_operator_equal(tmp_path):
                            os.path.join(HERE, "hostcheck", "point_cloud_update.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.split() == ["4", "2"], r.stdout
+
+
+# ---- host linear algebra of the epipolar initialisation (include/vo/epipolar.hpp, vo/linalg.hpp) ---------------------
+@pytest.fixture(scope="module")
+def epi():
+    so = os.path.join(HERE, "hostcheck", "libvo_epipolar_check.so")
+    src = os.path.join(HERE, "hostcheck", "epipolar_check.cpp")
+    root = os.path.join(HERE, "..")
+    deps = [src, os.path.join(root, "include", "vo", "epipolar.hpp"), os.path.join(root, "include", "vo", "linalg.hpp"),
+            os.path.join(root, "visual-odometry_amd", "csrc", "vo_math.h")]
+    if not os.path.exists(so) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                               "-I" + os.path.join(root, "include"), "-o", so, src])
+    return C.CDLL(so)
+
+
+def _estimate(epi, K, corr, p1, p2):
+    K = np.ascontiguousarray(np.asarray(K, np.float32).reshape(3, 3).T)       # column-major
+    corr = np.ascontiguousarray(corr, np.int32); p1 = np.ascontiguousarray(p1, np.float32); p2 = np.ascontiguousarray(p2, np.float32)
+    X = np.zeros(16, np.float32)
+    n_front = epi.hc_estimate_transform(p(K), p(corr), len(corr), p(p1), len(p1), p(p2), len(p2), p(X))
+    return X.reshape(4, 4).T.copy(), n_front
+
+
+def test_epipolar_initialisation_on_the_reference_data(epi, o32):
+    """The facade's host code on the first two frames of the reference's data directory with the known association
+    (initialization_real_data.cpp): against the ground truth of trajectory.dat and against the oracle's numpy restatement."""
+    from oracle import vo_pipeline as vp
+    data = os.path.join(HERE, "golden", "example_data", "data")
+    r = vp.run_real_init(data, o32)
+    X, n_front = _estimate(epi, r["K"], r["corr"], r["p0"], r["p1"])
+    assert n_front == len(r["corr"]) == 115
+    assert np.abs(X - r["X"]).max() < 2e-5                                  # Jacobi here, LAPACK there; both double inside
+    gt = vp.read_gt(os.path.join(data, "trajectory.dat"))
+    H = r["H"].astype(np.float64)
+    X_gt = np.linalg.inv(H) @ np.linalg.inv(gt[1]) @ gt[0] @ H
+    scale = np.linalg.norm(X_gt[:3, 3]) / np.linalg.norm(X[:3, 3])
+    assert np.abs(X[:3, :3] - X_gt[:3, :3]).max() < 2e-5 and np.abs(X[:3, 3] * scale - X_gt[:3, 3]).max() < 5e-5
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_epipolar_initialisation_recovers_a_synthetic_motion(epi, o32, vo, seed):
+    from oracle import vo_pipeline as vp
+    fp = vo.synth.frame_pair(400, seed=seed, noise_px=0.0, max_angle=0.2, max_t=0.5)
+    corr = fp["gt_matches"]
+    X, n_front = _estimate(epi, fp["K"], corr, fp["ref_pts"], fp["cur_pts"])
+    Xo = vp.estimate_transform(o32, fp["K"], corr, fp["ref_pts"], fp["cur_pts"])
+    assert n_front == len(corr)
+    assert np.abs(X - Xo).max() < 5e-5
+    Xg = fp["X_gt"].astype(np.float64)
+    t, tg = X[:3, 3] / np.linalg.norm(X[:3, 3]), Xg[:3, 3] / np.linalg.norm(Xg[:3, 3])
+    assert np.abs(X[:3, :3] - Xg[:3, :3]).max() < 1e-3 and float(t @ tg) > 0.9999   # pixel coordinates are float32
+
+
+def test_svd3_of_the_facade(epi):
+    rng = np.random.default_rng(5)
+    mats = [rng.normal(size=(3, 3)) for _ in range(20)]
+    mats.append(np.outer([1.0, 2.0, 3.0], [0.5, -1.0, 2.0]))               # rank 1
+    mats.append(np.diag([3.0, 3.0, 0.0]))                                  # repeated singular value, rank 2
+    mats.append(np.zeros((3, 3)))
+    for rel in (1e-6, 1e-9, 1e-12, 1e-15):                                  # a nearly vanishing singular value: an essential matrix
+        Q1, _ = np.linalg.qr(rng.normal(size=(3, 3))); Q2, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        mats.append(Q1 @ np.diag([2.0, 1.5, 2.0 * rel]) @ Q2.T)
+    for M in mats:
+        M = np.ascontiguousarray(M, np.float64)
+        U = np.zeros((3, 3)); V = np.zeros((3, 3)); s = np.zeros(3)
+        epi.hc_svd3(p(M), p(U), p(s), p(V))
+        assert np.allclose(U @ np.diag(s) @ V.T, M, atol=1e-12)
+        assert np.allclose(np.sort(s)[::-1], np.linalg.svd(M, compute_uv=False), atol=1e-12)
+        assert s[0] >= s[1] >= s[2] >= 0
+        assert np.allclose(U.T @ U, np.eye(3), atol=1e-12) and np.allclose(V.T @ V, np.eye(3), atol=1e-12)   # rank-deficient too
