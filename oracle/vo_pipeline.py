@@ -315,7 +315,8 @@ def evaluate(data_dir, res):
     for i in range(1, len(gt)):
         Xr = np.linalg.inv(est[i - 1]) @ est[i]; Xg = np.linalg.inv(gt[i - 1]) @ gt[i]
         e_th.append(np.trace(np.eye(3) - Xr[:3, :3].T @ Xg[:3, :3]))
-        ratio.append(np.linalg.norm(Xr[:3, 3]) / np.linalg.norm(Xg[:3, 3]))
+        with np.errstate(divide="ignore", invalid="ignore"):           # a zero ground-truth step gives inf, as in the reference
+            ratio.append(np.linalg.norm(Xr[:3, 3]) / np.linalg.norm(Xg[:3, 3]))
     r = sorted(ratio)[len(ratio) // 2]
     scale = 1.0 / r
     rmse_pos = np.sqrt(np.mean([np.linalg.norm(g[:3, 3] - e[:3, 3] * scale) ** 2 for g, e in zip(gt, est)]))

@@ -253,3 +253,62 @@ def test_svd3_of_the_facade(epi):
         assert np.allclose(np.sort(s)[::-1], np.linalg.svd(M, compute_uv=False), atol=1e-12)
         assert s[0] >= s[1] >= s[2] >= 0
         assert np.allclose(U.T @ U, np.eye(3), atol=1e-12) and np.allclose(V.T @ V, np.eye(3), atol=1e-12)   # rank-deficient too
+
+
+# ---- file readers / writers and the evaluation of the facade (include/vo/files.hpp, vo/evaluation.hpp) -----------------
+def test_files_and_evaluation_of_the_facade(tmp_path, o32):
+    """The host code a `vo_complete` + `evaluation` user runs around the GPU path, without a GPU: parse the reference's data
+    directory, write a trajectory, evaluate it -- against the Python restatement (oracle/vo_pipeline.py) on the same files."""
+    import re
+    from oracle import vo_pipeline as vp
+    root = os.path.join(HERE, "..")
+    data = os.path.join(HERE, "golden", "example_data", "data")
+    exe = str(tmp_path / "files_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(HERE, "hostcheck", "files_check.cpp"), "-o", exe])
+    res = vp.run_vo_complete(data, rounds=100, o=o32)
+    np.savetxt(tmp_path / "poses_in.txt", np.array(res["trajectory"]).reshape(-1, 16), fmt="%.9g")
+    np.savetxt(tmp_path / "map.txt", res["map"], fmt="%.9g")
+    np.savetxt(tmp_path / "map_appearances.txt", res["map_app"], fmt="%.9g")
+    r = subprocess.run([exe, data, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = {line.split()[0] + ("_" + line.split()[1] if line.startswith("meas") else ""): line.split() for line in r.stdout.splitlines()}
+    files = sorted(f for f in os.listdir(data) if re.search(r"^meas-\d.*\.dat$", f))
+    assert out["files"][1] == "121" and out["files"][3] == files[0] and out["files"][5] == files[-1]
+    w10 = np.arange(1, 11, dtype=np.float64)
+    for f in (files[0], files[-1]):
+        pts, app, ids = vp.read_meas(os.path.join(data, f))
+        m = out["meas_" + f]
+        assert int(m[3]) == len(ids) == int(m[11])
+        assert float(m[5]) == float(ids.sum())
+        s_uv = float((pts[:, 0].astype(np.float64) + 2.0 * pts[:, 1]).sum()); s_app = float((app.astype(np.float64) * w10).sum())
+        assert abs(float(m[7]) - s_uv) < 1e-9 * abs(s_uv) and abs(float(m[9]) - s_app) < 1e-9 * max(1.0, abs(s_app))
+        assert abs(float(m[12]) - (s_uv + s_app)) < 1e-9 * abs(s_uv)                  # the point-cloud reader: same numbers
+    world, wapp = vp.read_world(os.path.join(data, "world.dat"))
+    s_w = float((world.astype(np.float64) * [1.0, 2.0, 3.0]).sum()); s_wa = float((wapp.astype(np.float64) * w10).sum())
+    assert int(out["world"][2]) == len(world) == 1000
+    assert abs(float(out["world"][4]) - s_w) < 1e-9 * abs(s_w) and abs(float(out["world"][6]) - s_wa) < 1e-9 * max(1.0, abs(s_wa))
+    K, H, ints = vp.read_camera(os.path.join(data, "camera.dat"))
+    c = out["camera"]
+    assert [int(x) for x in c[2:6]] == [ints["z_near"], ints["z_far"], ints["width"], ints["height"]]
+    assert np.array_equal(np.array(c[7:16], np.float32).reshape(3, 3), K) and np.array_equal(np.array(c[17:33], np.float32).reshape(4, 4), H)
+    gt = vp.read_gt(os.path.join(data, "trajectory.dat"))
+    s_gt = sum(float((np.arange(1, 13).reshape(3, 4) * T[:3]).sum()) for T in gt)
+    assert int(out["gt"][2]) == len(gt) == 121 and abs(float(out["gt"][4]) - s_gt) < 1e-5 * abs(s_gt)      # float sin/cos there
+    gt_txt = np.loadtxt(tmp_path / "trajectory_gt.txt")
+    assert gt_txt.shape == (121, 3) and np.abs(gt_txt - np.array([T[:3, 3] for T in gt])).max() < 1e-5
+    # save_trajectory: the composition H C X^-1 C^-1 (float32 there, float64 here)
+    ref = vp.robot_trajectory(res["trajectory"], res["H"])
+    est = np.loadtxt(tmp_path / "trajectory_est_complete.txt")
+    assert est.shape == (121, 3) and np.abs(est - np.array([T[:3, 3] for T in ref])).max() < 2e-4
+    data_txt = np.loadtxt(tmp_path / "trajectory_est_data.txt").reshape(121, 4, 3)
+    assert np.abs(data_txt[:, 0] - est).max() < 1e-6 and np.abs(data_txt[:, 1:] - np.array([T[:3, :3] for T in ref])).max() < 2e-5
+    # evaluate.cpp's numbers
+    ev = vp.evaluate(data, res)
+    e = out["eval"]
+    assert int(e[2]) == 121 and int(e[12]) == ev["matched"]
+    assert abs(float(e[4])) < 1e-5                                                     # float32 noise, like the README's 5.3e-6
+    assert abs(float(e[6]) - ev["median_ratio_inv"]) < 1e-4 * ev["median_ratio_inv"]
+    assert abs(float(e[8]) - ev["rmse_position"]) < 2e-3 * ev["rmse_position"]
+    assert abs(float(e[10]) - ev["rmse_map"]) < 2e-3 * ev["rmse_map"]
+    perf = np.loadtxt(tmp_path / "out_performance.txt")
+    assert perf.shape == (120, 2)
