@@ -121,3 +121,41 @@ def test_matcher_with_non_finite_rows_and_radius_sweep(vo, ctx, o32, n):
     got = vo.radius_search(a, b, 0.1, ctx=ctx)
     exp = o32.radius_search(a, b, 0.1, brute=True)
     assert len(got) == len(exp) == len(b) and all(np.array_equal(g, e) for g, e in zip(got, exp))
+
+
+@pytest.mark.parametrize("seed,angle,t", [(41, 0.5, 0.8), (42, 0.3, 1.0), (43, 0.7, 0.4)])
+def test_general_motions(vo, ctx, o32, seed, angle, t):
+    """Rotations of tenths of a radian between the views (the other synthetic frames move by 0.05 rad): the first solver rounds
+    take large steps (v2tEuler far from the identity), the triangulation sees a general relative pose, the eight-point
+    initialisation a general essential matrix.  GPU against oracle and against the generating motion."""
+    from oracle import vo_pipeline as vp
+    fp = vo.synth.frame_pair(400, seed=seed, noise_px=0.0, max_angle=angle, max_t=t)
+    m = vo.compute_correspondences_images(fp["ref_app"], fp["cur_app"], ctx=ctx)
+    assert np.array_equal(m, fp["gt_matches"])
+    j = vo.extract_correspondences_world(m, fp["model_pairs"], ctx=ctx)
+    Xg = fp["X_gt"].astype(np.float64)
+    cam_o = OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4))
+    r = o32.picp_solve_raw(cam_o, fp["model"], fp["cur_pts"], j, 60, 10000.0, False)
+    for exact in (True, False):
+        s = vo.PICPSolver(ctx)
+        s.setExact(exact)
+        s.setKernelThreshold(10000.0)
+        s.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx), fp["model"], fp["cur_pts"])
+        T = []
+        for _ in range(60):
+            s.oneRound(j, False)
+            T.append(s.camera().worldInCameraPose().copy())
+        T = np.array(T)
+        if exact:
+            assert np.array_equal(T, r["T"])                              # every round of the descent, bit for bit
+        else:
+            assert np.abs(T - r["T"]).max() < 2e-4 and np.abs(T[-1] - r["T"][-1]).max() < 2e-5
+        assert np.abs(T[-1] - Xg).max() < 1e-4 and s.numInliers() == len(j)
+        s.close()
+    xyz, pairs, _ = vo.triangulate_points(fp["K"], fp["X_gt"], m, fp["ref_pts"], fp["cur_pts"], ctx=ctx)
+    e_xyz, e_pairs, _ = o32.triangulate(fp["K"], fp["X_gt"], m, fp["ref_pts"], fp["cur_pts"])
+    assert np.array_equal(pairs, e_pairs) and np.array_equal(xyz, e_xyz)
+    X = vo.estimate_transform(fp["K"], m, fp["ref_pts"], fp["cur_pts"], ctx=ctx)
+    Xo = vp.estimate_transform(o32, fp["K"], m, fp["ref_pts"], fp["cur_pts"])
+    d, dg = X[:3, 3] / np.linalg.norm(X[:3, 3]), Xg[:3, 3] / np.linalg.norm(Xg[:3, 3])
+    assert np.abs(X - Xo).max() < 5e-5 and np.abs(X[:3, :3] - Xg[:3, :3]).max() < 1e-4 and float(d @ dg) > 1 - 1e-7

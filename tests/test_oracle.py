@@ -231,3 +231,34 @@ def test_radius_search_kdtree_equals_brute_force(o32):
     b = o32.radius_search(lat, lat[:100], 0.0625, brute=True)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     assert [len(x) for x in o32.radius_search(np.zeros((0, 10), np.float32), base[:3])] == [0, 0, 0]
+
+
+@pytest.mark.parametrize("seed,angle,t", [(41, 0.5, 0.8), (42, 0.3, 1.0), (43, 0.7, 0.4)])
+def test_general_motions_have_their_analytic_answers(o32, o64, vo, seed, angle, t):
+    """Large rotations / translations (the other synthetic tests move the camera by 0.05 rad / 0.1): triangulation recovers
+    the generating points, the solver converges to the generating pose from the identity, the eight-point initialisation
+    recovers rotation and translation direction -- formulas that are only right for small motions would fail here."""
+    from oracle import vo_pipeline as vp
+    fp = vo.synth.frame_pair(400, seed=seed, noise_px=0.0, max_angle=angle, max_t=t)
+    m = o32.match(fp["ref_app"], fp["cur_app"])
+    assert np.array_equal(m, fp["gt_matches"])
+    Xg = fp["X_gt"].astype(np.float64)
+    assert np.abs(Xg[:3, :3] - np.eye(3)).max() > 0.05                     # a motion worth the name
+    for o in (o64, o32):
+        xyz, pairs, _ = o.triangulate(fp["K"], fp["X_gt"], m, fp["ref_pts"], fp["cur_pts"])
+        model_of_ref = dict(fp["model_pairs"].tolist())
+        ref_of_cur = {c: r for r, c in m.tolist()}
+        truth = np.array([fp["model"][model_of_ref[ref_of_cur[c]]] for c in pairs[:, 0]])
+        e = np.abs(xyz - truth).max(axis=1)
+        assert len(pairs) == len(m)
+        if o is o64:
+            assert e.max() < 5e-3                                          # the pixel coordinates are float32
+        else:                                                              # float32 depth from a short baseline: far points are loose
+            assert np.median(e) < 2e-3 and np.quantile(e, 0.95) < 0.1
+    j = o32.join(m, fp["model_pairs"])
+    r = o32.picp_solve(Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4)), fp["model"], fp["cur_pts"], j, 60,
+                       10000.0, False, trace=False)
+    assert np.abs(r["T"] - Xg).max() < 1e-4 and r["num_inliers"] == len(j)
+    X = vp.estimate_transform(o32, fp["K"], m, fp["ref_pts"], fp["cur_pts"]).astype(np.float64)
+    d, dg = X[:3, 3] / np.linalg.norm(X[:3, 3]), Xg[:3, 3] / np.linalg.norm(Xg[:3, 3])
+    assert np.abs(X[:3, :3] - Xg[:3, :3]).max() < 1e-4 and float(d @ dg) > 1 - 1e-7
