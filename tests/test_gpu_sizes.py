@@ -159,3 +159,20 @@ def test_general_motions(vo, ctx, o32, seed, angle, t):
     Xo = vp.estimate_transform(o32, fp["K"], m, fp["ref_pts"], fp["cur_pts"])
     d, dg = X[:3, 3] / np.linalg.norm(X[:3, 3]), Xg[:3, 3] / np.linalg.norm(Xg[:3, 3])
     assert np.abs(X - Xo).max() < 5e-5 and np.abs(X[:3, :3] - Xg[:3, :3]).max() < 1e-4 and float(d @ dg) > 1 - 1e-7
+
+
+@pytest.mark.parametrize("scale,offset,radius", [(100.0, 5000.0, 10.0), (1e-3, 0.0, 1e-4), (1.0, -3e4, 0.1), (255.0, 0.0, 20.0)])
+def test_matcher_on_scaled_and_shifted_descriptors(vo, ctx, o32, scale, offset, radius):
+    """Descriptors need not live in [-1, 1]: the bucketing of the pruned searches derives its cells from the data's bounds and
+    the radius, and an offset of 3e4 leaves about 3 decimal digits below the radius in float32 -- the search must still return the
+    oracle's pairs (distances are evaluated on the same float values on both sides)."""
+    fp = vo.synth.frame_pair(4000, seed=8800, distractors=200)
+    a = (fp["ref_app"].astype(np.float64) * scale + offset).astype(np.float32)
+    b = (fp["cur_app"].astype(np.float64) * scale + offset).astype(np.float32)
+    exp = o32.match(a, b, radius)
+    assert len(exp) > 3000
+    for mode in (0, 1, 2, 3):
+        assert ctx.lib.vo_match_set_mode(ctx.h, mode) == 0
+        got = vo.compute_correspondences_images(a, b, radius, ctx=ctx)
+        assert np.array_equal(got, exp), (mode, len(got), len(exp))
+    assert ctx.lib.vo_match_set_mode(ctx.h, 0) == 0
