@@ -182,3 +182,35 @@ def test_cpp_resident_sequence_equals_frame_by_frame(vo, seq_run, tmp_path):
         x, y = np.loadtxt(a + name), np.loadtxt(b + name)
         assert x.shape == y.shape, name
         assert np.array_equal(x, y), (name, float(np.abs(x - y).max()))
+
+
+@pytest.mark.parametrize("case", ["normal", "empty5", "foreign5", "tiny5", "empty_last"])
+def test_degenerate_sequences_follow_the_reference_loop(vo, ctx, o32, case):
+    """Tracking lost in the middle of a sequence: a frame without measurements, a frame whose appearances match nothing, a
+    frame of three points, an empty last frame.  The reference's loop has no special case for any of them (zero
+    correspondences leave the pose at the identity, a zero baseline makes the next triangulation degenerate, NaN points
+    poison the poses after that); the device-resident chain, with the solver in reference-order arithmetic, must do
+    exactly the same: counts equal, finite poses bit-identical, NaN where the oracle's loop has NaN."""
+    from oracle import vo_pipeline as vp
+    seq = vo.synth.sequence(seed=3100, n_frames=12, n_visible=600)
+    fr = seq["frames"]
+    empty = dict(ids=np.zeros(0, np.int64), pts=np.zeros((0, 2), np.float32), app=np.zeros((0, 10), np.float32))
+    if case == "empty5":
+        fr[5] = empty
+    if case == "empty_last":
+        fr[11] = empty
+    if case == "foreign5":
+        fr[5] = dict(ids=fr[5]["ids"], pts=fr[5]["pts"], app=np.random.default_rng(1).uniform(5, 6, fr[5]["app"].shape).astype(np.float32))
+    if case == "tiny5":
+        fr[5] = dict(ids=fr[5]["ids"][:3], pts=fr[5]["pts"][:3].copy(), app=fr[5]["app"][:3].copy())
+    sp = vo.SequencePipeline(ctx, seq, n_iters=30, exact=True)
+    sp.run()
+    traj, counts = sp.trajectory(), sp.counts()
+    sp.close()
+    res = vp.run_sequence([(f["pts"], f["app"]) for f in fr], seq["K"], seq["rows"], seq["cols"], seq["z_near"], seq["z_far"], 30, o32,
+                          X0=traj[1], keep_map=False)
+    ref = np.array(res["trajectory"], np.float32)
+    assert np.array_equal(counts[2:, :2], np.array([s[:2] for s in res["stats"]]))         # matches, joined pairs
+    assert np.array_equal(counts[1:, 2], np.array(res["tri_counts"]))                       # triangulated points
+    assert np.array_equal(np.isnan(traj), np.isnan(ref)) and np.array_equal(traj, ref, equal_nan=True)
+    assert np.isfinite(ref).all() == (case in ("normal", "tiny5", "empty_last"))            # the lost frames do poison the rest

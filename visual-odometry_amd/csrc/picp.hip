@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void picp_pack_kernel(const int32_t* __restric
     const int k = threadIdx.x;
     S->pose[0][k] = k < 9 ? T0[(k % 3) + 4 * (k / 3)] : T0[12 + (k - 9)];
   }
-  const float qnan = __int_as_float(0x7fc00000);
+  const float qnan = __int_as_float((int)VO_DROPPED_BITS);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int m = pairs[2 * i];       // .first  -> measurement (picp_solver.cpp:66)
     const int w = pairs[2 * i + 1];   // .second -> world point (picp_solver.cpp:67)
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
     else v = (k < 9 && (k % 4) == 0) ? 1.f : 0.f;
     a.states[p].pose[0][k] = v;
   }
-  const float qnan = __int_as_float(0x7fc00000);
+  const float qnan = __int_as_float((int)VO_DROPPED_BITS);
   for (int i = fb.b * 256 + threadIdx.x; i < n; i += fb.nb * 256) {
     const int m = pairs[2 * i], w = pairs[2 * i + 1];
     float x = qnan, y = 0.f, z = 0.f, u = 0.f, v = 0.f;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
       x = world[3 * (size_t)w]; y = world[3 * (size_t)w + 1]; z = world[3 * (size_t)w + 2];
       u = meas[2 * (size_t)m]; v = meas[2 * (size_t)m + 1];
     } else if (a.n_bad) {
-      atomicAdd(&a.n_bad[p], 1);        // dropped (NaN marker) and counted: reported in stats_out[4p + 3]
+      atomicAdd(&a.n_bad[p], 1);        // dropped (marker) and counted: reported in stats_out[4p + 3]
     }
     dst[i] = x; dst[a.cap + i] = y; dst[2 * a.cap + i] = z; dst[3 * a.cap + i] = u; dst[4 * a.cap + i] = v;
   }

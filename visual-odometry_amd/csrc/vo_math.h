@@ -24,6 +24,13 @@ namespace vo {
 
 VO_HD float vo_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// A correspondence whose index lies outside its point array is DROPPED by the gather kernels: its world x carries this
+// bit pattern (a quiet NaN with a payload no arithmetic produces) and the linearisation skips it.  A world point that
+// really is NaN is not such a marker: it goes through the arithmetic like in the reference (and poisons the pose, like
+// in the reference).
+constexpr uint32_t VO_DROPPED_BITS = 0x7fc0d0d0u;
+VO_HD bool is_dropped(float wx) { return __builtin_bit_cast(uint32_t, wx) == VO_DROPPED_BITS; }
+
 // Eigen 3.4 sums a fixed-size, non-vectorised 3-term inner product as
 // x0 + (x1 + x2) (Core/Redux.h, redux_novec_unroller).
 VO_HD float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
@@ -150,7 +157,7 @@ VO_HD bool is_pinhole(const float K[9]) {
 // Written without divergent control flow: the reference's "continue"/"if"
 // decisions become predicates, and a term that must not contribute has the
 // inputs of its Jacobian zeroed so that no inf/nan of a rejected projection
-// can reach an accumulator.  A NaN world x marks a dropped correspondence.
+// can reach an accumulator.  A world x of VO_DROPPED_BITS marks a dropped correspondence.
 //
 // Decisions (depth/image gates, chi^2 test) use the reference's operation
 // order without FMA.  The accumulators use one FMA per product:
@@ -174,7 +181,7 @@ VO_HD void picp_accumulate_t(const CamK& cam, const Pose& T, float thr, float wx
   float iz = 1.0f / ph[2];                                              // camera.h:31, picp_solver.cpp:44
   const float u = ph[0] * iz, v = ph[1] * iz;
   const bool in_img = !(u < 0.f || u > (float)(cam.cols - 1)) && !(v < 0.f || v > (float)(cam.rows - 1));
-  const bool ok = z_ok && in_img && (wx == wx);                         // :32-34, :72-73
+  const bool ok = z_ok && in_img && !is_dropped(wx);                    // :32-34, :72-73
   float e0 = u - zu, e1 = v - zv;                                       // :35
   const float chi = e0 * e0 + e1 * e1;                                  // :75
   const bool inl = ok && !(chi > thr);                                  // :78 (strict >)
@@ -260,7 +267,7 @@ VO_HD int picp_term_exact(const CamK& cam, const Pose& T, float thr, float wx, f
                           float zv, float term[NTERM]) {
   float pc[3], ph[3];
   pose_apply(T, wx, wy, wz, pc[0], pc[1], pc[2]);                       // camera.h:27
-  if (!(wx == wx)) return 0;                                            // dropped correspondence (pack marker)
+  if (is_dropped(wx)) return 0;                                         // dropped correspondence (pack marker)
   if (pc[2] > (float)cam.z_far || pc[2] < (float)cam.z_near) return 0;  // camera.h:28
   mat3_vec(cam.K, 3, pc, ph);                                           // camera.h:30
   const float iz = 1.0f / ph[2];                                        // camera.h:31, picp_solver.cpp:44

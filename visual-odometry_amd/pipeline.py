@@ -272,8 +272,10 @@ class SequencePipeline:
     (PointCloudVector::update) is host code in the C++ application and not part of this chain."""
 
     def __init__(self, ctx: Context, seq: dict, n_iters: int = 100, kernel_threshold: float = 10000.0,
-                 keep_appearance: bool = False, matches: list | None = None, overlap_match: bool = False):
-        """matches: optional precomputed appearance matches, matches[t-1] = (n,2) int32 pairs
+                 keep_appearance: bool = False, matches: list | None = None, overlap_match: bool = False, exact: bool = False):
+        """exact: the solver in reference-order arithmetic (vo_picp_set_exact): the whole chain is then bit-identical to the
+        float32 CPU restatement of the loop started from the same first relative pose.
+        matches: optional precomputed appearance matches, matches[t-1] = (n,2) int32 pairs
         (idx in frame t-1, idx in frame t) for t = 1..F-1 -- e.g. computed up front, sharded over several
         GPUs (dist.gather_ragged); the chain then skips its own matcher launches.
         overlap_match: the matcher of frame t+1 depends on the appearances alone; run it on a second
@@ -325,6 +327,7 @@ class SequencePipeline:
         self.solver = h
         _chk(self.lib.vo_picp_set_camera(h, *map(C.c_int, self.cam), _ptr(self.K), _ptr(_colmajor(np.eye(4), 4))))
         _chk(self.lib.vo_picp_set_kernel_threshold(h, C.c_float(kernel_threshold)))
+        _chk(self.lib.vo_picp_set_exact(h, C.c_int(1 if exact else 0)))
         p = C.c_void_p()
         _chk(self.lib.vo_picp_pose_dev_ptr(h, C.byref(p)))
         self.d_pose = p.value
