@@ -176,3 +176,44 @@ def test_matcher_on_scaled_and_shifted_descriptors(vo, ctx, o32, scale, offset, 
         got = vo.compute_correspondences_images(a, b, radius, ctx=ctx)
         assert np.array_equal(got, exp), (mode, len(got), len(exp))
     assert ctx.lib.vo_match_set_mode(ctx.h, 0) == 0
+
+
+def test_non_finite_points_go_through_like_in_the_reference(vo, ctx, o32):
+    """NaN / inf coordinates: the reference's gates are written as `if (x < lo || x > hi) reject`, which a NaN PASSES (every
+    comparison is false) -- a NaN point is projected "inside", triangulated "in front", and carried on.  Same here, element for
+    element (NaN where the oracle has NaN, equal bits elsewhere, equal counts)."""
+    fp = vo.synth.frame_pair(600, seed=8900)
+    rng = np.random.default_rng(3)
+    world = fp["model"].copy()
+    bad = rng.permutation(len(world))[:30]
+    world[bad[:10], rng.integers(0, 3, 10)] = np.nan
+    world[bad[10:20], rng.integers(0, 3, 10)] = np.inf
+    world[bad[20:30], rng.integers(0, 3, 10)] = -np.inf
+    same = lambda a, b: a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a, b, equal_nan=True)
+    assert same(vo.transform_points(fp["X_gt"], world, ctx=ctx), o32.transform_points(fp["X_gt"], world))
+    cam = vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], fp["X_gt"], ctx=ctx)
+    cam_o = OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], fp["X_gt"])
+    for keep in (True, False):
+        uv, n_in = cam.projectPoints(world, keep_indices=keep)
+        e_uv, e_in = o32.project_points(cam_o, world, keep_indices=keep)
+        assert n_in == e_in and same(uv, e_uv), keep
+    assert np.isnan(e_uv).any()                                            # a NaN point did pass the gates
+    p1, p2 = fp["ref_pts"].copy(), fp["cur_pts"].copy()
+    p1[bad[:10], 0] = np.nan; p2[bad[10:20], 1] = np.inf; p1[bad[20:25], 1] = -np.inf
+    m = fp["gt_matches"]
+    xyz, pairs, app = vo.triangulate_points(fp["K"], fp["X_gt"], m, p1, p2, fp["cur_app"], ctx=ctx)
+    e_xyz, e_pairs, e_app = o32.triangulate(fp["K"], fp["X_gt"], m, p1, p2, fp["cur_app"])
+    assert np.array_equal(pairs, e_pairs) and np.array_equal(app, e_app) and same(xyz, e_xyz)
+    assert np.isnan(e_xyz).any()
+    # the solver: a NaN landmark among the correspondences poisons H, b and the pose, in both arithmetic modes, like the oracle's loop
+    j = vo.extract_correspondences_world(m, fp["model_pairs"], ctx=ctx)
+    r = o32.picp_solve_raw(OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4)), world, fp["cur_pts"], j, 3, 10000.0, False)
+    assert np.isnan(r["T"][-1]).any()
+    for exact in (True, False):
+        s = vo.PICPSolver(ctx)
+        s.setExact(exact); s.setKernelThreshold(10000.0)
+        s.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx), world, fp["cur_pts"])
+        s.solve(j, False, 3)
+        T = s.camera().worldInCameraPose()
+        assert np.array_equal(np.isnan(T), np.isnan(r["T"][-1])), exact
+        s.close()
