@@ -266,3 +266,48 @@ def test_batched_solver_reports_bad_indices(vo, ctx, o32, form):
         r = o32.picp_solve(OCam(480, 640, 0, 10, fps[p]["K"], np.eye(4)), fps[p]["model"], fps[p]["cur_pts"], pairs[p][ok],
                            8, 10000.0, False, trace=False)
         assert int(st[p, 2]) == r["num_inliers"] and np.abs(T[p].reshape(4, 4).T - r["T"]).max() < 1e-4
+
+
+def test_contexts_on_concurrent_host_threads(vo, o32):
+    """One context per host thread, four threads driving the whole frame (match -> join -> rounds -> triangulate) at the same
+    time through the C ABI (ctypes releases the GIL inside every call): the library keeps no state outside its handles, so every
+    thread must get exactly the single-threaded result of its own frame."""
+    import threading
+    fps = [vo.synth.frame_pair(3000 + 500 * k, seed=9100 + k, drop=0.05, distractors=30, model_drop=0.05) for k in range(4)]
+
+    def frame(ctx, fp):
+        m = vo.compute_correspondences_images(fp["ref_app"], fp["cur_app"], ctx=ctx)
+        j = vo.extract_correspondences_world(m, fp["model_pairs"], ctx=ctx)
+        s = vo.PICPSolver(ctx)
+        s.setKernelThreshold(10000.0)
+        s.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx), fp["model"], fp["cur_pts"])
+        s.solve(j, False, 15)
+        T = s.camera().worldInCameraPose().copy()
+        n_in = s.numInliers()
+        s.close()
+        xyz, pairs, app = vo.triangulate_points(fp["K"], T, m, fp["ref_pts"], fp["cur_pts"], fp["cur_app"], ctx=ctx)
+        return (m.tobytes(), j.tobytes(), T.tobytes(), n_in, xyz.tobytes(), pairs.tobytes(), app.tobytes())
+
+    c0 = vo.Context(0)
+    expect = [frame(c0, fp) for fp in fps]
+    c0.close()
+    for k, fp in enumerate(fps):                       # anchored on the oracle, not only on itself
+        assert np.array_equal(np.frombuffer(expect[k][0], np.int32).reshape(-1, 2), o32.match(fp["ref_app"], fp["cur_app"]))
+    errors = []
+
+    def worker(k):
+        try:
+            ctx = vo.Context(0)
+            for _ in range(12):
+                got = frame(ctx, fps[k])
+                if got != expect[k]:
+                    errors.append((k, [a == b for a, b in zip(got, expect[k])]))
+                    break
+            ctx.close()
+        except Exception as e:                        # noqa: BLE001 -- reported through the assertion below
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads) and not errors, errors

@@ -366,7 +366,8 @@ int vo_project_points(vo_ctx* c, int rows, int cols, int z_near, int z_far, cons
   VO_HIP_CHECK(hipMemcpyAsync(h, c->counts.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   VO_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (h[0] > 0)
-    VO_HIP_CHECK(hipMemcpy(out_uv, c->out[0].p, sizeof(float) * 2 * (size_t)h[0], hipMemcpyDeviceToHost));
+    VO_HIP_CHECK(hipMemcpyAsync(out_uv, c->out[0].p, sizeof(float) * 2 * (size_t)h[0], hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (n_out) *n_out = h[0];
   if (n_inside) *n_inside = h[1];
   return VO_OK;
@@ -867,7 +868,8 @@ int vo_match_appearances(vo_ctx* c, const float* a1, int n1, const float* a2, in
   int h = 0;
   VO_HIP_CHECK(hipMemcpyAsync(&h, c->counts.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   VO_HIP_CHECK(hipStreamSynchronize(c->stream));
-  if (h > 0) VO_HIP_CHECK(hipMemcpy(out_pairs, c->out[0].p, sizeof(int32_t) * 2 * (size_t)h, hipMemcpyDeviceToHost));
+  if (h > 0) VO_HIP_CHECK(hipMemcpyAsync(out_pairs, c->out[0].p, sizeof(int32_t) * 2 * (size_t)h, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
   *n_out = h;
   return VO_OK;
 }
@@ -955,7 +957,8 @@ int vo_join_correspondences(vo_ctx* c, const int32_t* img, int n_img, const int3
   int h = 0;
   VO_HIP_CHECK(hipMemcpyAsync(&h, c->counts.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   VO_HIP_CHECK(hipStreamSynchronize(c->stream));
-  if (h > 0) VO_HIP_CHECK(hipMemcpy(out, c->out[0].p, sizeof(int32_t) * 2 * (size_t)h, hipMemcpyDeviceToHost));
+  if (h > 0) VO_HIP_CHECK(hipMemcpyAsync(out, c->out[0].p, sizeof(int32_t) * 2 * (size_t)h, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
   *n_out = h;
   return VO_OK;
 }
@@ -992,7 +995,8 @@ int vo_radius_search(vo_ctx* c, const float* tree, int n_tree, const float* qry,
   if (*n_total > capacity)
     return fail(VO_ERR_INVALID_ARG, "vo_radius_search: %d hits, room for %d", *n_total, capacity);
   if (*n_total > 0)
-    VO_HIP_CHECK(hipMemcpy(indices, c->out[1].p, sizeof(int32_t) * (size_t)*n_total, hipMemcpyDeviceToHost));
+    VO_HIP_CHECK(hipMemcpyAsync(indices, c->out[1].p, sizeof(int32_t) * (size_t)*n_total, hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
   return VO_OK;
 }
 
@@ -1065,9 +1069,10 @@ int vo_triangulate(vo_ctx* c, const float K[9], const float X[16], const int32_t
   VO_HIP_CHECK(hipMemcpyAsync(&h, c->counts.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   VO_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (h > 0) {
-    VO_HIP_CHECK(hipMemcpy(out_xyz, c->out[0].p, sizeof(float) * 3 * (size_t)h, hipMemcpyDeviceToHost));
-    if (out_pairs) VO_HIP_CHECK(hipMemcpy(out_pairs, c->out[1].p, sizeof(int32_t) * 2 * (size_t)h, hipMemcpyDeviceToHost));
-    if (want_app) VO_HIP_CHECK(hipMemcpy(out_app, c->out[2].p, sizeof(float) * 10 * (size_t)h, hipMemcpyDeviceToHost));
+    VO_HIP_CHECK(hipMemcpyAsync(out_xyz, c->out[0].p, sizeof(float) * 3 * (size_t)h, hipMemcpyDeviceToHost, c->stream));
+    if (out_pairs) VO_HIP_CHECK(hipMemcpyAsync(out_pairs, c->out[1].p, sizeof(int32_t) * 2 * (size_t)h, hipMemcpyDeviceToHost, c->stream));
+    if (want_app) VO_HIP_CHECK(hipMemcpyAsync(out_app, c->out[2].p, sizeof(float) * 10 * (size_t)h, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP_CHECK(hipStreamSynchronize(c->stream));
   }
   *n_out = h;
   return VO_OK;

@@ -323,7 +323,10 @@ int vo_kdtree_fast_search(vo_kdtree* t, const float* qry, int nq, float radius, 
   KD_CHECK(hipStreamSynchronize(st));
   *n_total = offsets[nq];
   if (*n_total > capacity) return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_fast_search: %d hits, room for %d", *n_total, capacity);
-  if (*n_total > 0) KD_CHECK(hipMemcpy(indices, t->d_i, sizeof(int32_t) * (size_t)*n_total, hipMemcpyDeviceToHost));
+  if (*n_total > 0) {
+    KD_CHECK(hipMemcpyAsync(indices, t->d_i, sizeof(int32_t) * (size_t)*n_total, hipMemcpyDeviceToHost, st));
+    KD_CHECK(hipStreamSynchronize(st));
+  }
   return VO_OK;
 }
 
