@@ -142,3 +142,33 @@ def test_cell_hash_matcher_beyond_the_staging_budgets(vo, o32, n, drop):
     m_o = o32.match_kdtree(fp["ref_app"], fp["cur_app"])
     assert np.array_equal(m, m_o) and len(m) > 0.85 * n
     c.close()
+
+
+@pytest.mark.parametrize("dist", ["cluster", "line", "heavy_tail", "duplicates"])
+def test_pruned_searches_equal_the_full_scan_on_hostile_distributions(vo, dist):
+    """Distributions that defeat the bucketing (a coarse bin holding more points than a 16-bit relative start or the LDS
+    staging can take, all spread in one component, outliers stretching the grid, thousands of exact duplicates): the pruned
+    searches fall back to their global-memory walks and must still return the pairs of the full scan (mode 1, itself checked
+    against the oracle elsewhere), exact ties to the lowest index included."""
+    rng = np.random.default_rng(11)
+    n = 80000
+    if dist == "cluster":
+        a = np.concatenate([rng.normal(0.0, 0.01, (70000, 10)), rng.uniform(-1, 1, (n - 70000, 10))])
+    elif dist == "line":
+        a = np.zeros((n, 10)); a[:, 7] = rng.uniform(-50, 50, n); a += rng.normal(0, 1e-3, (n, 10))
+    elif dist == "heavy_tail":
+        a = rng.standard_cauchy((n, 10)) * 0.05
+    else:
+        base = rng.uniform(-1, 1, (4000, 10)); a = base[rng.integers(0, 4000, n)]
+    a = a.astype(np.float32)
+    perm = rng.permutation(n)
+    b = (a[perm].astype(np.float64) + (0 if dist == "duplicates" else rng.normal(0, 2e-3, (n, 10)))).astype(np.float32)
+    b = b[: n - 5000]                                                     # unequal set sizes: the larger one is searched
+    res = []
+    for mode in (1, 2, 3):
+        c = vo.Context(0)
+        assert c.lib.vo_match_set_mode(c.h, mode) == 0
+        res.append(vo.compute_correspondences_images(a, b, ctx=c))
+        c.close()
+    assert len(res[0]) > 0.5 * len(b)
+    assert np.array_equal(res[1], res[0]) and np.array_equal(res[2], res[0])
