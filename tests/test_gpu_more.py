@@ -311,3 +311,42 @@ def test_contexts_on_concurrent_host_threads(vo, o32):
     for t in threads: t.start()
     for t in threads: t.join(timeout=300)
     assert not any(t.is_alive() for t in threads) and not errors, errors
+
+
+def test_two_solvers_interleaved_on_one_context(vo, ctx, o32):
+    """Two PICPSolver handles of one context used alternately, round by round, each on its own problem and with its own
+    correspondences / threshold / arithmetic mode: nothing of one may leak into the other (cached correspondences, captured
+    graphs, partial buffers are per handle)."""
+    fa = vo.synth.frame_pair(2500, seed=9200, drop=0.05, distractors=10, model_drop=0.05)
+    fb = vo.synth.frame_pair(900, seed=9201)
+    probs = []
+    for fp, thr, keep, exact in ((fa, 10000.0, False, False), (fb, 40.0, True, True)):
+        m = vo.compute_correspondences_images(fp["ref_app"], fp["cur_app"], ctx=ctx)
+        j = vo.extract_correspondences_world(m, fp["model_pairs"], ctx=ctx)
+        probs.append((fp, j, thr, keep, exact))
+
+    def make(fp, thr, exact):
+        s = vo.PICPSolver(ctx)
+        s.setKernelThreshold(thr); s.setExact(exact)
+        s.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx), fp["model"], fp["cur_pts"])
+        return s
+
+    alone = []
+    for fp, j, thr, keep, exact in probs:
+        s = make(fp, thr, exact)
+        T = []
+        for _ in range(10):
+            s.oneRound(j, keep); T.append(s.camera().worldInCameraPose().tobytes())
+        alone.append(T); s.close()
+    solvers = [make(fp, thr, exact) for fp, j, thr, keep, exact in probs]
+    both = [[], []]
+    for _ in range(10):
+        for k, (fp, j, thr, keep, exact) in enumerate(probs):
+            solvers[k].oneRound(j, keep)
+        for k in (1, 0):
+            both[k].append(solvers[k].camera().worldInCameraPose().tobytes())
+    for s in solvers: s.close()
+    assert both == alone
+    fp, j, thr, keep, _ = probs[1]                                          # and the exact one is the oracle's, bit for bit
+    r = o32.picp_solve_raw(OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4)), fp["model"], fp["cur_pts"], j, 10, thr, keep)
+    assert alone[1][-1] == r["T"][-1].astype(np.float32).tobytes()
