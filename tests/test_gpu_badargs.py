@@ -1,0 +1,97 @@
+"""Invalid arguments at the C ABI: every host-pointer entry point is called with one argument broken at a time (NULL where
+an array or a result is required, a negative count, a NULL handle) and must come back with a negative status and a message --
+never a crash, never VO_OK.  The reference has undefined behaviour for all of these; a drop-in library must not."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_invalid_arguments_are_refused_one_by_one(vo, ctx):
+    lib, h = ctx.lib, ctx.h
+    fp = vo.synth.frame_pair(300, seed=9300)
+    K = np.ascontiguousarray(fp["K"].astype(np.float32).T); T = np.ascontiguousarray(np.eye(4, dtype=np.float32))
+    world = np.ascontiguousarray(fp["model"], np.float32); uv = np.ascontiguousarray(fp["cur_pts"], np.float32)
+    a1 = np.ascontiguousarray(fp["ref_app"], np.float32); a2 = np.ascontiguousarray(fp["cur_app"], np.float32)
+    p1 = np.ascontiguousarray(fp["ref_pts"], np.float32)
+    pairs = np.ascontiguousarray(fp["gt_matches"], np.int32); mp = np.ascontiguousarray(fp["model_pairs"], np.int32)
+    n = len(world)
+    out2 = np.zeros((n, 2), np.float32); out3 = np.zeros((n, 3), np.float32); outp = np.zeros((n, 2), np.int32); outa = np.zeros((n, 10), np.float32)
+    offs = np.zeros(n + 1, np.int32); idx = np.zeros(8 * n, np.int32); X = np.zeros(16, np.float32)
+    n_out, n_in = C.c_int(), C.c_int()
+    I, F, NUL = C.c_int, C.c_float, C.c_void_p(0)
+    calls = {
+        # name: (argument list of a VALID call, indices that must not be NULL, indices of counts that must not be negative)
+        "vo_project_points": ([h, I(480), I(640), I(0), I(10), _p(K), _p(T), _p(world), I(n), I(1), _p(out2), C.byref(n_out), C.byref(n_in)],
+                              [0, 5, 6, 7, 10], [8]),
+        "vo_match_appearances": ([h, _p(a1), I(len(a1)), _p(a2), I(len(a2)), F(0.1), _p(outp), C.byref(n_out)], [0, 1, 3, 6, 7], [2, 4]),
+        "vo_radius_search": ([h, _p(a1), I(len(a1)), _p(a2), I(len(a2)), F(0.1), _p(offs), _p(idx), I(len(idx)), C.byref(n_out)],
+                             [0, 1, 3, 6, 7, 9], [2, 4, 8]),
+        "vo_join_correspondences": ([h, _p(pairs), I(len(pairs)), _p(mp), I(len(mp)), _p(outp), C.byref(n_out)], [0, 1, 3, 5, 6], [2, 4]),
+        "vo_transform_points": ([h, _p(T), _p(world), I(n), _p(out3)], [0, 1, 2, 4], [3]),
+        "vo_triangulate": ([h, _p(K), _p(T), _p(pairs), I(len(pairs)), _p(p1), I(len(p1)), _p(uv), I(len(uv)), _p(a2), _p(out3), _p(outp), _p(outa),
+                            C.byref(n_out)], [0, 1, 2, 3, 5, 7, 10, 13], [4, 6, 8]),
+        "vo_estimate_transform": ([h, _p(K), _p(pairs), I(len(pairs)), _p(p1), I(len(p1)), _p(uv), I(len(uv)), _p(X)], [0, 1, 2, 4, 6, 8], [3, 5, 7]),
+    }
+    checked = 0
+    for name, (args, ptrs, counts) in calls.items():
+        f = getattr(lib, name)
+        f.restype = C.c_int
+        assert f(*args) == 0, (name, lib.vo_last_error())                  # the baseline call is valid
+        for i in ptrs:
+            bad = list(args); bad[i] = NUL
+            rc = f(*bad)
+            assert rc < 0 and lib.vo_last_error(), (name, "NULL argument", i, rc)
+            checked += 1
+        for i in counts:
+            bad = list(args); bad[i] = I(-1)
+            rc = f(*bad)
+            assert rc < 0 and lib.vo_last_error(), (name, "negative count", i, rc)
+            checked += 1
+        assert f(*args) == 0, (name, "valid call after the refused ones", lib.vo_last_error())
+    assert checked == 54
+
+    # the solver handle
+    s = C.c_void_p()
+    assert lib.vo_picp_create(h, C.byref(s)) == 0
+    assert lib.vo_picp_create(NUL, C.byref(s)) < 0 and lib.vo_picp_create(h, NUL) < 0
+    assert lib.vo_picp_one_round(s, _p(pairs), I(len(pairs)), I(0)) < 0                     # before init: not ready
+    assert lib.vo_picp_set_camera(s, I(480), I(640), I(0), I(10), NUL, _p(T)) < 0
+    assert lib.vo_picp_set_camera(s, I(480), I(640), I(0), I(10), _p(K), NUL) < 0
+    assert lib.vo_picp_set_camera(s, I(480), I(640), I(0), I(10), _p(K), _p(T)) == 0
+    assert lib.vo_picp_set_points(s, NUL, I(n), _p(uv), I(len(uv))) < 0
+    assert lib.vo_picp_set_points(s, _p(world), I(-1), _p(uv), I(len(uv))) < 0
+    assert lib.vo_picp_set_points(s, _p(world), I(n), NUL, I(len(uv))) < 0
+    assert lib.vo_picp_set_points(s, _p(world), I(n), _p(uv), I(len(uv))) == 0
+    j = np.ascontiguousarray(np.stack([np.arange(50), np.arange(50)], 1), np.int32)
+    assert lib.vo_picp_one_round(s, NUL, I(50), I(0)) < 0
+    assert lib.vo_picp_one_round(s, _p(j), I(-1), I(0)) < 0
+    assert lib.vo_picp_solve(s, _p(j), I(50), I(0), I(-1)) < 0
+    assert lib.vo_picp_one_round(NUL, _p(j), I(50), I(0)) < 0
+    assert lib.vo_picp_one_round(s, _p(j), I(50), I(0)) == 0
+    assert lib.vo_picp_get_pose(s, NUL) < 0 and lib.vo_picp_get_pose(NUL, _p(X)) < 0
+    assert lib.vo_picp_get_stats(s, NUL, NUL, NUL) <= 0                                     # all-NULL outputs: refused or a no-op, not a crash
+    assert lib.vo_picp_get_pose(s, _p(X)) == 0 and np.isfinite(X).all()
+    assert lib.vo_picp_destroy(s) == 0
+    assert lib.vo_picp_destroy(NUL) <= 0
+    # handles of the wrong kind are NULL-checked only; contexts
+    assert lib.vo_ctx_synchronize(NUL) < 0 and lib.vo_ctx_destroy(NUL) <= 0 and lib.vo_match_set_mode(NUL, I(1)) < 0
+    assert lib.vo_match_set_mode(h, I(9)) < 0 and lib.vo_picp_batch_set_form(h, I(7)) < 0
+    kd = C.c_void_p()
+    assert lib.vo_kdtree_create(h, NUL, I(10), I(20), C.byref(kd)) < 0
+    assert lib.vo_kdtree_create(h, _p(a1), I(-1), I(20), C.byref(kd)) < 0
+    assert lib.vo_kdtree_create(h, _p(a1), I(len(a1)), I(20), NUL) < 0
+    assert lib.vo_kdtree_create(h, _p(a1), I(len(a1)), I(20), C.byref(kd)) == 0
+    best = np.zeros(len(a2), np.int32)
+    assert lib.vo_kdtree_best_match_fast(kd, NUL, I(len(a2)), F(0.1), _p(best)) < 0
+    assert lib.vo_kdtree_best_match_fast(kd, _p(a2), I(-1), F(0.1), _p(best)) < 0
+    assert lib.vo_kdtree_best_match_fast(kd, _p(a2), I(len(a2)), F(0.1), NUL) < 0
+    assert lib.vo_kdtree_best_match_fast(NUL, _p(a2), I(len(a2)), F(0.1), _p(best)) < 0
+    assert lib.vo_kdtree_best_match_fast(kd, _p(a2), I(len(a2)), F(0.1), _p(best)) == 0
+    assert lib.vo_kdtree_destroy(kd) == 0

@@ -32,9 +32,11 @@ void set_error_v(const char* fmt, va_list ap) { vsnprintf(g_err, sizeof(g_err), 
 #define VO_HIP_CHECK(expr)                                                              \
   do {                                                                                  \
     hipError_t _e = (expr);                                                             \
-    if (_e != hipSuccess)                                                               \
+    if (_e != hipSuccess) {                                                             \
+      (void)hipGetLastError(); /* reported here: must not resurface in the next call's launch check */ \
       return fail(_e == hipErrorOutOfMemory ? VO_ERR_OUT_OF_MEMORY : VO_ERR_HIP,        \
                   "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    }                                                                                   \
   } while (0)
 
 #define VO_REQUIRE(cond, msg) \
@@ -856,6 +858,7 @@ int vo_match_appearances(vo_ctx* c, const float* a1, int n1, const float* a2, in
   VO_REQUIRE(c && n_out, "null argument");
   VO_REQUIRE(n1 >= 0 && n2 >= 0, "negative count");
   VO_REQUIRE((n1 == 0 || a1) && (n2 == 0 || a2), "null appearance array");
+  VO_REQUIRE((n1 == 0 || n2 == 0) || out_pairs, "null output");
   if (int r = set_device(c)) return r;
   const int nq = n1 < n2 ? n1 : n2;
   if (int r = upload(c, c->in[0], a1, sizeof(float) * 10 * (size_t)n1)) return r;

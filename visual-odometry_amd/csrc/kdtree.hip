@@ -200,9 +200,11 @@ struct vo_kdtree {
 #define KD_CHECK(expr)                                                                         \
   do {                                                                                         \
     hipError_t _e = (expr);                                                                    \
-    if (_e != hipSuccess)                                                                      \
+    if (_e != hipSuccess) {                                                                    \
+      (void)hipGetLastError();                                                                 \
       return vo_fail(_e == hipErrorOutOfMemory ? VO_ERR_OUT_OF_MEMORY : VO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
                      hipGetErrorString(_e), __FILE__, __LINE__);                               \
+    }                                                                                          \
   } while (0)
 
 static int kd_grow(void** p, size_t* cap, size_t bytes, hipStream_t st) {
