@@ -73,7 +73,10 @@ int vo_ctx_device_info(vo_ctx *ctx, char *name, int name_len, int *n_cu);
  * a whole frame (match, join, transform, n rounds, triangulate = ~80 launches) then
  * costs one launch on the host.  Device pointers and counts are baked in; data and
  * device-side counts may change between replays.  A graph (like a vo_picp or a vo_event)
- * must be destroyed before the context it was made on. */
+ * must be destroyed before the context it was made on.  Between begin and end every entry
+ * point that copies host memory, allocates or waits (the forms without _dev, vo_ctx_synchronize,
+ * vo_dev_alloc ...) and every *_dev call that would have to grow a workspace is refused with
+ * VO_ERR_NOT_READY / VO_ERR_HIP before it touches the stream: the capture stays valid. */
 typedef struct vo_graph vo_graph;
 int vo_ctx_begin_capture(vo_ctx *ctx);
 int vo_ctx_end_capture(vo_ctx *ctx, vo_graph **out);

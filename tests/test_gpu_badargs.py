@@ -95,3 +95,52 @@ def test_invalid_arguments_are_refused_one_by_one(vo, ctx):
     assert lib.vo_kdtree_best_match_fast(NUL, _p(a2), I(len(a2)), F(0.1), _p(best)) < 0
     assert lib.vo_kdtree_best_match_fast(kd, _p(a2), I(len(a2)), F(0.1), _p(best)) == 0
     assert lib.vo_kdtree_destroy(kd) == 0
+
+
+def test_misuse_of_capture_allocation_and_batches(vo, o32):
+    """API misuse that must be refused and leave the context usable: capture begun twice / ended without a begin / a host
+    entry point inside a capture, an allocation far beyond the card, a frame batch with missing arrays or nonsense sizes."""
+    c = vo.Context(0)
+    lib, h = c.lib, c.h
+    NUL, I = C.c_void_p(0), C.c_int
+    g = C.c_void_p()
+    assert lib.vo_ctx_end_capture(h, C.byref(g)) < 0                       # nothing to end
+    assert lib.vo_ctx_begin_capture(h) == 0
+    assert lib.vo_ctx_begin_capture(h) < 0                                 # already capturing
+    fp = vo.synth.frame_pair(200, seed=9400)
+    a1 = np.ascontiguousarray(fp["ref_app"], np.float32); a2 = np.ascontiguousarray(fp["cur_app"], np.float32)
+    outp = np.zeros((200, 2), np.int32); n_out = C.c_int()
+    rc = lib.vo_match_appearances(h, _p(a1), I(200), _p(a2), I(200), C.c_float(0.1), _p(outp), C.byref(n_out))
+    assert rc < 0                                                          # host copies / synchronisation are not capturable
+    assert lib.vo_ctx_end_capture(h, C.byref(g)) in (0, -3)                # the capture ends (possibly invalidated by the refused call)
+    if g.value:
+        assert lib.vo_graph_destroy(g) == 0
+    assert lib.vo_ctx_end_capture(h, NUL) < 0 and lib.vo_graph_launch(NUL) < 0
+    m = vo.compute_correspondences_images(a1, a2, ctx=c)                   # and the context still works
+    assert np.array_equal(m, o32.match(a1, a2))
+    # allocation beyond the card
+    d = C.c_void_p()
+    rc = lib.vo_dev_alloc(h, C.c_size_t(1 << 42), C.byref(d))              # 4 TiB
+    assert rc == -4 and not d.value, rc                                    # VO_ERR_OUT_OF_MEMORY
+    assert lib.vo_dev_alloc(h, C.c_size_t(1 << 20), C.byref(d)) == 0 and d.value
+    assert lib.vo_dev_free(h, d) == 0
+    assert lib.vo_dev_alloc(NUL, C.c_size_t(16), C.byref(d)) < 0 and lib.vo_dev_alloc(h, C.c_size_t(16), NUL) < 0
+    assert np.array_equal(vo.compute_correspondences_images(a1, a2, ctx=c), m)
+    # frame batch: NULL batch, and a valid batch broken one field at a time
+    assert lib.vo_frames_batch_dev(h, NUL) < 0
+    fps = [vo.synth.frame_pair(300, seed=9400 + 3 * k) for k in range(2)]
+    bp = vo.BatchPipeline(c, fps, n_iters=3)
+    bp.run()
+    ok_poses = bp.poses().copy()
+    b = bp.b
+    for field, bad in (("n_frames", -1), ("n_ref", -1), ("n_cur", -5), ("n_model", -1), ("n_model_pairs", -2), ("n_iters", -1),
+                       ("ref_app", None), ("cur_pts", None), ("model", None), ("model_pairs", None), ("matches", None), ("joined", None),
+                       ("model_moved", None), ("poses", None), ("tri_xyz", None), ("tri_pairs", None), ("counts", None)):
+        keep = getattr(b, field)
+        setattr(b, field, bad)
+        rc = lib.vo_frames_batch_dev(h, C.byref(b))
+        setattr(b, field, keep)
+        assert rc < 0, (field, rc)
+    bp.run()
+    assert np.array_equal(bp.poses(), ok_poses)
+    bp.close(); c.close()

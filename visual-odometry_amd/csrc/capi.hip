@@ -42,12 +42,21 @@ void set_error_v(const char* fmt, va_list ap) { vsnprintf(g_err, sizeof(g_err), 
 #define VO_REQUIRE(cond, msg) \
   do { if (!(cond)) return fail(VO_ERR_INVALID_ARG, "%s: %s", __func__, msg); } while (0)
 
+// entry points that copy host memory or wait for the stream cannot be part of a graph capture (vo_ctx_begin_capture): refused
+// BEFORE any HIP call, because a refused HIP call would invalidate the capture in progress
+#define VO_NOT_CAPTURING(ctx) \
+  do { if ((ctx)->capturing) return fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture (only *_dev entry points are)", __func__); } while (0)
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
   // grow-only; contents are NOT preserved
   hipError_t ensure(size_t bytes, hipStream_t st) {
     if (bytes <= cap) return hipSuccess;
+    {   // growing frees, allocates and synchronises: none of it may happen inside a graph capture
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return hipErrorStreamCaptureUnsupported;
+    }
     if (p) {
       hipError_t e = hipStreamSynchronize(st);
       if (e != hipSuccess) return e;
@@ -187,12 +196,14 @@ int vo_ctx_destroy(vo_ctx* c) {
 
 int vo_ctx_synchronize(vo_ctx* c) {
   VO_REQUIRE(c, "ctx is null");
+  VO_NOT_CAPTURING(c);
   VO_HIP_CHECK(hipStreamSynchronize(c->stream));
   return VO_OK;
 }
 
 void* vo_ctx_stream(vo_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
 int vo_ctx_device(vo_ctx* c) { return c ? c->device : -1; }
+int vo_ctx_capturing(vo_ctx* c) { return (c && c->capturing) ? 1 : 0; }
 
 int vo_ctx_device_info(vo_ctx* c, char* name, int name_len, int* n_cu) {
   VO_REQUIRE(c, "ctx is null");
@@ -216,11 +227,25 @@ int vo_ctx_end_capture(vo_ctx* c, vo_graph** out) {
   *out = nullptr;
   c->capturing = false;
   hipGraph_t graph = nullptr;
-  VO_HIP_CHECK(hipStreamEndCapture(c->stream, &graph));
+  hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+  if (ee != hipSuccess) {
+    // a capture invalidated by a call that cannot be captured: make sure the stream is out of capture mode again
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      if (c->own_stream) {
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) { (void)hipStreamDestroy(c->stream); c->stream = fresh; }
+      }
+    }
+    return fail(VO_ERR_HIP, "hipStreamEndCapture: %s (the captured sequence contained a call that cannot be captured)", hipGetErrorString(ee));
+  }
   hipGraphExec_t exec = nullptr;
   hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
-  if (e != hipSuccess) return fail(VO_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(VO_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
   vo_graph* g = new vo_graph();
   g->ctx = c;
   g->exec = exec;
@@ -281,6 +306,7 @@ int vo_event_destroy(vo_event* ev) {
 
 int vo_dev_alloc(vo_ctx* c, size_t bytes, void** dptr) {
   VO_REQUIRE(c && dptr, "null argument");
+  VO_NOT_CAPTURING(c);
   if (int r = set_device(c)) return r;
   VO_HIP_CHECK(hipMalloc(dptr, bytes ? bytes : 16));
   return VO_OK;
@@ -288,6 +314,7 @@ int vo_dev_alloc(vo_ctx* c, size_t bytes, void** dptr) {
 
 int vo_dev_free(vo_ctx* c, void* dptr) {
   VO_REQUIRE(c, "ctx is null");
+  VO_NOT_CAPTURING(c);
   if (!dptr) return VO_OK;
   VO_HIP_CHECK(hipStreamSynchronize(c->stream));
   VO_HIP_CHECK(hipFree(dptr));
@@ -296,6 +323,7 @@ int vo_dev_free(vo_ctx* c, void* dptr) {
 
 int vo_memcpy_h2d(vo_ctx* c, void* dst, const void* src, size_t bytes) {
   VO_REQUIRE(c && (bytes == 0 || (dst && src)), "null argument");
+  VO_NOT_CAPTURING(c);
   if (bytes == 0) return VO_OK;
   VO_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
   VO_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -304,6 +332,7 @@ int vo_memcpy_h2d(vo_ctx* c, void* dst, const void* src, size_t bytes) {
 
 int vo_memcpy_d2h(vo_ctx* c, void* dst, const void* src, size_t bytes) {
   VO_REQUIRE(c && (bytes == 0 || (dst && src)), "null argument");
+  VO_NOT_CAPTURING(c);
   if (bytes == 0) return VO_OK;
   VO_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   VO_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -356,6 +385,7 @@ int vo_project_points(vo_ctx* c, int rows, int cols, int z_near, int z_far, cons
                       const float T[16], const float* world, int n, int keep_indices, float* out_uv,
                       int* n_out, int* n_inside) {
   VO_REQUIRE(c && K && T, "null argument");
+  VO_NOT_CAPTURING(c);
   VO_REQUIRE(n >= 0 && (n == 0 || (world && out_uv)), "bad point arrays");
   if (int r = set_device(c)) return r;
   if (int r = upload(c, c->in[0], world, sizeof(float) * 3 * (size_t)n)) return r;
@@ -378,6 +408,7 @@ int vo_project_points(vo_ctx* c, int rows, int cols, int z_near, int z_far, cons
 // ---- PICPSolver -----------------------------------------------------------------------
 int vo_picp_create(vo_ctx* c, vo_picp** out) {
   VO_REQUIRE(c && out, "null argument");
+  VO_NOT_CAPTURING(c);
   *out = nullptr;
   if (int r = set_device(c)) return r;
   vo_picp* s = new vo_picp();
@@ -410,6 +441,7 @@ int vo_picp_create(vo_ctx* c, vo_picp** out) {
 
 int vo_picp_destroy(vo_picp* s) {
   if (!s) return VO_OK;
+  VO_NOT_CAPTURING(s->ctx);
   (void)hipSetDevice(s->ctx->device);
   (void)hipStreamSynchronize(s->ctx->stream);
   for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -423,6 +455,7 @@ int vo_picp_destroy(vo_picp* s) {
 
 int vo_picp_set_pose(vo_picp* s, const float T[16]) {
   VO_REQUIRE(s && T, "null argument");
+  VO_NOT_CAPTURING(s->ctx);
   if (int r = set_device(s->ctx)) return r;
   const Pose P = pose_from_T16(T);
   float pose[12];
@@ -469,6 +502,7 @@ int vo_picp_set_points_dev(vo_picp* s, const float* d_world, int n_world, const 
 
 int vo_picp_set_points(vo_picp* s, const float* world, int n_world, const float* meas, int n_meas) {
   VO_REQUIRE(s, "null argument");
+  VO_NOT_CAPTURING(s->ctx);
   VO_REQUIRE(n_world >= 0 && n_meas >= 0, "negative count");
   VO_REQUIRE((n_world == 0 || world) && (n_meas == 0 || meas), "null point array");
   if (int r = set_device(s->ctx)) return r;
@@ -606,6 +640,7 @@ static int picp_take_pairs(vo_picp* s, const int32_t* pairs, int n_pairs) {
 
 int vo_picp_solve(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_outliers, int n_iters) {
   VO_REQUIRE(s, "null argument");
+  VO_NOT_CAPTURING(s->ctx);
   VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || pairs), "bad pairs");
   VO_REQUIRE(n_iters >= 0, "negative n_iters");
   if (int r = set_device(s->ctx)) return r;
@@ -620,6 +655,7 @@ int vo_picp_one_round(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_ou
 
 int vo_picp_set_correspondences(vo_picp* s, const int32_t* pairs, int n_pairs) {
   VO_REQUIRE(s, "null argument");
+  VO_NOT_CAPTURING(s->ctx);
   VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || pairs), "bad pairs");
   if (int r = set_device(s->ctx)) return r;
   s->packed_valid = false;          // explicit hand-over: always uploaded
@@ -655,6 +691,7 @@ static int picp_read_state(vo_picp* s, PicpState* h) {
 
 int vo_picp_get_pose(vo_picp* s, float T[16]) {
   VO_REQUIRE(s && T, "null argument");
+  VO_NOT_CAPTURING(s->ctx);
   if (int r = set_device(s->ctx)) return r;
   PicpState h;
   const int r = picp_read_state(s, &h);
@@ -700,6 +737,7 @@ int vo_picp_get_pose_dev(vo_picp* s, float* d_T16) {
 
 int vo_picp_get_stats(vo_picp* s, float* chi_in, float* chi_out, int* n_in) {
   VO_REQUIRE(s, "null argument");
+  VO_NOT_CAPTURING(s->ctx);
   if (int r = set_device(s->ctx)) return r;
   PicpState h;
   const int r = picp_read_state(s, &h);
@@ -722,6 +760,7 @@ int vo_debug_get_stamps(vo_picp* s, unsigned long long* out) {
 
 int vo_picp_get_system(vo_picp* s, float H[36], float b[6]) {
   VO_REQUIRE(s, "null argument");
+  VO_NOT_CAPTURING(s->ctx);
   if (int r = set_device(s->ctx)) return r;
   PicpState h;
   const int r = picp_read_state(s, &h);
@@ -856,6 +895,7 @@ int vo_match_appearances_dev(vo_ctx* c, const float* d_a1, int n1, const float* 
 int vo_match_appearances(vo_ctx* c, const float* a1, int n1, const float* a2, int n2, float radius,
                          int32_t* out_pairs, int* n_out) {
   VO_REQUIRE(c && n_out, "null argument");
+  VO_NOT_CAPTURING(c);
   VO_REQUIRE(n1 >= 0 && n2 >= 0, "negative count");
   VO_REQUIRE((n1 == 0 || a1) && (n2 == 0 || a2), "null appearance array");
   VO_REQUIRE((n1 == 0 || n2 == 0) || out_pairs, "null output");
@@ -943,6 +983,7 @@ int vo_join_correspondences_dev(vo_ctx* c, const int32_t* d_img, int n_img, cons
 int vo_join_correspondences(vo_ctx* c, const int32_t* img, int n_img, const int32_t* world, int n_world,
                             int32_t* out, int* n_out) {
   VO_REQUIRE(c && n_out, "null argument");
+  VO_NOT_CAPTURING(c);
   VO_REQUIRE(n_img >= 0 && n_world >= 0, "negative count");
   VO_REQUIRE((n_img == 0 || (img && out)) && (n_world == 0 || world), "null pair array");
   if (int r = set_device(c)) return r;
@@ -982,6 +1023,7 @@ int vo_radius_search_dev(vo_ctx* c, const float* d_tree, int n_tree, const float
 int vo_radius_search(vo_ctx* c, const float* tree, int n_tree, const float* qry, int n_q, float radius,
                      int32_t* offsets, int32_t* indices, int capacity, int* n_total) {
   VO_REQUIRE(c && offsets && n_total, "null argument");
+  VO_NOT_CAPTURING(c);
   VO_REQUIRE(n_tree >= 0 && n_q >= 0 && capacity >= 0, "negative count");
   VO_REQUIRE((n_tree == 0 || tree) && (n_q == 0 || qry) && (capacity == 0 || indices), "null array");
   if (int r = set_device(c)) return r;
@@ -1016,6 +1058,7 @@ int vo_transform_points_dev(vo_ctx* c, const float T[16], const float* d_T16, co
 
 int vo_transform_points(vo_ctx* c, const float T[16], const float* in, int n, float* out) {
   VO_REQUIRE(c && T, "null argument");
+  VO_NOT_CAPTURING(c);
   VO_REQUIRE(n >= 0 && (n == 0 || (in && out)), "bad point arrays");
   if (n == 0) return VO_OK;
   if (int r = set_device(c)) return r;
@@ -1050,6 +1093,7 @@ int vo_triangulate(vo_ctx* c, const float K[9], const float X[16], const int32_t
                    const float* p1, int n1, const float* p2, int n2, const float* app2, float* out_xyz,
                    int32_t* out_pairs, float* out_app, int* n_out) {
   VO_REQUIRE(c && K && X && n_out, "null argument");
+  VO_NOT_CAPTURING(c);
   VO_REQUIRE(n >= 0 && n1 >= 0 && n2 >= 0, "negative count");
   VO_REQUIRE(n == 0 || (pairs && p1 && p2 && out_xyz), "null array");
   if (int r = set_device(c)) return r;
@@ -1085,6 +1129,7 @@ int vo_triangulate(vo_ctx* c, const float K[9], const float X[16], const int32_t
 int vo_estimate_transform(vo_ctx* c, const float K[9], const int32_t* pairs, int n, const float* p1, int n1,
                           const float* p2, int n2, float X_out[16]) {
   VO_REQUIRE(c && K && pairs && p1 && p2 && X_out, "null argument");
+  VO_NOT_CAPTURING(c);
   VO_REQUIRE(n >= 8, "fewer than 8 correspondences");
   VO_REQUIRE(n1 > 0 && n2 > 0, "empty point set");
   for (int i = 0; i < n; ++i)

@@ -218,6 +218,7 @@ static int kd_grow(void** p, size_t* cap, size_t bytes, hipStream_t st) {
 extern "C" {
 
 int vo_kdtree_create(vo_ctx* c, const float* app, int n, int max_points_in_leaf, vo_kdtree** out) {
+  if (vo_ctx_capturing(c)) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
   if (!c || !out || n < 0 || (n > 0 && !app)) return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_create: null argument or negative count");
   if (max_points_in_leaf < 1) return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_create: max_points_in_leaf must be >= 1");
   *out = nullptr;
@@ -251,6 +252,7 @@ int vo_kdtree_create(vo_ctx* c, const float* app, int n, int max_points_in_leaf,
 }
 
 int vo_kdtree_destroy(vo_kdtree* t) {
+  if (t && vo_ctx_capturing(t->ctx)) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
   if (!t) return VO_OK;
   (void)hipSetDevice(vo_ctx_device(t->ctx));
   (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(vo_ctx_stream(t->ctx)));
@@ -279,6 +281,7 @@ int vo_kdtree_best_match_fast_dev(vo_kdtree* t, const float* d_qry, int nq, floa
 }
 
 int vo_kdtree_best_match_fast(vo_kdtree* t, const float* qry, int nq, float radius, int32_t* out) {
+  if (t && vo_ctx_capturing(t->ctx)) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
   if (!t || nq < 0 || (nq > 0 && (!qry || !out))) return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_best_match_fast: bad argument");
   if (nq == 0) return VO_OK;
   KD_CHECK(hipSetDevice(vo_ctx_device(t->ctx)));
@@ -311,6 +314,7 @@ int vo_kdtree_fast_search_dev(vo_kdtree* t, const float* d_qry, int nq, float ra
 
 int vo_kdtree_fast_search(vo_kdtree* t, const float* qry, int nq, float radius, int32_t* offsets, int32_t* indices, int capacity,
                           int* n_total) {
+  if (t && vo_ctx_capturing(t->ctx)) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
   if (!t || nq < 0 || capacity < 0 || !offsets || !n_total || (nq > 0 && !qry) || (capacity > 0 && !indices))
     return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_fast_search: bad argument");
   KD_CHECK(hipSetDevice(vo_ctx_device(t->ctx)));
