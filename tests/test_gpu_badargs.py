@@ -144,3 +144,48 @@ def test_misuse_of_capture_allocation_and_batches(vo, o32):
     bp.run()
     assert np.array_equal(bp.poses(), ok_poses)
     bp.close(); c.close()
+
+
+def test_wild_indices_are_dropped_not_dereferenced(vo, ctx, o32):
+    """Index pairs pointing outside their arrays (negative, INT_MAX, INT_MIN, one past the end): undefined behaviour in the
+    reference, a dropped pair here -- the result equals the oracle's on the input with those pairs removed."""
+    fp = vo.synth.frame_pair(1200, seed=9500, drop=0.05, model_drop=0.05)
+    rng = np.random.default_rng(4)
+    m = o32.match(fp["ref_app"], fp["cur_app"])
+    wild = np.array([-1, -7, 2**31 - 1, -2**31, len(fp["ref_pts"]), len(fp["cur_pts"]) + 5], np.int64)
+
+    def spoil(pairs, n_first, n_second):
+        p = pairs.astype(np.int64).copy()
+        rows = rng.permutation(len(p))[:60]
+        p[rows[:30], 0] = rng.choice(wild, 30); p[rows[30:], 1] = rng.choice(wild, 30)
+        p = p.astype(np.int32)
+        good = (p[:, 0] >= 0) & (p[:, 0] < n_first) & (p[:, 1] >= 0) & (p[:, 1] < n_second)
+        return np.ascontiguousarray(p), np.ascontiguousarray(p[good])
+
+    # triangulation: (index in p1, index in p2)
+    bad, clean = spoil(m, len(fp["ref_pts"]), len(fp["cur_pts"]))
+    assert len(clean) < len(bad)
+    xyz, pairs, app = vo.triangulate_points(fp["K"], fp["X_gt"], bad, fp["ref_pts"], fp["cur_pts"], fp["cur_app"], ctx=ctx)
+    e_xyz, e_pairs, e_app = o32.triangulate(fp["K"], fp["X_gt"], clean, fp["ref_pts"], fp["cur_pts"], fp["cur_app"])
+    assert np.array_equal(pairs, e_pairs) and np.array_equal(xyz, e_xyz) and np.array_equal(app, e_app)
+    # join: image pairs (ref, cur) with world pairs (ref, model); a wild ref on either side finds no partner
+    mp = fp["model_pairs"]
+    bad_img, _ = spoil(m, 1 << 30, 1 << 30)                               # only the sign / size of .first matters to the join
+    bad_img[:, 1] = m[:, 1]
+    n_ref = len(fp["ref_pts"])
+    ok_img = bad_img[(bad_img[:, 0] >= 0) & (bad_img[:, 0] < n_ref)]          # the oracle would index its table with the wild ones
+    bad_mp = mp.astype(np.int64).copy(); rows = rng.permutation(len(mp))[:20]; bad_mp[rows, 0] = rng.choice(wild[:4], 20); bad_mp = bad_mp.astype(np.int32)
+    ok_mp = bad_mp[(bad_mp[:, 0] >= 0) & (bad_mp[:, 0] < n_ref)]
+    j = vo.extract_correspondences_world(bad_img, bad_mp, ctx=ctx)
+    assert np.array_equal(j, o32.join(ok_img, ok_mp, linear=True))
+    # solver: reported, not dereferenced
+    s = vo.PICPSolver(ctx)
+    s.setKernelThreshold(10000.0)
+    s.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx), fp["model"], fp["cur_pts"])
+    jj = o32.join(m, mp)
+    spoiled = jj.copy(); spoiled[5, 1] = 2**31 - 1; spoiled[9, 0] = -3
+    s.oneRound(spoiled, False)
+    with pytest.raises(vo.VoError) as e:
+        s.numInliers()
+    assert e.value.code == -5                                              # VO_ERR_BAD_INDEX
+    s.close()
