@@ -217,3 +217,25 @@ def test_non_finite_points_go_through_like_in_the_reference(vo, ctx, o32):
         T = s.camera().worldInCameraPose()
         assert np.array_equal(np.isnan(T), np.isnan(r["T"][-1])), exact
         s.close()
+
+
+def test_denormal_range_values_round_like_on_the_cpu(vo, ctx, o32):
+    """float32 subnormals are neither flushed on input nor on output (the reference's SSE2 build honours them): a rigid
+    transform of points of size 1e-39, and a matcher whose squared distances and squared radius are subnormal."""
+    rng = np.random.default_rng(6)
+    pts = (rng.uniform(-1, 1, (5000, 3)) * 1e-39).astype(np.float32)
+    assert (np.abs(pts[pts != 0]) < 1.2e-38).all()
+    fp = vo.synth.frame_pair(10, seed=1)
+    X = fp["X_gt"].copy(); X[:3, 3] = 0
+    got, exp = vo.transform_points(X, pts, ctx=ctx), o32.transform_points(X, pts)
+    assert np.array_equal(got, exp) and np.count_nonzero(exp) > 14000
+    base = rng.uniform(-1, 1, (3000, 10))
+    a = (base * 1e-19).astype(np.float32)
+    b = ((base[rng.permutation(3000)] + rng.normal(0, 1e-2, (3000, 10))) * 1e-19).astype(np.float32)
+    radius = 1e-20                                                        # r^2 = 1e-40: subnormal
+    exp_m = o32.match(a, b, radius)
+    assert 100 < len(exp_m) <= 3000
+    for mode in (0, 1, 2, 3):
+        assert ctx.lib.vo_match_set_mode(ctx.h, mode) == 0
+        assert np.array_equal(vo.compute_correspondences_images(a, b, radius, ctx=ctx), exp_m), mode
+    assert ctx.lib.vo_match_set_mode(ctx.h, 0) == 0
