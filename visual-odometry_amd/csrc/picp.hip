@@ -662,13 +662,20 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
 // CPU restatement by tests/test_gpu_exact.py): the per-correspondence terms are computed in parallel with every
 // product unfused (picp_term_exact), staged through LDS, and lane k of the first wave adds entry
 // k of H / b / chi SEQUENTIALLY IN CORRESPONDENCE ORDER -- parallel across the 30 entries, serial
-// across the correspondences, which is the reference's summation order.  The tail is Eigen's
+// across the correspondences, which is the reference's summation order.  The serial chain (one dependent
+// float add per correspondence) is the floor of a round; everything else is taken off it: six producer waves
+// linearise chunk c+1 into one LDS buffer while the summing wave drains chunk c from the other (one
+// ds_read_b128 per four adds, no flags: an entry the reference does not add is staged as +0.0f, and
+// x + (+0.0f) == x bit for bit for every x but -0.0f, which a sum started at +0.0f never holds).  The tail is Eigen's
 // pivoted LDLT with true divisions (ldlt6_solve) and sin/cos in double rounded to float
 // (v2t_euler_exact).  One workgroup per problem, all rounds inside the launch.  Meant for
 // verification and for small frames (the reference's dataset has <= 127 points per frame, where
-// a round costs a few microseconds); at 50k correspondences a round is ~1 ms.
-constexpr int EX_BLOCK = 256;
-constexpr int EX_STRIDE = NTERM + 1;   // 29 floats per staged correspondence: odd stride, conflict-free stores
+// a round costs a few microseconds); at 50k correspondences a round is 0.18 ms -- 50 000 dependent adds at 7.5 cycles
+// each are 0.156 ms that no arrangement can remove.
+constexpr int EX_BLOCK = 512;             // 8 waves: wave 0 sums, waves 1-3 and 5-7 linearise; wave 4 idles so that SIMD 0 is the summing wave's alone
+constexpr int EX_CHUNK = 384;             // correspondences per chunk = producer threads
+constexpr int EX_ROW = EX_CHUNK + 4;      // floats per LDS row (one row per accumulator, 16-byte aligned; +4: rows start on different banks)
+static_assert(EX_CHUNK % 64 == 0, "the drain works in steps of 64 slots");
 
 struct ExactArgs {
   const float* packed;       // 5 SoA arrays of `cap` floats per problem
@@ -685,11 +692,13 @@ struct ExactArgs {
 
 template <bool SINGLE>
 __global__ __launch_bounds__(EX_BLOCK) void picp_exact_kernel(ExactArgs a) {
-  __shared__ float s_term[EX_BLOCK * EX_STRIDE];
-  __shared__ int s_flag[EX_BLOCK];
+  __shared__ __attribute__((aligned(16))) float s_term[2][NACC * EX_ROW + 32];   // [buffer][accumulator][correspondence of the chunk] + read-ahead pad
   __shared__ float s_sum[NACC + 2];
   __shared__ float s_pose[12];
   const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const bool producer = wave != 0 && wave != 4;
+  const int pt = ((wave < 4 ? wave - 1 : wave - 2) << 6) | (tid & 63);       // producer thread 0 .. EX_CHUNK-1
   const size_t p = blockIdx.x;
   CamK cam; float thr, damping; int keep, n;
   Pose T;
@@ -715,34 +724,65 @@ __global__ __launch_bounds__(EX_BLOCK) void picp_exact_kernel(ExactArgs a) {
   const float* Z = Y + a.cap;
   const float* U = Z + a.cap;
   const float* V = U + a.cap;
+  const int n_chunks = (n + EX_CHUNK - 1) / EX_CHUNK;
+  // what one producer thread stages for correspondence c * EX_CHUNK + pt: the value each accumulator ADDS (:72-94).
+  // Its five inputs were requested one chunk ahead (ld), so that their latency hides behind the previous chunk's work.
+  float px = 0.f, py = 0.f, pz = 0.f, pu = 0.f, pv = 0.f;
+  auto ld = [&](int c) {
+    const int i = c * EX_CHUNK + pt;
+    if (i < n) { px = X[i]; py = Y[i]; pz = Z[i]; pu = U[i]; pv = V[i]; }
+  };
+  auto fill = [&](int c) {
+    float* buf = s_term[c & 1];
+    const int i = c * EX_CHUNK + pt;
+    const float wx = px, wy = py, wz = pz, zu = pu, zv = pv;
+    ld(c + 1 < n_chunks ? c + 1 : 0);                                     // next chunk (after the last one: the next round's first)
+    float term[NTERM];
+    int flag = 0;
+    if (i < n) flag = picp_term_exact(cam, T, thr, wx, wy, wz, zu, zv, term);
+    const bool inl = flag == 1, outl = flag == 2;
+    const bool in_sys = inl || (outl && keep != 0);                       // :90-94
+#pragma unroll
+    for (int k = 0; k < 27; ++k) buf[k * EX_ROW + pt] = in_sys ? term[k] : 0.f;
+    buf[27 * EX_ROW + pt] = inl ? term[27] : 0.f;                         // chi of the inliers (:86)
+    buf[28 * EX_ROW + pt] = outl ? term[27] : 0.f;                        // chi of the outliers (:82)
+    buf[29 * EX_ROW + pt] = inl ? 1.f : 0.f;                              // inlier count (:87, exact below 2^24)
+  };
+  if (producer && n_chunks > 0) ld(0);
   for (int it = 0; it < a.n_iters; ++it) {
     float run = 0.f;                                   // lane k < NACC of wave 0: running sum of entry k (:57-61)
-    for (int base = 0; base < n; base += EX_BLOCK) {
-      const int i = base + tid;
-      int flag = 0;
-      if (i < n) {
-        float term[NTERM];
-        flag = picp_term_exact(cam, T, thr, X[i], Y[i], Z[i], U[i], V[i], term);
-        if (flag) {
-#pragma unroll
-          for (int k = 0; k < NTERM; ++k) s_term[tid * EX_STRIDE + k] = term[k];
-        }
-      }
-      s_flag[tid] = flag;
-      __syncthreads();
+    if (producer && n_chunks > 0) fill(0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+      if (producer && c + 1 < n_chunks) fill(c + 1);
       if (tid < NACC) {
-        const int m = (n - base) < EX_BLOCK ? (n - base) : EX_BLOCK;
-        for (int j = 0; j < m; ++j) {
-          const int f = s_flag[j];
-          if (f == 0) continue;                                            // :72-73
-          bool add;
-          float v;
-          if (tid < 27) { add = f == 1 || keep != 0; v = s_term[j * EX_STRIDE + tid]; }      // :90-94
-          else if (tid == 27) { add = f == 1; v = s_term[j * EX_STRIDE + 27]; }            // :86
-          else if (tid == 28) { add = f == 2; v = s_term[j * EX_STRIDE + 27]; }            // :82
-          else { add = f == 1; v = 1.f; }                                                  // :87 (exact below 2^24)
-          if (add) run += v;
+        // Every slot of the chunk is staged (a slot without correspondence, or whose term the reference does not add, holds
+        // +0.0f), so the drain needs no bounds inside a step: steps of 64 adds, two register sets of eight float4 swapping
+        // roles, each read issued 32 dependent adds (~240 cycles) before its use.  The read-ahead of the last step runs into
+        // the next row / the pad behind the buffer and is never added.
+        const int left = n - c * EX_CHUNK;
+        const int steps = ((left < EX_CHUNK ? left : EX_CHUNK) + 63) >> 6;
+        const float4* row = reinterpret_cast<const float4*>(s_term[c & 1] + tid * EX_ROW);
+#define VO_RD8(q, at) { q##0 = row[at]; q##1 = row[(at) + 1]; q##2 = row[(at) + 2]; q##3 = row[(at) + 3]; \
+                        q##4 = row[(at) + 4]; q##5 = row[(at) + 5]; q##6 = row[(at) + 6]; q##7 = row[(at) + 7]; }
+#define VO_ADD4(v) run += v.x; run += v.y; run += v.z; run += v.w
+#define VO_ADD32(q) VO_ADD4(q##0); VO_ADD4(q##1); VO_ADD4(q##2); VO_ADD4(q##3); VO_ADD4(q##4); VO_ADD4(q##5); VO_ADD4(q##6); VO_ADD4(q##7)
+        float4 P0, P1, P2, P3, P4, P5, P6, P7, Q0, Q1, Q2, Q3, Q4, Q5, Q6, Q7;
+        VO_RD8(P, 0)
+        for (int st = 0; st < steps; ++st) {
+          const int g = st * 16;
+          VO_RD8(Q, g + 8)
+          __builtin_amdgcn_sched_barrier(0);              // keep the issue order: the compiler would hoist every read to the top
+          VO_ADD32(P);
+          __builtin_amdgcn_sched_barrier(0);
+          VO_RD8(P, g + 16)
+          __builtin_amdgcn_sched_barrier(0);
+          VO_ADD32(Q);
+          __builtin_amdgcn_sched_barrier(0);
         }
+#undef VO_RD8
+#undef VO_ADD4
+#undef VO_ADD32
       }
       __syncthreads();
     }
