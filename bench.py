@@ -203,12 +203,18 @@ def main():
         with torch.cuda.stream(stream):
             if args.frame_steps > 0 and "frame" in legs:
                 out["frame"] = frame_leg(torch, ctx, stream, pipe, fp, args, vo)
+                out["exact_mode"] = exact_leg(torch, ctx, stream, pipe, fp, args)
             if args.batch_pairs > 0 and "batched" in legs:
                 out["batched"] = batched_leg(torch, vo, ctx, stream, args)
             if args.seq_frames >= 3 and "sequence" in legs:
                 out["sequence"] = sequence_leg(vo, ctx, args)
         if args.cpu_seconds > 0 and world == 1 and "cpu" in legs:
             out["cpu_baseline"] = cpu_leg(fp, pipe, args)
+            if "exact_mode" in out:     # same pair, same rounds: the reference-order GPU pose against the CPU restatement's
+                out["exact_mode"]["bit_identical_to_cpu_baseline"] = bool(np.array_equal(out["exact_mode"]["_pose"], out["cpu_baseline"].pop("_pose")))
+                out["exact_mode"]["vs_cpu_baseline"] = out["exact_mode"]["iters_per_sec"] / out["cpu_baseline"]["value"]
+        if "exact_mode" in out:
+            out["exact_mode"].pop("_pose", None)
     pipe.close()
     _PairGen.stop_pool()
     if dist is not None:
@@ -402,6 +408,35 @@ def frame_throughput_strong(vo, torch, ctx, stream, args, dist=None, vdist=None,
                          "algorithmic_bytes_per_pass": alg},
             "note": "all pairs distinct (seeds 4000+p), resident in HBM before the timed region; every pass = the rank's "
                     "share through vo_frames_batch_dev" + (" + one all_gather_into_tensor of the poses" if dist is not None else "")}
+
+
+def exact_leg(torch, ctx, stream, pipe, fp, args):
+    """The same rounds on the same pair with the solver in reference-order arithmetic (vo_picp_set_exact): one workgroup,
+    the serial chain of one dependent float add per correspondence.  Its pose is compared BIT FOR BIT with the CPU baseline's
+    in cpu_leg (same rounds, same input)."""
+    lib = ctx.lib
+    _chk(lib, lib.vo_picp_set_exact(pipe.solver, 1))
+    reps = 5
+    try:
+        pipe.picp()
+        ctx.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            pipe.picp()
+        e1.record(stream)
+        ctx.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        T = pipe.pose()
+    finally:
+        _chk(lib, lib.vo_picp_set_exact(pipe.solver, 0))
+    pipe.picp()                                      # leave the fast mode's pose behind, as the later legs expect
+    ctx.synchronize()
+    return {"iters_per_sec": args.iters / (ms * 1e-3), "us_per_round": ms * 1e3 / args.iters, "points": args.points,
+            "pose_err_vs_gt": float(np.abs(T - fp["X_gt"]).max()), "_pose": T,
+            "note": "reference-order arithmetic (terms unfused, H / b / chi summed sequentially in correspondence order, Eigen's "
+                    "LDLT, double sin/cos): bit-identical to the float32 CPU restatement; floor = one dependent v_add_f32 "
+                    "(7.5 cycles) per correspondence and round"}
 
 
 def frame_leg(torch, ctx, stream, pipe, fp, args, vo_mod=None):
@@ -675,7 +710,7 @@ def cpu_leg(fp, pipe, args):
             "all_cores": all_cores, "march_native": march_native, "other_stages": stages,
             "sample": f"median of {reps} x {args.iters} rounds of the C float32 restatement (oracle/, gcc -O3 -ffp-contract=off) "
                       f"on the same {len(corr)}-correspondence pair; the reference itself needs Eigen3 (absent)",
-            "pose_diff_gpu_vs_cpu": float(np.abs(gpu_T - r["T"]).max()),
+            "pose_diff_gpu_vs_cpu": float(np.abs(gpu_T - r["T"]).max()), "_pose": np.asarray(r["T"], np.float32),
             "host": _cpu_model(), "host_cores_available": os.cpu_count()}
 
 
