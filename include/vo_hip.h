@@ -59,6 +59,9 @@ const char *vo_last_error(void);
 /* stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL
  * to let the context create its own non-blocking stream. */
 int vo_ctx_create(int device, void *stream, vo_ctx **out);
+/* Handles made on a context (vo_picp, vo_graph, vo_kdtree) should be destroyed before it.  If one outlives its
+ * context anyway, every use of it fails with VO_ERR_INVALID_ARG and its destroy still releases what it owns;
+ * destroying a context twice is refused. */
 int vo_ctx_destroy(vo_ctx *ctx);
 int vo_ctx_synchronize(vo_ctx *ctx);
 void *vo_ctx_stream(vo_ctx *ctx);

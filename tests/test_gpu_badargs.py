@@ -189,3 +189,43 @@ def test_wild_indices_are_dropped_not_dereferenced(vo, ctx, o32):
         s.numInliers()
     assert e.value.code == -5                                              # VO_ERR_BAD_INDEX
     s.close()
+
+
+def test_handles_that_outlive_their_context(vo, o32):
+    """A context destroyed BEFORE the solver / kd-tree / graph made on it (static destruction order, a script closing things
+    in the wrong order): the survivors must fail cleanly when used and must still be destroyable -- no use-after-free."""
+    c = vo.Context(0)
+    lib = c.lib
+    fp = vo.synth.frame_pair(400, seed=9600)
+    s = vo.PICPSolver(c)
+    s.setKernelThreshold(10000.0)
+    s.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=c), fp["model"], fp["cur_pts"])
+    j = o32.join(o32.match(fp["ref_app"], fp["cur_app"]), fp["model_pairs"])
+    s.solve(j, False, 5)
+    T = s.camera().worldInCameraPose().copy()
+    kd = vo.KdTree(fp["ref_app"], ctx=c)
+    p = vo.FramePipeline(c, fp, n_iters=3)
+    p.frame(); p.capture_frame(); p.frame_graph(); p.counts()
+    graph = p.graph if hasattr(p, "graph") else None
+    h_ctx = c.h
+    assert lib.vo_ctx_destroy(h_ctx) == 0
+    c.h = None                                               # the Python object must not destroy it again
+    assert lib.vo_ctx_destroy(h_ctx) < 0                     # destroyed twice: refused, not a double free
+    with pytest.raises(vo.VoError):
+        s.oneRound(j, False)
+    with pytest.raises(vo.VoError):
+        s.camera()
+    with pytest.raises(vo.VoError):
+        kd.bestMatchFast(fp["cur_app"])
+    if graph is not None:
+        assert lib.vo_graph_launch(graph) < 0
+    s.close(); kd.close()                                     # still destroyable
+    c2 = vo.Context(0)                                        # and the library goes on
+    p.ctx = c2                                                # the pipeline's graph and solver go the same way, its buffers through a live context
+    p.close()
+    s2 = vo.PICPSolver(c2)
+    s2.setKernelThreshold(10000.0)
+    s2.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=c2), fp["model"], fp["cur_pts"])
+    s2.solve(j, False, 5)
+    assert np.array_equal(s2.camera().worldInCameraPose(), T)
+    s2.close(); c2.close()

@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
+#include <set>
 #include <tuple>
 #include <vector>
 
@@ -111,6 +113,16 @@ struct vo_event {
   hipEvent_t ev = nullptr;
 };
 
+// Contexts that exist.  Solvers, graphs and kd-trees keep a pointer to the context they were made on; the header asks for
+// them to be destroyed first, but destruction order is easy to get wrong in a host program (statics, members, scripting
+// languages), so a handle that outlives its context must fail cleanly when used and must still be destroyable.
+static std::mutex g_ctx_mu;
+static std::set<const vo_ctx*> g_ctx_live;
+static bool ctx_alive(const vo_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  return c && g_ctx_live.count(c) != 0;
+}
+
 struct vo_graph {
   vo_ctx* ctx = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -177,12 +189,17 @@ int vo_ctx_create(int device, void* stream, vo_ctx** out) {
     if (es != hipSuccess) { delete c; return fail(VO_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(es)); }
     c->own_stream = true;
   }
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctx_live.insert(c); }
   *out = c;
   return VO_OK;
 }
 
 int vo_ctx_destroy(vo_ctx* c) {
   if (!c) return VO_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (!g_ctx_live.erase(c)) return fail(VO_ERR_INVALID_ARG, "vo_ctx_destroy: not a live context (destroyed twice?)");
+  }
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   c->scratch.release(); c->best.release(); c->table.release(); c->counts.release();
@@ -203,7 +220,8 @@ int vo_ctx_synchronize(vo_ctx* c) {
 
 void* vo_ctx_stream(vo_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
 int vo_ctx_device(vo_ctx* c) { return c ? c->device : -1; }
-int vo_ctx_capturing(vo_ctx* c) { return (c && c->capturing) ? 1 : 0; }
+int vo_ctx_capturing(vo_ctx* c) { return (ctx_alive(c) && c->capturing) ? 1 : 0; }
+int vo_ctx_alive(vo_ctx* c) { return ctx_alive(c) ? 1 : 0; }
 
 int vo_ctx_device_info(vo_ctx* c, char* name, int name_len, int* n_cu) {
   VO_REQUIRE(c, "ctx is null");
@@ -255,6 +273,7 @@ int vo_ctx_end_capture(vo_ctx* c, vo_graph** out) {
 
 int vo_graph_launch(vo_graph* g) {
   VO_REQUIRE(g && g->exec, "null graph");
+  VO_REQUIRE(ctx_alive(g->ctx), "the context this graph was captured on has been destroyed");
   if (int r = set_device(g->ctx)) return r;
   VO_HIP_CHECK(hipGraphLaunch(g->exec, g->ctx->stream));
   return VO_OK;
@@ -262,7 +281,8 @@ int vo_graph_launch(vo_graph* g) {
 
 int vo_graph_destroy(vo_graph* g) {
   if (!g) return VO_OK;
-  (void)hipStreamSynchronize(g->ctx->stream);
+  if (ctx_alive(g->ctx)) (void)hipStreamSynchronize(g->ctx->stream);
+  else (void)hipDeviceSynchronize();
   if (g->exec) (void)hipGraphExecDestroy(g->exec);
   delete g;
   return VO_OK;
@@ -441,9 +461,13 @@ int vo_picp_create(vo_ctx* c, vo_picp** out) {
 
 int vo_picp_destroy(vo_picp* s) {
   if (!s) return VO_OK;
-  VO_NOT_CAPTURING(s->ctx);
-  (void)hipSetDevice(s->ctx->device);
-  (void)hipStreamSynchronize(s->ctx->stream);
+  if (ctx_alive(s->ctx)) {
+    VO_NOT_CAPTURING(s->ctx);
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+  } else {
+    (void)hipDeviceSynchronize();       // the context went first: its stream is gone, the solver's memory is not
+  }
   for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
   s->world_own.release(); s->meas_own.release(); s->pairs_own.release();
   s->packed.release(); s->partials.release();
@@ -455,6 +479,7 @@ int vo_picp_destroy(vo_picp* s) {
 
 int vo_picp_set_pose(vo_picp* s, const float T[16]) {
   VO_REQUIRE(s && T, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   if (int r = set_device(s->ctx)) return r;
   const Pose P = pose_from_T16(T);
@@ -471,6 +496,7 @@ int vo_picp_set_pose(vo_picp* s, const float T[16]) {
 int vo_picp_set_camera(vo_picp* s, int rows, int cols, int z_near, int z_far, const float K[9],
                        const float T[16]) {
   VO_REQUIRE(s && K && T, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   s->hp.cam = make_cam(rows, cols, z_near, z_far, K);
   s->params_dirty = true;
   return vo_picp_set_pose(s, T);
@@ -478,6 +504,7 @@ int vo_picp_set_camera(vo_picp* s, int rows, int cols, int z_near, int z_far, co
 
 int vo_picp_set_kernel_threshold(vo_picp* s, float thr) {
   VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   s->hp.thr = thr;
   s->params_dirty = true;
   return VO_OK;
@@ -485,12 +512,14 @@ int vo_picp_set_kernel_threshold(vo_picp* s, float thr) {
 
 int vo_picp_get_kernel_threshold(vo_picp* s, float* thr) {
   VO_REQUIRE(s && thr, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   *thr = s->hp.thr;
   return VO_OK;
 }
 
 int vo_picp_set_points_dev(vo_picp* s, const float* d_world, int n_world, const float* d_meas, int n_meas) {
   VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   VO_REQUIRE(n_world >= 0 && n_meas >= 0, "negative count");
   VO_REQUIRE((n_world == 0 || d_world) && (n_meas == 0 || d_meas), "null point array");
   s->d_world = d_world; s->n_world = n_world;
@@ -502,6 +531,7 @@ int vo_picp_set_points_dev(vo_picp* s, const float* d_world, int n_world, const 
 
 int vo_picp_set_points(vo_picp* s, const float* world, int n_world, const float* meas, int n_meas) {
   VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   VO_REQUIRE(n_world >= 0 && n_meas >= 0, "negative count");
   VO_REQUIRE((n_world == 0 || world) && (n_meas == 0 || meas), "null point array");
@@ -610,6 +640,7 @@ extern "C" {
 int vo_picp_solve_dev(vo_picp* s, const int32_t* d_pairs, int n_pairs, const int* d_n_pairs,
                       int keep_outliers, int n_iters) {
   VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || d_pairs), "bad pairs");
   VO_REQUIRE(n_iters >= 0, "negative n_iters");
   if (int r = set_device(s->ctx)) return r;
@@ -640,6 +671,7 @@ static int picp_take_pairs(vo_picp* s, const int32_t* pairs, int n_pairs) {
 
 int vo_picp_solve(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_outliers, int n_iters) {
   VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || pairs), "bad pairs");
   VO_REQUIRE(n_iters >= 0, "negative n_iters");
@@ -655,6 +687,7 @@ int vo_picp_one_round(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_ou
 
 int vo_picp_set_correspondences(vo_picp* s, const int32_t* pairs, int n_pairs) {
   VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || pairs), "bad pairs");
   if (int r = set_device(s->ctx)) return r;
@@ -667,6 +700,7 @@ int vo_picp_set_correspondences(vo_picp* s, const int32_t* pairs, int n_pairs) {
 
 int vo_picp_rounds(vo_picp* s, int keep_outliers, int n_iters) {
   VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   VO_REQUIRE(n_iters >= 0, "negative n_iters");
   if (s->set_n < 0 || !s->shadow_valid)
     return fail(VO_ERR_NOT_READY, "vo_picp_rounds: vo_picp_set_correspondences has not been called");
@@ -677,6 +711,7 @@ int vo_picp_rounds(vo_picp* s, int keep_outliers, int n_iters) {
 
 int vo_picp_set_exact(vo_picp* s, int on) {
   VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   s->exact = on ? 1 : 0;
   return VO_OK;
 }
@@ -691,6 +726,7 @@ static int picp_read_state(vo_picp* s, PicpState* h) {
 
 int vo_picp_get_pose(vo_picp* s, float T[16]) {
   VO_REQUIRE(s && T, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   if (int r = set_device(s->ctx)) return r;
   PicpState h;
@@ -704,6 +740,7 @@ int vo_picp_get_pose(vo_picp* s, float T[16]) {
 
 int vo_picp_set_pose_dev(vo_picp* s, const float* d_T16) {
   VO_REQUIRE(s && d_T16, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   // consumed by the next solve: folded into its gather launch (or a 12-thread launch of its own)
   s->pending_T0 = d_T16;
   return VO_OK;
@@ -711,6 +748,7 @@ int vo_picp_set_pose_dev(vo_picp* s, const float* d_T16) {
 
 int vo_picp_pose_dev_ptr(vo_picp* s, const float** d_T16) {
   VO_REQUIRE(s && d_T16, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   *d_T16 = s->d_state->T16;
   return VO_OK;
 }
@@ -729,6 +767,7 @@ __global__ void pose12_to_T16_kernel(const float* p, float* T) {
 
 int vo_picp_get_pose_dev(vo_picp* s, float* d_T16) {
   VO_REQUIRE(s && d_T16, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   if (int r = set_device(s->ctx)) return r;
   hipLaunchKernelGGL(pose12_to_T16_kernel, dim3(1), dim3(64), 0, s->ctx->stream, s->d_state->pose[0], d_T16);
   VO_HIP_CHECK(hipGetLastError());
@@ -737,6 +776,7 @@ int vo_picp_get_pose_dev(vo_picp* s, float* d_T16) {
 
 int vo_picp_get_stats(vo_picp* s, float* chi_in, float* chi_out, int* n_in) {
   VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   if (int r = set_device(s->ctx)) return r;
   PicpState h;
@@ -760,6 +800,7 @@ int vo_debug_get_stamps(vo_picp* s, unsigned long long* out) {
 
 int vo_picp_get_system(vo_picp* s, float H[36], float b[6]) {
   VO_REQUIRE(s, "null argument");
+  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   if (int r = set_device(s->ctx)) return r;
   PicpState h;

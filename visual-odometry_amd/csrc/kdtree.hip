@@ -254,8 +254,12 @@ int vo_kdtree_create(vo_ctx* c, const float* app, int n, int max_points_in_leaf,
 int vo_kdtree_destroy(vo_kdtree* t) {
   if (t && vo_ctx_capturing(t->ctx)) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
   if (!t) return VO_OK;
-  (void)hipSetDevice(vo_ctx_device(t->ctx));
-  (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(vo_ctx_stream(t->ctx)));
+  if (vo_ctx_alive(t->ctx)) {
+    (void)hipSetDevice(vo_ctx_device(t->ctx));
+    (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(vo_ctx_stream(t->ctx)));
+  } else {
+    (void)hipDeviceSynchronize();       // the context went first
+  }
   for (void* p : {(void*)t->d_nodes, (void*)t->d_pts, (void*)t->d_index, t->d_q, t->d_o, t->d_i}) if (p) (void)hipFree(p);
   delete t;
   return VO_OK;
@@ -270,6 +274,7 @@ int vo_kdtree_info(vo_kdtree* t, int* n_points, int* n_nodes, int* n_leaves) {
 }
 
 int vo_kdtree_best_match_fast_dev(vo_kdtree* t, const float* d_qry, int nq, float radius, int32_t* d_out) {
+  if (t && !vo_ctx_alive(t->ctx)) return vo_fail(VO_ERR_INVALID_ARG, "%s: the context this tree was made on has been destroyed", __func__);
   if (!t || nq < 0 || (nq > 0 && (!d_qry || !d_out))) return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_best_match_fast_dev: bad argument");
   if (nq == 0) return VO_OK;
   KD_CHECK(hipSetDevice(vo_ctx_device(t->ctx)));
@@ -281,6 +286,7 @@ int vo_kdtree_best_match_fast_dev(vo_kdtree* t, const float* d_qry, int nq, floa
 }
 
 int vo_kdtree_best_match_fast(vo_kdtree* t, const float* qry, int nq, float radius, int32_t* out) {
+  if (t && !vo_ctx_alive(t->ctx)) return vo_fail(VO_ERR_INVALID_ARG, "%s: the context this tree was made on has been destroyed", __func__);
   if (t && vo_ctx_capturing(t->ctx)) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
   if (!t || nq < 0 || (nq > 0 && (!qry || !out))) return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_best_match_fast: bad argument");
   if (nq == 0) return VO_OK;
@@ -297,6 +303,7 @@ int vo_kdtree_best_match_fast(vo_kdtree* t, const float* qry, int nq, float radi
 
 int vo_kdtree_fast_search_dev(vo_kdtree* t, const float* d_qry, int nq, float radius, int32_t* d_offsets, int32_t* d_indices,
                               int capacity) {
+  if (t && !vo_ctx_alive(t->ctx)) return vo_fail(VO_ERR_INVALID_ARG, "%s: the context this tree was made on has been destroyed", __func__);
   if (!t || nq < 0 || capacity < 0 || !d_offsets || (nq > 0 && !d_qry) || (capacity > 0 && !d_indices))
     return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_fast_search_dev: bad argument");
   KD_CHECK(hipSetDevice(vo_ctx_device(t->ctx)));
@@ -314,6 +321,7 @@ int vo_kdtree_fast_search_dev(vo_kdtree* t, const float* d_qry, int nq, float ra
 
 int vo_kdtree_fast_search(vo_kdtree* t, const float* qry, int nq, float radius, int32_t* offsets, int32_t* indices, int capacity,
                           int* n_total) {
+  if (t && !vo_ctx_alive(t->ctx)) return vo_fail(VO_ERR_INVALID_ARG, "%s: the context this tree was made on has been destroyed", __func__);
   if (t && vo_ctx_capturing(t->ctx)) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
   if (!t || nq < 0 || capacity < 0 || !offsets || !n_total || (nq > 0 && !qry) || (capacity > 0 && !indices))
     return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_fast_search: bad argument");

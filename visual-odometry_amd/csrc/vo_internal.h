@@ -10,6 +10,7 @@
 // records the message vo_last_error() returns on this thread and hands `code` back (capi.hip)
 int vo_fail(int code, const char* fmt, ...);
 extern "C" int vo_ctx_capturing(struct vo_ctx* ctx);   // 1 while a graph capture is in progress on the context (capi.hip)
+extern "C" int vo_ctx_alive(struct vo_ctx* ctx);       // 0 once the context has been destroyed (handles may outlive it)
 
 namespace vo {
 
