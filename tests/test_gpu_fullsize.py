@@ -102,3 +102,55 @@ def test_sequence_40x50k_is_bit_identical_to_ref32(vo, ctx, o32):
     # last bits: a borderline point may flip
     assert np.abs(c_fast[:, 1:] - counts[:, 1:]).max() <= 8
     assert np.abs(np.array(t_fast) - np.array(traj)).max() < 5e-4
+
+
+def test_properties_at_full_size(vo, ctx, o32):
+    """Size-independent properties of the path at 50 000 points (the oracle's double loops would take minutes here):
+    permutation equivariance and role symmetry of the matcher, join with the identity, transform round trip, triangulate ->
+    project consistency, solver independence of the correspondence order, reference-order solver = its own batched form."""
+    fp = vo.synth.frame_pair(N, seed=2000)
+    rng = np.random.default_rng(21)
+    a, b = fp["ref_app"], fp["cur_app"]
+    m = vo.compute_correspondences_images(a, b, ctx=ctx)
+    assert np.array_equal(m, fp["gt_matches"])                                      # the generator's permutation
+    # (1) permuting the queries permutes the answer; swapping the roles swaps the columns (equal sizes: either set may be "the tree")
+    pq = rng.permutation(N)
+    mb = vo.compute_correspondences_images(a, b[pq], ctx=ctx)
+    inv = np.empty(N, np.int64); inv[pq] = np.arange(N)
+    back = np.stack([m[:, 0], inv[m[:, 1]]], 1)
+    assert np.array_equal(mb[np.argsort(mb[:, 1], kind="stable")], back[np.argsort(back[:, 1], kind="stable")].astype(np.int32))
+    ms = vo.compute_correspondences_images(b, a, ctx=ctx)
+    assert np.array_equal(ms[np.argsort(ms[:, 1], kind="stable")][:, ::-1], m[np.argsort(m[:, 0], kind="stable")])
+    # (2) joining with the identity model (ref i <-> model i) renames nothing
+    ident = np.stack([np.arange(N), np.arange(N)], 1).astype(np.int32)
+    j = vo.extract_correspondences_world(m, ident, ctx=ctx)
+    assert np.array_equal(j, np.stack([m[:, 1], m[:, 0]], 1))
+    # (3) X^-1 (X p) = p up to two roundings
+    X = fp["X_gt"].astype(np.float64)
+    Xi = np.linalg.inv(X).astype(np.float32)
+    rt = vo.transform_points(Xi, vo.transform_points(fp["X_gt"], fp["model"], ctx=ctx), ctx=ctx)
+    assert np.abs(rt - fp["model"]).max() < 2e-5
+    # (4) what triangulates from the two views projects back onto the measurements of the second view
+    xyz, pairs, _ = vo.triangulate_points(fp["K"], fp["X_gt"], m, fp["ref_pts"], fp["cur_pts"], ctx=ctx)
+    assert len(xyz) > 0.97 * N                                       # a few rays diverge under 0.5 px of noise: cheirality reject
+    cam = vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], fp["X_gt"], ctx=ctx)   # the points live in the FIRST camera's frame
+    uv, n_in = cam.projectPoints(xyz, keep_indices=True)
+    ok = uv[:, 0] >= 0
+    assert ok.mean() > 0.9 and np.median(np.abs(uv[ok] - fp["cur_pts"][pairs[ok, 0]])) < 1.0       # 0.5 px of noise on both views, baseline 0.1: depth is loose, the reprojection is not
+    # (5) the fast solver does not care about the order of the correspondences beyond rounding; the exact one is its batched form
+    jw = vo.extract_correspondences_world(m, fp["model_pairs"], ctx=ctx)
+    poses = []
+    for order in (np.arange(len(jw)), rng.permutation(len(jw))):
+        s = vo.PICPSolver(ctx)
+        s.setKernelThreshold(10000.0)
+        s.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx), fp["model"], fp["cur_pts"])
+        s.solve(np.ascontiguousarray(jw[order]), False, 30)
+        poses.append(s.camera().worldInCameraPose().copy()); n_in_s = s.numInliers(); s.close()
+    assert np.abs(poses[0] - poses[1]).max() < 5e-6 and n_in_s == N and np.abs(poses[0] - fp["X_gt"]).max() < 1e-4
+    s = vo.PICPSolver(ctx)
+    s.setExact(True); s.setKernelThreshold(10000.0)
+    s.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx), fp["model"], fp["cur_pts"])
+    s.solve(jw, False, 6)
+    T_exact = s.camera().worldInCameraPose().copy(); s.close()
+    r = o32.picp_solve_raw(OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4)), fp["model"], fp["cur_pts"], jw, 6, 10000.0, False)
+    assert np.array_equal(T_exact, r["T"][-1])                      # 6 rounds x 50 000 sequential adds per accumulator: same bits
