@@ -2,6 +2,7 @@
 thread (grid-stride path), a solver reused across sizes, keep_outliers in the
 batched solver, empty problems in a batch, the device-resident frame pipeline."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -350,3 +351,53 @@ def test_two_solvers_interleaved_on_one_context(vo, ctx, o32):
     fp, j, thr, keep, _ = probs[1]                                          # and the exact one is the oracle's, bit for bit
     r = o32.picp_solve_raw(OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4)), fp["model"], fp["cur_pts"], j, 10, thr, keep)
     assert alone[1][-1] == r["T"][-1].astype(np.float32).tobytes()
+
+
+@pytest.mark.parametrize("n,keep,thr", [(1, False, 10000.0), (37, False, 10000.0), (127, True, 40.0), (256, False, 10000.0), (200, True, 25.0)])
+def test_small_problem_form_equals_the_round_kernels(vo, o32, n, keep, thr):
+    """Up to 256 correspondences the solver runs all rounds of a call in ONE launch (picp_small_kernel); VO_PICP_SMALL=0 keeps
+    the launch-per-round form.  Same arithmetic by construction: pose, H, b and the statistics must agree bit for bit, for one
+    round at a time as well as for a whole solve, and stay within the usual tolerance of the oracle."""
+    import subprocess, sys, json
+    code = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+vo = g.load_package()
+n, keep, thr = %d, %s, %r
+fp = vo.synth.frame_pair(max(n, 8), seed=9700 + n, noise_px=1.5)
+corr = np.stack([fp["gt_matches"][:n, 1], fp["model_pairs"][fp["gt_matches"][:n, 0], 1]], 1).astype(np.int32)
+ctx = vo.Context(0)
+out = []
+for mode in ("solve", "rounds"):
+    s = vo.PICPSolver(ctx)
+    s.setKernelThreshold(thr)
+    s.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx), fp["model"], fp["cur_pts"])
+    if mode == "solve":
+        s.solve(corr, keep, 9)
+    else:
+        for _ in range(9):
+            s.oneRound(corr, keep)
+    H, b = s.system()
+    out.append([s.camera().worldInCameraPose().tobytes().hex(), H.tobytes().hex(), b.tobytes().hex(),
+                float(s.chiInliers()).hex(), float(s.chiOutliers()).hex(), s.numInliers()])
+    s.close()
+print(json.dumps(out))
+''' % (os.path.join(os.path.dirname(__file__), ".."), n, keep, thr)
+    res = {}
+    for small in ("1", "0"):
+        env = dict(os.environ, VO_PICP_SMALL=small)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[small] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["1"][0] == res["1"][1]                    # one launch of nine rounds = nine launches of one
+    assert res["1"] == res["0"]                          # = the launch-per-round kernels, bit for bit
+    # and the oracle, within the fast mode's tolerance
+    fp = vo.synth.frame_pair(max(n, 8), seed=9700 + n, noise_px=1.5)
+    corr = np.stack([fp["gt_matches"][:n, 1], fp["model_pairs"][fp["gt_matches"][:n, 0], 1]], 1).astype(np.int32)
+    r = o32.picp_solve(OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4)), fp["model"], fp["cur_pts"], corr, 9, thr, keep, trace=False)
+    T = np.frombuffer(bytes.fromhex(res["1"][0][0]), np.float32).reshape(4, 4)
+    assert res["1"][0][5] == r["num_inliers"]
+    if n >= 16:
+        assert np.abs(T - r["T"]).max() < 1e-4

@@ -456,6 +456,90 @@ hipError_t launch_picp_pack(hipStream_t st, const int32_t* d_pairs, const int* d
   return hipGetLastError();
 }
 
+// ---- all rounds of ONE small problem in one launch ------------------------------------------------
+// A problem of at most PICP_BLOCK correspondences is one workgroup in the launch-per-round form, whose round then costs a kernel
+// boundary and a trip of its single partial row through memory for nothing (5.3 us, whatever the size -- the reference's dataset has
+// <= 127 points per frame).  Here the same workgroup keeps going: its correspondence stays in registers, the reduced row goes
+// through LDS, and the arithmetic is EXACTLY that of the launch-per-round form with one workgroup (same accumulation, same
+// workgroup reduction; the sum over "all partial rows" there is 0 + row + 0 + ..., i.e. the row, a -0.0f turned into +0.0f),
+// so the two forms return the same bits (tests/test_gpu_more.py::test_small_problem_form_equals_the_round_kernels).
+template <bool PINHOLE, bool KEEP>
+__global__ __launch_bounds__(PICP_BLOCK) void picp_small_kernel(const PicpParams* __restrict__ P, PicpState* S, const float* pk_base,
+                                                                size_t pk_cap, int n_iters) {
+  __shared__ __attribute__((aligned(16))) float s_acc[PICP_SACC];
+  __shared__ float s_part[PICP_PARTS * 32];
+  __shared__ float s_tot[32];
+  __shared__ float s_sys[PICP_BLOCK / 64][48];
+  __shared__ float s_stat[4];
+  const PackedCorr pk{const_cast<float*>(pk_base), pk_cap};
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int n = P->n_corr;
+  if (n > PICP_BLOCK) n = PICP_BLOCK;                   // (the host only picks this form for at most PICP_BLOCK correspondences)
+  const CamK cam = P->cam;
+  const float thr = P->thr, damping = P->damping;
+  const bool have = tid < n;
+  float x = 0.f, y = 0.f, z = 0.f, u = 0.f, v = 0.f;
+  if (have) { x = pk.arr(0)[tid]; y = pk.arr(1)[tid]; z = pk.arr(2)[tid]; u = pk.arr(3)[tid]; v = pk.arr(4)[tid]; }
+  Pose T = uniform_pose(load_pose12(S->pose[0]));
+  for (int it = 0; it < n_iters; ++it) {
+    const bool last = it == n_iters - 1;
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    if (have) picp_accumulate_t<PINHOLE, KEEP>(cam, T, thr, x, y, z, u, v, acc);
+    const float tot = block_reduce_lds256(acc, s_acc, s_part);
+    if (tid < 32) s_tot[tid] = tid < NACC ? tot : 0.f;
+    __syncthreads();
+    // every wave builds the system and solves it on its own (as step (4) of picp_round_body)
+    float* sys = s_sys[wave];
+    if (lane < 45) {
+      int slot;
+      bool diag = false;
+      if (lane < 36) {
+        const int r = lane / 6, c = lane - 6 * r;
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        slot = (13 * lo - lo * lo) / 2 + (hi - lo);
+        diag = r == c;
+      } else {
+        slot = 21 + (lane - 36);
+      }
+      const float tsum = 0.f + s_tot[slot];              // what summing the one partial row and its zero padding gives
+      if (lane < 36) {
+        const float hv = diag ? tsum + 1.f * damping : tsum;
+        sys[lane] = hv;
+        if (last && wave == 0) S->H[(lane % 6) * 6 + lane / 6] = hv;    // col-major
+      } else if (lane < 42) {
+        sys[lane] = -tsum;
+        if (last && wave == 0) S->b[lane - 36] = tsum;
+      } else if (wave == 0) {
+        s_stat[lane - 42] = tsum;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const Pose Tn = picp_tail_wave(sys, T);
+    if (last && tid == 0) {
+      store_pose12(S->pose[0], Tn);
+      float T16[16];
+      pose_to_T16(Tn, T16);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) S->T16[k] = T16[k];
+      S->chi_in = s_stat[0];
+      S->chi_out = s_stat[1];
+      S->n_in = (int)(s_stat[2] + 0.5f);
+    }
+    T = uniform_pose(Tn);
+    __syncthreads();                                     // s_acc / s_tot are reused by the next round
+  }
+}
+
+// VO_PICP_SMALL=0 in the environment keeps small problems on the launch-per-round form (the test of the equality above)
+static bool picp_small_enabled() {
+  static const bool on = [] { const char* e = getenv("VO_PICP_SMALL"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <bool PINHOLE, bool KEEP>
 static void launch_rounds_t(hipStream_t st, const PicpParams* d_params, PicpState* d_state, PackedCorr pk,
                             float* d_partials, int grid, int n_iters) {
@@ -472,6 +556,14 @@ hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpSt
                               PackedCorr pk, float* d_partials, int grid, int n_iters, bool pinhole,
                               bool keep_outliers) {
   if (n_iters <= 0) return hipSuccess;
+  if (grid == 1 && picp_small_enabled()) {      // one workgroup's worth of correspondences (picp_grid_for): all rounds in one launch
+    const dim3 g(1), b(PICP_BLOCK);
+    if (pinhole && keep_outliers) hipLaunchKernelGGL((picp_small_kernel<true, true>), g, b, 0, st, d_params, d_state, pk.base, pk.cap, n_iters);
+    else if (pinhole) hipLaunchKernelGGL((picp_small_kernel<true, false>), g, b, 0, st, d_params, d_state, pk.base, pk.cap, n_iters);
+    else if (keep_outliers) hipLaunchKernelGGL((picp_small_kernel<false, true>), g, b, 0, st, d_params, d_state, pk.base, pk.cap, n_iters);
+    else hipLaunchKernelGGL((picp_small_kernel<false, false>), g, b, 0, st, d_params, d_state, pk.base, pk.cap, n_iters);
+    return hipGetLastError();
+  }
   if (pinhole) {
     if (keep_outliers) launch_rounds_t<true, true>(st, d_params, d_state, pk, d_partials, grid, n_iters);
     else launch_rounds_t<true, false>(st, d_params, d_state, pk, d_partials, grid, n_iters);
