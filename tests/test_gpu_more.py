@@ -401,3 +401,23 @@ print(json.dumps(out))
     assert res["1"][0][5] == r["num_inliers"]
     if n >= 16:
         assert np.abs(T - r["T"]).max() < 1e-4
+
+
+def test_batched_frames_are_bitwise_reproducible_run_to_run(vo):
+    """The sorted matcher variants rank points inside a bin with LDS atomics (arbitrary order inside a bin), workgroups finish in
+    any order: none of that may reach a result.  40 runs of one 16-frame call: every output buffer identical, bit for bit."""
+    import hashlib
+    c = vo.Context(0)
+    fps = [vo.synth.frame_pair(6000, seed=9800 + 3 * k, distractors=40) for k in range(16)]
+    bp = vo.BatchPipeline(c, fps, n_iters=12)
+    seen = set()
+    for _ in range(40):
+        bp.run()
+        h = hashlib.sha256()
+        h.update(bp.counts().tobytes()); h.update(bp.poses().tobytes()); h.update(bp.stats().tobytes())
+        for f in (0, 7, 15):
+            for what in ("match", "join", "tri_xyz", "tri_pairs", "tri_app"):
+                h.update(bp.fetch(what, f).tobytes())
+        seen.add(h.hexdigest())
+    bp.close(); c.close()
+    assert len(seen) == 1
