@@ -66,6 +66,12 @@ class KdTree {
   //! eigen_kdtree.h:56-71 for every query: every point within `norm`
   std::vector<std::vector<int>> fullSearch(const Vector10fVector& queries, float norm) const { return full_search(points_, queries, norm); }
 
+  //! (points, nodes, leaves) of the tree
+  void info(int& n_points, int& n_nodes, int& n_leaves) const { check(vo_kdtree_info(h_, &n_points, &n_nodes, &n_leaves), "KdTree::info"); }
+  int size() const { int n, a, b; info(n, a, b); return n; }
+  int nodes() const { int n, a, b; info(n, a, b); return a; }
+  int leaves() const { int n, a, b; info(n, a, b); return b; }
+
   vo_kdtree* handle() const { return h_; }
 
  private:

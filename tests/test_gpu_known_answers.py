@@ -114,3 +114,18 @@ def test_vo_da_known_app(tmp_path, o32):
     q = subprocess.run([os.path.join(BIN, "vo_complete"), DATA, str(out2), "100", "--exact"], capture_output=True, text=True, timeout=300)
     assert q.returncode == 0
     assert np.array_equal(_poses_raw(out2 / "poses_raw.txt"), poses)
+
+
+def test_compute_corr_kdtree_and_read_data_apps():
+    """The remaining programs of the reference's src/tests/ on the GPU path: compute_corr (appearance matcher = id association on
+    every consecutive pair of the data directory), the kd-tree test (approximate against exact search) and read_data_test."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "apps"), "-s"])
+    p = subprocess.run([os.path.join(BIN, "compute_corr"), DATA], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr
+    assert "120 consecutive frame pairs" in p.stdout and "equals the id association everywhere" in p.stdout
+    for args in (["1"], ["2", "500", "200", "10"], ["3", "5000", "400", "20"], ["4", "7", "10", "10"]):
+        q = subprocess.run([os.path.join(BIN, "kdtree_test")] + args, capture_output=True, text=True, timeout=120)
+        assert q.returncode == 0, q.stdout[-1500:] + q.stderr
+        assert "tree ok" in q.stdout and "FAST" in q.stdout
+    r = subprocess.run([os.path.join(BIN, "read_data_test"), DATA], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "121 measurement files" in r.stdout and "world.dat: 1000 landmarks" in r.stdout, r.stdout
