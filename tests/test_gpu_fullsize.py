@@ -4,7 +4,7 @@
    (gridDim over 200 frames, 200 MB of packed correspondences, the cell-hash matcher picked by the auto rule): every
    frame against the generator's ground truth, three frames stage by stage against the oracle (its matcher is the
    reference's own PCA kd-tree: the double loop would take minutes).
- * config 3: the device-resident sequence at 40 frames x ~50k landmarks in view x 100 rounds, solver in reference-order
+ * config 3: the device-resident sequence at its full 200 frames x ~50k landmarks in view x 100 rounds, solver in reference-order
    arithmetic: every count and every pose of the chain against the oracle-side run of the same loop, bit for bit.
 """
 import ctypes as C
@@ -74,8 +74,9 @@ def test_batched_frames_reference_order_form(vo, ctx, o32):
         ctx.lib.vo_picp_batch_set_form(ctx.h, 0)
 
 
-def test_sequence_40x50k_is_bit_identical_to_ref32(vo, ctx, o32):
-    seq = vo.synth.sequence(seed=3000, n_frames=40, n_visible=N)
+@pytest.mark.parametrize("n_frames", [200])            # BASELINE config 3 at its full length (40 frames until the reference-order solver got 5x faster)
+def test_sequence_200x50k_is_bit_identical_to_ref32(vo, ctx, o32, n_frames):
+    seq = vo.synth.sequence(seed=3000, n_frames=n_frames, n_visible=N)
     n = [len(f["pts"]) for f in seq["frames"]]
     assert min(n) > 45000
     sp = vo.SequencePipeline(ctx, seq, n_iters=100)
@@ -101,7 +102,8 @@ def test_sequence_40x50k_is_bit_identical_to_ref32(vo, ctx, o32):
     # joined pairs follow the previous frame's triangulation, whose cheirality test sees a pose that differs in the
     # last bits: a borderline point may flip
     assert np.abs(c_fast[:, 1:] - counts[:, 1:]).max() <= 8
-    assert np.abs(np.array(t_fast) - np.array(traj)).max() < 5e-4
+    # rounding-level differences of one frame's pose scale the next frame's model: over 200 chained frames they grow to ~2e-3
+    assert np.abs(np.array(t_fast) - np.array(traj)).max() < 5e-3 and np.abs(np.array(t_fast[:40]) - np.array(traj[:40])).max() < 5e-4
 
 
 def test_properties_at_full_size(vo, ctx, o32):
