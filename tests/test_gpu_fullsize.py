@@ -54,24 +54,30 @@ def test_batched_frames_200x50k(vo, ctx, o32):
     bp.close()
 
 
-def test_batched_frames_reference_order_form(vo, ctx, o32):
+@pytest.mark.parametrize("n,f", [(6000, 12), (N, 24)])
+def test_batched_frames_reference_order_form(vo, ctx, o32, n, f):
     """the same call with the solver stage in reference-order arithmetic (vo_picp_batch_set_form(3)): poses and
-    statistics of every frame equal ref32 bit for bit (12 frames x 6 000 points: the form is ~1 ms per 50k-round)"""
-    fps = [vo.synth.frame_pair(6000, seed=4100 + p, drop=0.0) for p in range(12)]
+    statistics of every frame equal ref32 bit for bit -- 12 frames x 6 000 points, and 24 frames x 50 000 points x 50 rounds
+    (one workgroup per frame, 0.18 ms per round)"""
+    fps = [vo.synth.frame_pair(n, seed=4100 + p) for p in range(f)]
     assert ctx.lib.vo_picp_batch_set_form(ctx.h, 3) == 0
     try:
-        bp = vo.BatchPipeline(ctx, fps, n_iters=20)
+        bp = vo.BatchPipeline(ctx, fps, n_iters=ITERS if n == N else 20)
         bp.run()
-        ctx.synchronize()
-        T, st, c = bp.poses(), bp.stats(), bp.counts()
-        for f, fp in enumerate(fps):
-            j = bp.fetch("join", f)
-            r = o32.picp_solve_raw(OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4)), fp["model"],
-                                   fp["cur_pts"], j, 20, 10000.0, False)
-            assert np.array_equal(T[f], r["T"][-1]) and np.array_equal(st[f, :3], r["stats"][-1])
+        T, st = bp.poses(), bp.stats()
+        for i, fp in enumerate(fps):
+            j = bp.fetch("join", i)
+            if n == N:
+                assert len(j) == n                       # (the matcher and the join are checked against the oracle elsewhere)
+            else:
+                assert np.array_equal(j, o32.join(o32.match(fp["ref_app"], fp["cur_app"]), fp["model_pairs"]))
+            r = o32.picp_solve(OCam(480, 640, 0, 10, fp["K"], np.eye(4)), fp["model"], fp["cur_pts"], j, ITERS if n == N else 20, 10000.0, False,
+                               trace=False)
+            assert np.array_equal(T[i], r["T"].astype(np.float32)), i
+            assert st[i, 0] == np.float32(r["chi_inliers"]) and st[i, 1] == np.float32(r["chi_outliers"]) and int(st[i, 2]) == r["num_inliers"]
         bp.close()
     finally:
-        ctx.lib.vo_picp_batch_set_form(ctx.h, 0)
+        assert ctx.lib.vo_picp_batch_set_form(ctx.h, 0) == 0
 
 
 @pytest.mark.parametrize("n_frames", [200])            # BASELINE config 3 at its full length (40 frames until the reference-order solver got 5x faster)
