@@ -127,5 +127,8 @@ def test_compute_corr_kdtree_and_read_data_apps():
         q = subprocess.run([os.path.join(BIN, "kdtree_test")] + args, capture_output=True, text=True, timeout=120)
         assert q.returncode == 0, q.stdout[-1500:] + q.stderr
         assert "tree ok" in q.stdout and "FAST" in q.stdout
+    for seed in ("3", "5", "11", "12", "13"):              # initialization_test.cpp: rotation 1e-4, translation ratios consistent
+        t = subprocess.run([os.path.join(BIN, "init_test"), seed, "4000"], capture_output=True, text=True, timeout=60)
+        assert t.returncode == 0, t.stdout + t.stderr
     r = subprocess.run([os.path.join(BIN, "read_data_test"), DATA], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "121 measurement files" in r.stdout and "world.dat: 1000 landmarks" in r.stdout, r.stdout
