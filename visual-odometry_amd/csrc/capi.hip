@@ -106,6 +106,7 @@ struct vo_ctx {
   int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan, 3 cell-hash search
   int batch_form = 0; // batched solver: 0 auto, 1 one launch per round, 2 one workgroup per problem
   bool capturing = false;
+  unsigned long long id = 0;   // unique per context ever created: an address can be reused, an id cannot
 };
 
 struct vo_event {
@@ -118,18 +119,26 @@ struct vo_event {
 // languages), so a handle that outlives its context must fail cleanly when used and must still be destroyable.
 static std::mutex g_ctx_mu;
 static std::set<const vo_ctx*> g_ctx_live;
+static unsigned long long g_ctx_next_id = 1;
 static bool ctx_alive(const vo_ctx* c) {
   std::lock_guard<std::mutex> lk(g_ctx_mu);
   return c && g_ctx_live.count(c) != 0;
 }
+// the context a handle was made on: still there, and still THAT context (not a new one at the recycled address)
+static bool ctx_alive(const vo_ctx* c, unsigned long long id) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  return c && g_ctx_live.count(c) != 0 && c->id == id;
+}
 
 struct vo_graph {
   vo_ctx* ctx = nullptr;
+  unsigned long long ctx_id = 0;
   hipGraphExec_t exec = nullptr;
 };
 
 struct vo_picp {
   vo_ctx* ctx = nullptr;
+  unsigned long long ctx_id = 0;
   PicpParams hp;               // host mirror of the device parameters
   PicpParams* d_params = nullptr;
   PicpState* d_state = nullptr;
@@ -189,7 +198,7 @@ int vo_ctx_create(int device, void* stream, vo_ctx** out) {
     if (es != hipSuccess) { delete c; return fail(VO_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(es)); }
     c->own_stream = true;
   }
-  { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctx_live.insert(c); }
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); c->id = g_ctx_next_id++; g_ctx_live.insert(c); }
   *out = c;
   return VO_OK;
 }
@@ -222,6 +231,7 @@ void* vo_ctx_stream(vo_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) :
 int vo_ctx_device(vo_ctx* c) { return c ? c->device : -1; }
 int vo_ctx_capturing(vo_ctx* c) { return (ctx_alive(c) && c->capturing) ? 1 : 0; }
 int vo_ctx_alive(vo_ctx* c) { return ctx_alive(c) ? 1 : 0; }
+unsigned long long vo_ctx_id(vo_ctx* c) { std::lock_guard<std::mutex> lk(g_ctx_mu); return (c && g_ctx_live.count(c)) ? c->id : 0ull; }
 
 int vo_ctx_device_info(vo_ctx* c, char* name, int name_len, int* n_cu) {
   VO_REQUIRE(c, "ctx is null");
@@ -266,6 +276,7 @@ int vo_ctx_end_capture(vo_ctx* c, vo_graph** out) {
   if (e != hipSuccess) { (void)hipGetLastError(); return fail(VO_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
   vo_graph* g = new vo_graph();
   g->ctx = c;
+  g->ctx_id = c->id;
   g->exec = exec;
   *out = g;
   return VO_OK;
@@ -273,7 +284,7 @@ int vo_ctx_end_capture(vo_ctx* c, vo_graph** out) {
 
 int vo_graph_launch(vo_graph* g) {
   VO_REQUIRE(g && g->exec, "null graph");
-  VO_REQUIRE(ctx_alive(g->ctx), "the context this graph was captured on has been destroyed");
+  VO_REQUIRE(ctx_alive(g->ctx, g->ctx_id), "the context this graph was captured on has been destroyed");
   if (int r = set_device(g->ctx)) return r;
   VO_HIP_CHECK(hipGraphLaunch(g->exec, g->ctx->stream));
   return VO_OK;
@@ -281,7 +292,7 @@ int vo_graph_launch(vo_graph* g) {
 
 int vo_graph_destroy(vo_graph* g) {
   if (!g) return VO_OK;
-  if (ctx_alive(g->ctx)) (void)hipStreamSynchronize(g->ctx->stream);
+  if (ctx_alive(g->ctx, g->ctx_id)) (void)hipStreamSynchronize(g->ctx->stream);
   else (void)hipDeviceSynchronize();
   if (g->exec) (void)hipGraphExecDestroy(g->exec);
   delete g;
@@ -433,6 +444,7 @@ int vo_picp_create(vo_ctx* c, vo_picp** out) {
   if (int r = set_device(c)) return r;
   vo_picp* s = new vo_picp();
   s->ctx = c;
+  s->ctx_id = c->id;
   memset(&s->hp, 0, sizeof(s->hp));
   const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   s->hp.cam = make_cam(100, 100, 0, 10, I3);     // Camera defaults, camera.h:16-21
@@ -461,7 +473,7 @@ int vo_picp_create(vo_ctx* c, vo_picp** out) {
 
 int vo_picp_destroy(vo_picp* s) {
   if (!s) return VO_OK;
-  if (ctx_alive(s->ctx)) {
+  if (ctx_alive(s->ctx, s->ctx_id)) {
     VO_NOT_CAPTURING(s->ctx);
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
@@ -479,7 +491,7 @@ int vo_picp_destroy(vo_picp* s) {
 
 int vo_picp_set_pose(vo_picp* s, const float T[16]) {
   VO_REQUIRE(s && T, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   if (int r = set_device(s->ctx)) return r;
   const Pose P = pose_from_T16(T);
@@ -496,7 +508,7 @@ int vo_picp_set_pose(vo_picp* s, const float T[16]) {
 int vo_picp_set_camera(vo_picp* s, int rows, int cols, int z_near, int z_far, const float K[9],
                        const float T[16]) {
   VO_REQUIRE(s && K && T, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   s->hp.cam = make_cam(rows, cols, z_near, z_far, K);
   s->params_dirty = true;
   return vo_picp_set_pose(s, T);
@@ -504,7 +516,7 @@ int vo_picp_set_camera(vo_picp* s, int rows, int cols, int z_near, int z_far, co
 
 int vo_picp_set_kernel_threshold(vo_picp* s, float thr) {
   VO_REQUIRE(s, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   s->hp.thr = thr;
   s->params_dirty = true;
   return VO_OK;
@@ -512,14 +524,14 @@ int vo_picp_set_kernel_threshold(vo_picp* s, float thr) {
 
 int vo_picp_get_kernel_threshold(vo_picp* s, float* thr) {
   VO_REQUIRE(s && thr, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   *thr = s->hp.thr;
   return VO_OK;
 }
 
 int vo_picp_set_points_dev(vo_picp* s, const float* d_world, int n_world, const float* d_meas, int n_meas) {
   VO_REQUIRE(s, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   VO_REQUIRE(n_world >= 0 && n_meas >= 0, "negative count");
   VO_REQUIRE((n_world == 0 || d_world) && (n_meas == 0 || d_meas), "null point array");
   s->d_world = d_world; s->n_world = n_world;
@@ -531,7 +543,7 @@ int vo_picp_set_points_dev(vo_picp* s, const float* d_world, int n_world, const 
 
 int vo_picp_set_points(vo_picp* s, const float* world, int n_world, const float* meas, int n_meas) {
   VO_REQUIRE(s, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   VO_REQUIRE(n_world >= 0 && n_meas >= 0, "negative count");
   VO_REQUIRE((n_world == 0 || world) && (n_meas == 0 || meas), "null point array");
@@ -640,7 +652,7 @@ extern "C" {
 int vo_picp_solve_dev(vo_picp* s, const int32_t* d_pairs, int n_pairs, const int* d_n_pairs,
                       int keep_outliers, int n_iters) {
   VO_REQUIRE(s, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || d_pairs), "bad pairs");
   VO_REQUIRE(n_iters >= 0, "negative n_iters");
   if (int r = set_device(s->ctx)) return r;
@@ -671,7 +683,7 @@ static int picp_take_pairs(vo_picp* s, const int32_t* pairs, int n_pairs) {
 
 int vo_picp_solve(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_outliers, int n_iters) {
   VO_REQUIRE(s, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || pairs), "bad pairs");
   VO_REQUIRE(n_iters >= 0, "negative n_iters");
@@ -687,7 +699,7 @@ int vo_picp_one_round(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_ou
 
 int vo_picp_set_correspondences(vo_picp* s, const int32_t* pairs, int n_pairs) {
   VO_REQUIRE(s, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || pairs), "bad pairs");
   if (int r = set_device(s->ctx)) return r;
@@ -700,7 +712,7 @@ int vo_picp_set_correspondences(vo_picp* s, const int32_t* pairs, int n_pairs) {
 
 int vo_picp_rounds(vo_picp* s, int keep_outliers, int n_iters) {
   VO_REQUIRE(s, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   VO_REQUIRE(n_iters >= 0, "negative n_iters");
   if (s->set_n < 0 || !s->shadow_valid)
     return fail(VO_ERR_NOT_READY, "vo_picp_rounds: vo_picp_set_correspondences has not been called");
@@ -711,7 +723,7 @@ int vo_picp_rounds(vo_picp* s, int keep_outliers, int n_iters) {
 
 int vo_picp_set_exact(vo_picp* s, int on) {
   VO_REQUIRE(s, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   s->exact = on ? 1 : 0;
   return VO_OK;
 }
@@ -726,7 +738,7 @@ static int picp_read_state(vo_picp* s, PicpState* h) {
 
 int vo_picp_get_pose(vo_picp* s, float T[16]) {
   VO_REQUIRE(s && T, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   if (int r = set_device(s->ctx)) return r;
   PicpState h;
@@ -740,7 +752,7 @@ int vo_picp_get_pose(vo_picp* s, float T[16]) {
 
 int vo_picp_set_pose_dev(vo_picp* s, const float* d_T16) {
   VO_REQUIRE(s && d_T16, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   // consumed by the next solve: folded into its gather launch (or a 12-thread launch of its own)
   s->pending_T0 = d_T16;
   return VO_OK;
@@ -748,7 +760,7 @@ int vo_picp_set_pose_dev(vo_picp* s, const float* d_T16) {
 
 int vo_picp_pose_dev_ptr(vo_picp* s, const float** d_T16) {
   VO_REQUIRE(s && d_T16, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   *d_T16 = s->d_state->T16;
   return VO_OK;
 }
@@ -767,7 +779,7 @@ __global__ void pose12_to_T16_kernel(const float* p, float* T) {
 
 int vo_picp_get_pose_dev(vo_picp* s, float* d_T16) {
   VO_REQUIRE(s && d_T16, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   if (int r = set_device(s->ctx)) return r;
   hipLaunchKernelGGL(pose12_to_T16_kernel, dim3(1), dim3(64), 0, s->ctx->stream, s->d_state->pose[0], d_T16);
   VO_HIP_CHECK(hipGetLastError());
@@ -776,7 +788,7 @@ int vo_picp_get_pose_dev(vo_picp* s, float* d_T16) {
 
 int vo_picp_get_stats(vo_picp* s, float* chi_in, float* chi_out, int* n_in) {
   VO_REQUIRE(s, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   if (int r = set_device(s->ctx)) return r;
   PicpState h;
@@ -800,7 +812,7 @@ int vo_debug_get_stamps(vo_picp* s, unsigned long long* out) {
 
 int vo_picp_get_system(vo_picp* s, float H[36], float b[6]) {
   VO_REQUIRE(s, "null argument");
-  VO_REQUIRE(ctx_alive(s->ctx), "the context this solver was made on has been destroyed");
+  VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   VO_NOT_CAPTURING(s->ctx);
   if (int r = set_device(s->ctx)) return r;
   PicpState h;

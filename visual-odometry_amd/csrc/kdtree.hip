@@ -188,6 +188,7 @@ using namespace vo;
 
 struct vo_kdtree {
   vo_ctx* ctx = nullptr;
+  unsigned long long ctx_id = 0;
   int n = 0, n_nodes = 0, n_leaves = 0, depth = 0;
   KdNode* d_nodes = nullptr;
   float* d_pts = nullptr;
@@ -231,7 +232,7 @@ int vo_kdtree_create(vo_ctx* c, const float* app, int n, int max_points_in_leaf,
   for (int i = 0; i < n; ++i) h.index[(size_t)i] = i;
   h.build(0, n);
   vo_kdtree* t = new vo_kdtree();
-  t->ctx = c; t->n = n; t->n_nodes = (int)h.nodes.size();
+  t->ctx = c; t->ctx_id = vo_ctx_id(c); t->n = n; t->n_nodes = (int)h.nodes.size();
   for (const KdNode& nd : h.nodes) if (nd.left < 0) ++t->n_leaves;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->d_nodes), sizeof(KdNode) * h.nodes.size());
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_pts), sizeof(float) * KD * (size_t)(n ? n : 1));
@@ -252,9 +253,9 @@ int vo_kdtree_create(vo_ctx* c, const float* app, int n, int max_points_in_leaf,
 }
 
 int vo_kdtree_destroy(vo_kdtree* t) {
-  if (t && vo_ctx_capturing(t->ctx)) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
+  if (t && ((vo_ctx_id(t->ctx) == t->ctx_id && t->ctx_id != 0) && vo_ctx_capturing(t->ctx))) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
   if (!t) return VO_OK;
-  if (vo_ctx_alive(t->ctx)) {
+  if ((vo_ctx_id(t->ctx) == t->ctx_id && t->ctx_id != 0)) {
     (void)hipSetDevice(vo_ctx_device(t->ctx));
     (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(vo_ctx_stream(t->ctx)));
   } else {
@@ -274,7 +275,7 @@ int vo_kdtree_info(vo_kdtree* t, int* n_points, int* n_nodes, int* n_leaves) {
 }
 
 int vo_kdtree_best_match_fast_dev(vo_kdtree* t, const float* d_qry, int nq, float radius, int32_t* d_out) {
-  if (t && !vo_ctx_alive(t->ctx)) return vo_fail(VO_ERR_INVALID_ARG, "%s: the context this tree was made on has been destroyed", __func__);
+  if (t && !(vo_ctx_id(t->ctx) == t->ctx_id && t->ctx_id != 0)) return vo_fail(VO_ERR_INVALID_ARG, "%s: the context this tree was made on has been destroyed", __func__);
   if (!t || nq < 0 || (nq > 0 && (!d_qry || !d_out))) return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_best_match_fast_dev: bad argument");
   if (nq == 0) return VO_OK;
   KD_CHECK(hipSetDevice(vo_ctx_device(t->ctx)));
@@ -286,8 +287,8 @@ int vo_kdtree_best_match_fast_dev(vo_kdtree* t, const float* d_qry, int nq, floa
 }
 
 int vo_kdtree_best_match_fast(vo_kdtree* t, const float* qry, int nq, float radius, int32_t* out) {
-  if (t && !vo_ctx_alive(t->ctx)) return vo_fail(VO_ERR_INVALID_ARG, "%s: the context this tree was made on has been destroyed", __func__);
-  if (t && vo_ctx_capturing(t->ctx)) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
+  if (t && !(vo_ctx_id(t->ctx) == t->ctx_id && t->ctx_id != 0)) return vo_fail(VO_ERR_INVALID_ARG, "%s: the context this tree was made on has been destroyed", __func__);
+  if (t && ((vo_ctx_id(t->ctx) == t->ctx_id && t->ctx_id != 0) && vo_ctx_capturing(t->ctx))) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
   if (!t || nq < 0 || (nq > 0 && (!qry || !out))) return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_best_match_fast: bad argument");
   if (nq == 0) return VO_OK;
   KD_CHECK(hipSetDevice(vo_ctx_device(t->ctx)));
@@ -303,7 +304,7 @@ int vo_kdtree_best_match_fast(vo_kdtree* t, const float* qry, int nq, float radi
 
 int vo_kdtree_fast_search_dev(vo_kdtree* t, const float* d_qry, int nq, float radius, int32_t* d_offsets, int32_t* d_indices,
                               int capacity) {
-  if (t && !vo_ctx_alive(t->ctx)) return vo_fail(VO_ERR_INVALID_ARG, "%s: the context this tree was made on has been destroyed", __func__);
+  if (t && !(vo_ctx_id(t->ctx) == t->ctx_id && t->ctx_id != 0)) return vo_fail(VO_ERR_INVALID_ARG, "%s: the context this tree was made on has been destroyed", __func__);
   if (!t || nq < 0 || capacity < 0 || !d_offsets || (nq > 0 && !d_qry) || (capacity > 0 && !d_indices))
     return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_fast_search_dev: bad argument");
   KD_CHECK(hipSetDevice(vo_ctx_device(t->ctx)));
@@ -321,8 +322,8 @@ int vo_kdtree_fast_search_dev(vo_kdtree* t, const float* d_qry, int nq, float ra
 
 int vo_kdtree_fast_search(vo_kdtree* t, const float* qry, int nq, float radius, int32_t* offsets, int32_t* indices, int capacity,
                           int* n_total) {
-  if (t && !vo_ctx_alive(t->ctx)) return vo_fail(VO_ERR_INVALID_ARG, "%s: the context this tree was made on has been destroyed", __func__);
-  if (t && vo_ctx_capturing(t->ctx)) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
+  if (t && !(vo_ctx_id(t->ctx) == t->ctx_id && t->ctx_id != 0)) return vo_fail(VO_ERR_INVALID_ARG, "%s: the context this tree was made on has been destroyed", __func__);
+  if (t && ((vo_ctx_id(t->ctx) == t->ctx_id && t->ctx_id != 0) && vo_ctx_capturing(t->ctx))) return vo_fail(VO_ERR_NOT_READY, "%s: not allowed inside a graph capture", __func__);
   if (!t || nq < 0 || capacity < 0 || !offsets || !n_total || (nq > 0 && !qry) || (capacity > 0 && !indices))
     return vo_fail(VO_ERR_INVALID_ARG, "vo_kdtree_fast_search: bad argument");
   KD_CHECK(hipSetDevice(vo_ctx_device(t->ctx)));

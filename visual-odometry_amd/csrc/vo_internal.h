@@ -11,6 +11,7 @@
 int vo_fail(int code, const char* fmt, ...);
 extern "C" int vo_ctx_capturing(struct vo_ctx* ctx);   // 1 while a graph capture is in progress on the context (capi.hip)
 extern "C" int vo_ctx_alive(struct vo_ctx* ctx);       // 0 once the context has been destroyed (handles may outlive it)
+extern "C" unsigned long long vo_ctx_id(struct vo_ctx* ctx);   // unique id of a live context (0: not alive): addresses get recycled, ids do not
 
 namespace vo {
 
