@@ -14,8 +14,10 @@ corr = np.stack([fp["gt_matches"][:n, 1], fp["model_pairs"][fp["gt_matches"][:n,
 ctx = vo.Context(0)
 s = vo.PICPSolver(ctx)
 s.setKernelThreshold(10000.0)
+exact = os.environ.get("EXACT", "0") == "1"
+s.setExact(exact)
 cam = vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx)
 for rep in range(3):
     s.init(cam, fp["model"], fp["cur_pts"]); s.setCorrespondences(corr)
     t0 = time.perf_counter(); s.rounds(False, rounds); T = s.camera().worldInCameraPose(); dt = time.perf_counter() - t0
-print(f"VO_PICP_SMALL={os.environ.get('VO_PICP_SMALL', '1')}: {n} correspondences, {rounds} rounds: {dt*1e3:.2f} ms = {dt/rounds*1e6:.2f} us per round; pose err {np.abs(T - fp['X_gt']).max():.1e}")
+print(f"exact={int(exact)} VO_PICP_SMALL={os.environ.get('VO_PICP_SMALL', '1')}: {n} correspondences, {rounds} rounds: {dt*1e3:.2f} ms = {dt/rounds*1e6:.2f} us per round; pose err {np.abs(T - fp['X_gt']).max():.1e}")
