@@ -1,6 +1,6 @@
 // valu_rate.hip -- microbenchmark: sustained issue rate of v_fma_f32 vs
 // v_pk_fma_f32 on gfx950 as a function of waves per SIMD.  Diagnostic tool,
-// not part of the library.   hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o /tmp/valu_rate
+// not part of the library.   hipcc --offload-arch=gfx950 -O3 tools/micro/valu_rate.hip -o /tmp/valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
