@@ -790,7 +790,8 @@ __global__ __launch_bounds__(EX_BLOCK) void picp_exact_kernel(ExactArgs a) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const bool producer = wave != 0 && wave != 4;
-  const int pt = ((wave < 4 ? wave - 1 : wave - 2) << 6) | (tid & 63);       // producer thread 0 .. EX_CHUNK-1
+  const int pw = wave < 4 ? wave - 1 : wave - 2;                            // producer wave 0 .. 5 (waves 0 and 4 produce nothing)
+  const int pt = (pw < 0 ? 0 : pw) * 64 + (tid & 63);                       // producer thread 0 .. EX_CHUNK-1
   const size_t p = blockIdx.x;
   CamK cam; float thr, damping; int keep, n;
   Pose T;
