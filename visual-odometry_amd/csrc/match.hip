@@ -827,11 +827,11 @@ __global__ __launch_bounds__(256) void cell_coarse_hist_kernel(CellArgs a) {
   bool is_t; int lo, hi;
   cell_slice(blk, a.nt, a.nq, a.tb, a.qb, is_t, lo, hi);
   const float* src = is_t ? a.tree + f * a.tree_stride : a.qry + f * a.qry_stride;
+  // only the two coarse components are needed here (wave-uniform column indices): two 4-byte loads per point instead of the row
+  const int d0 = cp.dim[0], d1 = cp.dim[1];
   for (int i = lo + threadIdx.x; i < hi; i += 256) {
-    float v[10];
-    load10(src + 10 * (size_t)i, v);
-    int coarse, fine;
-    cell_bins(v, cp, coarse, fine);
+    const float x0 = src[10 * (size_t)i + d0], x1 = src[10 * (size_t)i + d1];
+    const int coarse = cell_of(x0, cp.lo[0], cp.scale[0], cp.nc[0]) * cp.nc[1] + cell_of(x1, cp.lo[1], cp.scale[1], cp.nc[1]);
     atomicAdd(&s_h[coarse], 1);
   }
   __syncthreads();
