@@ -86,6 +86,8 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    if 0 < args.strong_pairs < args.gpus:
+        raise SystemExit(f"--strong-pairs {args.strong_pairs} < --gpus {args.gpus}: every rank needs at least one pair")
     # VO_BENCH_FORCE_LAUNCH=1: take the self-launch route with one rank too (rehearsal of the N-rank path on a 1-GPU box)
     if (args.gpus > 1 or os.environ.get("VO_BENCH_FORCE_LAUNCH") == "1") and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))
@@ -210,11 +212,7 @@ def main():
                 out["sequence"] = sequence_leg(vo, ctx, args)
         if args.cpu_seconds > 0 and world == 1 and "cpu" in legs:
             out["cpu_baseline"] = cpu_leg(fp, pipe, args)
-            if "exact_mode" in out:     # same pair, same rounds: the reference-order GPU pose against the CPU restatement's
-                out["exact_mode"]["bit_identical_to_cpu_baseline"] = bool(np.array_equal(out["exact_mode"]["_pose"], out["cpu_baseline"].pop("_pose")))
-                out["exact_mode"]["vs_cpu_baseline"] = out["exact_mode"]["iters_per_sec"] / out["cpu_baseline"]["value"]
-        if "exact_mode" in out:
-            out["exact_mode"].pop("_pose", None)
+        _relate_exact_and_cpu(out)
     pipe.close()
     _PairGen.stop_pool()
     if dist is not None:
@@ -223,6 +221,18 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _relate_exact_and_cpu(out):
+    """The exact-mode leg and the CPU leg each carry their final pose (an ndarray) under "_pose": compare them when both
+    ran (same pair, same rounds: bit for bit), and take the arrays out of the dicts whichever legs ran -- the line must
+    stay JSON-serialisable for every --legs selection."""
+    ex, cpu = out.get("exact_mode"), out.get("cpu_baseline")
+    ex_pose = ex.pop("_pose", None) if ex is not None else None
+    cpu_pose = cpu.pop("_pose", None) if cpu is not None else None
+    if ex_pose is not None and cpu_pose is not None:
+        ex["bit_identical_to_cpu_baseline"] = bool(np.array_equal(ex_pose, cpu_pose))
+        ex["vs_cpu_baseline"] = ex["iters_per_sec"] / cpu["value"]
 
 
 def _pmc_file():
@@ -380,10 +390,8 @@ def frame_throughput_strong(vo, torch, ctx, stream, args, dist=None, vdist=None,
     Total work is fixed as the rank count grows: strong scaling.  One GPU runs all 1600 (in calls of
     --strong-per-call frames)."""
     P = args.strong_pairs
-    sh = vdist.shard_range
-    lo, hi = sh(P, rank, world)
-    n_local = hi - lo
-    blk = sh(P, 0, world)[1]                                # largest block: the gather needs equal-sized blocks
+    plan = vdist.StrongPlan(P, rank, world)                 # contiguous blocks; the gather needs equal-sized ones (padding)
+    lo, hi, n_local, blk = plan.lo, plan.hi, plan.n_local, plan.blk
     gen = _PairGen(args.points, lo)
     t0 = time.perf_counter()
     poses_t = torch.zeros((blk, 16), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
@@ -395,7 +403,9 @@ def frame_throughput_strong(vo, torch, ctx, stream, args, dist=None, vdist=None,
     sec, all_poses = _timed_batches(torch, ctx, bp, poses_t, dist, vdist, 2)
     if dist is not None:
         assert all_poses.shape == (world * blk, 16)
-        assert torch.equal(all_poses[rank * blk:rank * blk + n_local], poses_t[:n_local])
+        r0, r1 = plan.own_rows()
+        assert torch.equal(all_poses[r0:r1], poses_t[:n_local])
+        assert plan.global_order(all_poses).shape == (P, 16)
     err = _check_batches(bp, args.points)
     bp.close()
     alg = _frame_alg_bytes(args.points, args.iters) * P

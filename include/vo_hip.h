@@ -149,6 +149,11 @@ int vo_picp_solve(vo_picp *s, const int32_t *pairs, int n_pairs, int keep_outlie
  * (always uploaded), then run rounds on them with no per-call comparison at all. */
 int vo_picp_set_correspondences(vo_picp *s, const int32_t *pairs, int n_pairs);
 int vo_picp_rounds(vo_picp *s, int keep_outliers, int n_iters);
+/* Launch-graph bookkeeping of a handle (any pointer may be NULL): whether multi-round solves are replayed from a captured
+ * hipGraph (1) or issued as plain launches (0: VO_PICP_GRAPH=0, or a capture failed), how many graphs are cached, and how
+ * many captures failed.  A failed capture does not fail the solve -- the same kernels run as plain launches -- but it is
+ * reported once through vo_last_error() and counted here instead of passing unnoticed. */
+int vo_picp_graph_info(vo_picp *s, int *use_graph, int *n_graphs, int *n_failures);
 /* Reference-order arithmetic (off by default).  on != 0: every later round of this handle is computed
  * with the reference's own rounding -- per-correspondence terms unfused, (J0r*J0c + J1r*J1c)*lambda,
  * H / b / chi summed sequentially in correspondence order (picp_solver.cpp:62-95), Eigen's pivoted
@@ -233,7 +238,10 @@ int vo_radius_search_dev(vo_ctx *ctx, const float *d_tree_app, int n_tree, const
 /* bestMatchFast and fastSearch descend ONE side of every PCA split plane and brute-force the leaf they reach: their
  * answers depend on the tree (split directions, order of the points inside a leaf), so the tree is a handle.
  * vo_kdtree_create builds it on the host like the TreeNode_ constructor (:18-38; mean/covariance in float in array
- * order, eigen_covariance.h:5-43 with a double Jacobi for the eigen-solver, the two-pointer partition of split.h:8-34,
+ * order, eigen_covariance.h:5-43 with a double Jacobi for the eigen-solver -- the split normal's sign is fixed by
+ * convention (largest-magnitude component positive), which Eigen's SelfAdjointEigenSolver does not promise: every leaf
+ * holds the same SET of points as the reference's up to the solver's sign / degeneracy, the order inside a leaf (and with
+ * it bestMatchFast's first-minimum tie and fastSearch's result order) may differ --, the two-pointer partition of split.h:8-34,
  * recursion while a node holds >= max_points_in_leaf points; a node whose points all fall on one side becomes a leaf --
  * the reference recurses forever there) and uploads it; queries run on the GPU, one lane per query.  points: host
  * float[10n] (the reference's 11-vectors carry the index in slot 0; here the index is implicit).  Neither mode is used

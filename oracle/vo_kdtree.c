@@ -73,7 +73,12 @@ static void mean_and_direction(const float *pts, int begin, int end, float *mean
   jacobi_sym(AD, a, v);
   int best = 0;
   for (int i = 1; i < AD; ++i) if (a[i * AD + i] > a[best * AD + best]) best = i;
-  for (int i = 0; i < AD; ++i) { mean[i] = m[i]; normal[i] = (float)v[i * AD + best]; }
+  /* sign convention (shared with csrc/kdtree.hip): the component of largest magnitude is positive, the first among
+   * equals; Eigen's solver has no such rule -- the sign decides which child is "left", i.e. the order inside a leaf */
+  int big = 0;
+  for (int i = 1; i < AD; ++i) if (fabs(v[i * AD + best]) > fabs(v[big * AD + best])) big = i;
+  const double sgn = v[big * AD + best] < 0.0 ? -1.0 : 1.0;
+  for (int i = 0; i < AD; ++i) { mean[i] = m[i]; normal[i] = (float)(sgn * v[i * AD + best]); }
 }
 
 static float plane_dist(const float *p11, const float *mean, const float *normal) {

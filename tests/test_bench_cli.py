@@ -42,3 +42,33 @@ def test_frame_bytes_and_partition(vo):
     assert len(fps) == 2 and len(fps[0]["ref_app"]) == 300
     ref = vo.synth.frame_pair(300, seed=4000 + 8)
     assert (fps[1]["ref_app"] == ref["ref_app"]).all() and (fps[1]["X_gt"] == ref["X_gt"]).all()
+
+
+def test_result_line_is_json_for_every_leg_selection():
+    """cpu_leg and exact_leg carry an ndarray under "_pose"; whichever legs ran, the assembled dict must
+    serialise (with `--legs cpu` the array used to stay in the dict and json.dumps raised after all the GPU work)."""
+    import json
+    import numpy as np
+    b = _bench()
+    pose = np.eye(4, dtype=np.float32)
+    shapes = {
+        "cpu only": {"cpu_baseline": {"value": 860.0, "_pose": pose.copy()}},
+        "exact only": {"exact_mode": {"iters_per_sec": 5500.0, "_pose": pose.copy()}},
+        "both": {"exact_mode": {"iters_per_sec": 5500.0, "_pose": pose.copy()}, "cpu_baseline": {"value": 860.0, "_pose": pose.copy()}},
+        "both, poses differ": {"exact_mode": {"iters_per_sec": 1.0, "_pose": pose.copy()}, "cpu_baseline": {"value": 2.0, "_pose": pose + 1}},
+        "neither": {"metric": "x"},
+    }
+    for name, out in shapes.items():
+        b._relate_exact_and_cpu(out)
+        line = json.dumps(out)                                  # must not raise
+        assert "_pose" not in line, name
+    assert shapes["both"]["exact_mode"]["bit_identical_to_cpu_baseline"] is True
+    assert abs(shapes["both"]["exact_mode"]["vs_cpu_baseline"] - 5500.0 / 860.0) < 1e-9
+    assert shapes["both, poses differ"]["exact_mode"]["bit_identical_to_cpu_baseline"] is False
+    assert "bit_identical_to_cpu_baseline" not in shapes["exact only"]["exact_mode"]
+
+
+def test_strong_pairs_fewer_than_ranks_is_rejected_up_front():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--strong-pairs", "3"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "every rank needs at least one pair" in r.stderr and r.stdout.strip() == ""

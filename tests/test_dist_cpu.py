@@ -41,6 +41,27 @@ WORKER = textwrap.dedent("""
     for p, it in enumerate(every):
         assert it.shape == (p + 1, 2) and int(it[:, 1].min()) == p == int(it[:, 1].max())
         assert torch.equal(it[:, 0], torch.arange(p + 1, dtype=torch.int32))
+    # the strong-scaling leg's bookkeeping (bench.frame_throughput_strong): equal-sized padded blocks, own-slice check,
+    # global order after the gather -- uneven (7 = 4 + 3), even (8), and one pair per rank (2)
+    for P in (7, 8, 2):
+        plan = vdist.StrongPlan(P, rank, world)
+        assert (plan.lo, plan.hi) == vdist.shard_range(P, rank, world) and plan.blk == -(-P // world)
+        buf = torch.full((plan.blk, 16), -1.0)                # padding rows keep -1
+        for i, p in enumerate(range(plan.lo, plan.hi)):
+            buf[i] = torch.arange(16, dtype=torch.float32) + 100.0 * p
+        allp = vdist.gather_poses(buf)
+        assert allp.shape == (world * plan.blk, 16)
+        r0, r1 = plan.own_rows()
+        assert torch.equal(allp[r0:r1], buf[:plan.n_local])
+        g_all = plan.global_order(allp)
+        assert g_all.shape == (P, 16)
+        for p in range(P):
+            assert torch.equal(g_all[p], torch.arange(16, dtype=torch.float32) + 100.0 * p)
+    try:
+        vdist.StrongPlan(1, rank, world)
+        raise AssertionError("one pair over two ranks must be rejected")
+    except ValueError:
+        pass
     t = vdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
     assert t == float(world)
     dist.barrier()

@@ -199,6 +199,52 @@ def test_one_round_honours_in_place_edits(vo, ctx, o32):
         s.close()
 
 
+def test_rounds_after_a_solve_with_other_pairs_continue_on_those_pairs(vo, ctx, o32):
+    """setCorrespondences(A) ; solve(B) ; init (new points: the packing is invalidated) ; rounds() used to
+    re-pack len(A) pairs out of a buffer that held B followed by the tail of A.  Now the hand-over count follows the
+    array the solver last received: rounds() continues on B -- bit for bit in reference-order mode."""
+    fp = vo.synth.frame_pair(3000, seed=23, drop=0.0, distractors=0, model_drop=0.0)
+    m = o32.match(fp["ref_app"], fp["cur_app"])
+    A = np.ascontiguousarray(o32.join(m, fp["model_pairs"]).astype(np.int32))
+    B = np.ascontiguousarray(A[100:1300][::-1])           # fewer pairs, other order
+    assert len(A) > 2500
+    ocam = OCam(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4))
+    cam = vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx)
+    for exact in (True, False):
+        s = vo.PICPSolver(ctx)
+        s.setExact(exact)
+        s.setKernelThreshold(10000.0)
+        s.init(cam, fp["model"], fp["cur_pts"])
+        s.setCorrespondences(A)
+        s.rounds(False, 1)
+        s.solve(B, False, 2)                              # another array through the comparing entry point
+        s.init(cam, fp["model"], fp["cur_pts"])           # pose back to the identity, packing invalidated
+        s.rounds(False, 3)
+        want = o32.picp_solve(ocam, fp["model"], fp["cur_pts"], B, 3, 10000.0, False, trace=False)
+        got = s.camera().worldInCameraPose()
+        assert s.numInliers() == want["num_inliers"] == len(B)
+        if exact:
+            assert np.array_equal(got, want["T"])
+        else:
+            assert np.abs(got - want["T"]).max() < 1e-4
+        s.close()
+
+
+def test_graph_bookkeeping_is_visible(vo, ctx):
+    """a multi-round solve replays a captured graph; the handle says so (vo_picp_graph_info), and a failed capture
+    would be counted and reported through vo_last_error() instead of silently dropping to plain launches"""
+    fp = vo.synth.frame_pair(2000, seed=29, drop=0.0, distractors=0, model_drop=0.0)
+    s = vo.PICPSolver(ctx)
+    s.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx), fp["model"], fp["cur_pts"])
+    j = np.stack([np.arange(1500), np.arange(1500)], 1).astype(np.int32)
+    s.solve(j, False, 5)
+    s.solve(j, False, 5)
+    s.solve(j, False, 7)
+    use, n_graphs, n_fail = s.graphInfo()
+    assert (use, n_graphs, n_fail) == (1, 2, 0)
+    s.close()
+
+
 def _run_app(tmp_path, *flags):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "apps"), "-s"])
     r = subprocess.run([os.path.join(BIN, "vo_complete"), DATA, str(tmp_path), *flags], capture_output=True, text=True, timeout=300)

@@ -30,6 +30,6 @@ for kind in ("ctx", "event", "match", "frame", "capture", "all"):
     cycle(kind)
     f0 = free_bytes()
     vals = []
-    for _ in range(10):
+    for _ in range(16):
         cycle(kind); vals.append((f0 - free_bytes()) / 2**20)
     print(f"{kind:8s}: drift MiB after each cycle: " + " ".join(f"{v:7.2f}" for v in vals), flush=True)

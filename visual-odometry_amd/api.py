@@ -254,6 +254,12 @@ class PICPSolver:
         """reference-order arithmetic (vo_picp_set_exact): bit-identical to the reference's float32 loop"""
         _chk(self.lib.vo_picp_set_exact(self.h, C.c_int(int(bool(on)))))
 
+    def graphInfo(self):
+        """(use_graph, cached graphs, failed captures) of this handle: vo_picp_graph_info"""
+        u, n, f = C.c_int(), C.c_int(), C.c_int()
+        _chk(self.lib.vo_picp_graph_info(self.h, C.byref(u), C.byref(n), C.byref(f)))
+        return u.value, n.value, f.value
+
     def setCorrespondences(self, correspondences):
         p = _i32pairs(correspondences)
         _chk(self.lib.vo_picp_set_correspondences(self.h, _ptr(p), C.c_int(len(p))))

@@ -4,9 +4,10 @@
 // executable the reference builds; provided for API completeness.  The exact modes (bestMatchFull,
 // fullSearch) are tree-independent and live in match.hip (vo_match_appearances, vo_radius_search).
 //
-// The tree is built on the host, once per point set, exactly as the TreeNode_ constructor does (:18-38): mean and
+// The tree is built on the host, once per point set, the way the TreeNode_ constructor does (:18-38): mean and
 // covariance of the node's points accumulated in float in array order (eigen_covariance.h:5-30), the direction of
-// largest variance (a cyclic Jacobi in double stands in for Eigen's SelfAdjointEigenSolver, :35-43), the in-place
+// largest variance (a cyclic Jacobi in double stands in for Eigen's SelfAdjointEigenSolver, :35-43; its sign is fixed
+// by the convention in HostTree::direction -- same leaf sets as the reference, in-leaf order up to that sign), the in-place
 // two-pointer partition of split.h:8-34 (which fixes the order of the points inside every leaf), recursion while a
 // node holds >= max_points_in_leaf points.  Queries run on the GPU: one lane per query walks the <= ~log2(n) split
 // planes (10-D dot products in the reference's left-to-right order, unfused) and scans its leaf.
@@ -83,7 +84,14 @@ struct HostTree {
     jacobi10(a, v);
     int best = 0;
     for (int i = 1; i < KD; ++i) if (a[i][i] > a[best][best]) best = i;
-    for (int i = 0; i < KD; ++i) { nd.mean[i] = m[i]; nd.normal[i] = (float)v[i][best]; }
+    // An eigenvector is defined up to its sign, and the sign decides which child is "left", hence the order of the points
+    // inside a leaf.  Convention here (the CPU checker of the tests follows the same rule): the component of largest magnitude is positive (the
+    // first one among equals).  Eigen's SelfAdjointEigenSolver has no such rule, so in-leaf order may differ from the
+    // reference's; the leaf SETS do not depend on the sign.
+    int big = 0;
+    for (int i = 1; i < KD; ++i) if (fabs(v[i][best]) > fabs(v[big][best])) big = i;
+    const double sgn = v[big][best] < 0.0 ? -1.0 : 1.0;
+    for (int i = 0; i < KD; ++i) { nd.mean[i] = m[i]; nd.normal[i] = (float)(sgn * v[i][best]); }
   }
   int partition(int begin, int end, const KdNode& nd) {           // split.h:8-34
     int lower = begin, upper = end;

@@ -26,6 +26,33 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, hi
 
 
+class StrongPlan:
+    """Bookkeeping of the strong-scaling leg (BASELINE configs[3]): P pairs in total, rank r owns the contiguous block
+    shard_range(P, r, world); the all-gather needs equal-sized blocks, so every rank's pose buffer has `blk` rows (the
+    largest block) of which the first n_local are live.  P < world would leave a rank without a pair: rejected."""
+
+    def __init__(self, n_pairs: int, rank: int, world: int):
+        if n_pairs < world:
+            raise ValueError(f"{n_pairs} pairs cannot be sharded over {world} ranks (every rank needs at least one)")
+        self.P, self.rank, self.world = n_pairs, rank, world
+        self.lo, self.hi = shard_range(n_pairs, rank, world)
+        self.n_local = self.hi - self.lo
+        self.blk = shard_range(n_pairs, 0, world)[1]          # rank 0 holds a largest block
+
+    def own_rows(self):
+        """rows of the gathered (world*blk, 16) tensor that hold THIS rank's live poses"""
+        return self.rank * self.blk, self.rank * self.blk + self.n_local
+
+    def global_order(self, gathered):
+        """(world*blk, ...) gathered tensor -> (P, ...) in global pair order (the padding rows dropped)"""
+        import torch
+        parts = []
+        for r in range(self.world):
+            lo, hi = shard_range(self.P, r, self.world)
+            parts.append(gathered[r * self.blk: r * self.blk + (hi - lo)])
+        return torch.cat(parts, 0)
+
+
 def init(backend: str, device_index: int | None = None):
     import torch.distributed as dist
     if not dist.is_initialized():
