@@ -929,11 +929,12 @@ static int match_workspace(vo_ctx* c, int variant, int nt, int nq, int n_frames,
 // search (25 instead of ~1400 candidates per query: 4.0 vs 4.4 ms per 200 frames, its random accesses hidden
 // by occupancy).  VO_MATCH_AUTO=2|3 forces one of the sorted variants in auto mode.
 static int match_variant(const vo_ctx* c, int nt, int nq, int n_frames) {
-  if (c->match_mode != 0) return c->match_mode;
+  const bool cells_ok = match_cells_supported(nt, nq);      // the cell-hash search serves sets of up to 1.8 M points
+  if (c->match_mode != 0) return (c->match_mode == 3 && !cells_ok) ? 2 : c->match_mode;
   if ((double)nt * (double)nq < 4.0e6) return 1;
   static const int forced = [] { const char* e = getenv("VO_MATCH_AUTO"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 3) ? v : 0; }();
-  if (forced) return forced;
-  return n_frames >= 8 ? 3 : 2;
+  if (forced) return (forced == 3 && !cells_ok) ? 2 : forced;
+  return (n_frames >= 8 && cells_ok) ? 3 : 2;
 }
 
 int vo_match_set_mode(vo_ctx* c, int mode) {
@@ -1084,6 +1085,7 @@ int vo_radius_search_dev(vo_ctx* c, const float* d_tree, int n_tree, const float
   VO_REQUIRE(c && d_offsets, "null argument");
   VO_REQUIRE(n_tree >= 0 && n_q >= 0 && capacity >= 0, "negative count");
   VO_REQUIRE((n_tree == 0 || d_tree) && (n_q == 0 || d_qry) && (capacity == 0 || d_indices), "null array");
+  VO_REQUIRE(match_cells_supported(n_tree, n_q), "more than 1 835 008 points in one set");
   if (int r = set_device(c)) return r;
   void* ws = nullptr;
   if (n_tree > 0 && n_q > 0) if (int r = match_workspace(c, 3, n_tree, n_q, 1, &ws)) return r;

@@ -601,75 +601,102 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
 // the cell function is monotone and clamps -- points beyond the sampled range fall into the edge cells.
 // The tree is counting-sorted by the cell key ((c0*nc1 + c1)*nc2 + c2)*nc3 + c3 (<= 160 000 cells) in two
 // levels, both on LDS histograms (a global atomic per point -- 64 scattered memory-side requests per wave --
-// was 2x dearer): level 1 like the bucket sort above with the <= 400 coarse bins (c0, c1); level 2 one
-// workgroup per coarse bin, ordering its points by the <= 400 fine bins (c2, c3) and writing that bin's slice
-// of the start table.  The queries are only grouped by coarse bin (level 1 writes their indices).
+// was 2x dearer):
+//   level 1 (cell_place_kernel, ONE pass over the input rows): the sets are cut into slices of CELL_SLICE points; a
+//     workgroup reads its slice once, orders its records by the <= 400 coarse bins (c0, c1) in LDS and writes them back
+//     as one contiguous run, together with a directory row (count, offset) per bin.  (Round 2 histogrammed the rows in a
+//     first pass only to learn where every workgroup's records go, then read them again to place them: 0.19 ms of the
+//     1.6 ms chain per 200 x 50k frames, bound by touching every 40-B row a second time.)
+//   offsets (cell_offsets_kernel): column sums of the directory and their scan -> first slot of every coarse bin.
+//   level 2 (cell_fine_kernel): one workgroup per coarse bin GATHERS its points from the slices' runs (directory column),
+//     orders them by the <= 400 fine bins (c2, c3) in LDS and writes that bin's slice of the sorted tree and of the start
+//     table; the same workgroup copies the bin's query indices from their runs into one contiguous list.
+// A sorted tree point is 8 bytes: its original index and the FILTER WORD -- components 0..3 quantised to 8 bits each
+// (see quant8 / the filter's proof below).  The search never reads a float of the tree before it has a survivor.
 //
 // Search: one workgroup per STRIP of CS_NB coarse bins (c0, c1 .. c1 + CS_NB - 1).  Every query of a bin can only meet
 // tree points of the 3 x 3 coarse bins around it, i.e. nine CONTIGUOUS segments of the sorted tree (~140 points each
 // on 50k uniform points) and nine rows of the start table: the workgroup stages the 3 x (CS_NB + 2) bins of its strip in
-// LDS with coalesced loads (filter prefixes and 16-bit relative starts; the points' original indices stay in global
-// memory) and every lane then walks its own <= 27 runs (3 x 3 x 3 cells in c0, c1, c2; contiguous along c3) out of LDS.
-// (Per-lane gathers from global memory -- 54 table reads and ~25 16-byte candidate reads per query, each
-// its own cache line -- made the first version L1-request-bound: 1.41 ms per 200 x 50k frames.)  A query
-// visits, per component, the cells [cell(q - R), cell(q - R) + 2] clipped to cell(q + R): any tree value t
+// LDS with coalesced loads (filter words, original indices, 16-bit relative starts) and every lane then visits its own
+// <= 27 runs (3 x 3 x 3 cells in c0, c1, c2; contiguous along c3) out of LDS.
+// A query visits, per component, the cells [cell(q - R), cell(q - R) + 2] clipped to cell(q + R): any tree value t
 // with |t - q| < radius has cell(q - R) <= cell(t) (monotone) and (t - (q - R)) * scale < (r + R) * scale
 // <= 1.9991 (1 + eps) < 2, so cell(t) <= cell(q - R) + 2.  A tree point outside that box differs from the
 // query by at least the radius in one component, so that single non-negative term of the monotonically
 // accumulated sum already reaches radius^2 and the strict test can never pass: the box changes no decision.
-// Inside it the scan is the same conservative filter + exact re-evaluation as above, ties resolved on the
-// original index.  On U(-1,1)^10 appearances a query meets ~25 candidates instead of ~1400 in the 2-D
-// rectangle.  Segments too long for the LDS budget (clustered data) or a box reaching beyond the staged
-// bins (cells narrower than R by a rounding) fall back to the same walk on global memory.
+//
+// The filter.  quant8(x, k) = clamp(floor((x - qlo_k) * qscale), 0, 255) is monotone in x, and for two floats a, b
+// |quant8(a) - quant8(b)| <= |a - b| * qscale + 1.0001 (the floor costs one unit, the two float roundings of an unclamped
+// value < 256 cost < 1e-4, clamping only shrinks a difference).  A tree point t that passes the decision has
+// sum_k (t_k - q_k)^2 < r^2 (1 + 1e-6) over ALL components (the float sum is within 12 ulp of the real one), hence over
+// components 0..3 sum_k |t_k - q_k| <= 2 * sqrt(sum_k (t_k - q_k)^2) < 2.000002 r, and the sum of absolute differences of
+// the filter words is < 2.000002 r qscale + 4.0004 <= T = floor(2 R qscale) + 7.  So SAD(word_t, word_q) > T (ONE
+// v_sad_u8 and a compare, against nine VALU instructions on a 16-byte float prefix in round 2) proves that t cannot be
+// within the radius: the filter drops no point that could pass, and every survivor is decided from its full float row in
+// the reference's operation order (brute_force_search.h:31-38), ties on the original index.  On U(-1,1)^10 appearances a
+// random candidate survives with probability ~2e-4; a query meets ~27 candidates.
+// Exactness never depends on the quantisation being useful: any qlo / qscale (0 when the sampled spread is empty or not
+// finite) only changes how many survivors reach the decision.
+//
+// Segments too long for the LDS budget (clustered data) or a box reaching beyond the staged bins (cells narrower than R
+// by a rounding) fall back to the same search on global memory.
 constexpr int HK = 4;                    // hashed components
 constexpr int HNC = 20;                  // cells per component, at most
 constexpr int HCOARSE = HNC * HNC;       // coarse bins (c0, c1) / fine bins (c2, c3), at most
 constexpr int HCPAD = 512;               // HCOARSE rounded up to a power of two (scan width)
-constexpr int HBINS = HNC * HNC * HNC * HNC + 1;   // every key + the end sentinel
 constexpr int HROW = 408;                // u16 entries per row of the relative start table (>= HCOARSE + 1, 16-byte rows)
-constexpr int CELL_MAX_TB = 48, CELL_MAX_QB = 16, CELL_MAX_ROWS = CELL_MAX_TB + CELL_MAX_QB;   // level-1 workgroups per frame, at most
 constexpr int CELL_SAMPLE = 2048;        // points per set that define the grid's bounds
+constexpr int CELL_SLICE = 1792;         // points per level-1 workgroup: 7 per thread, ordered in 28 KiB of LDS
+constexpr int CELL_PPT = CELL_SLICE / 256;
+constexpr int CELL_MAX_SLICES = 1024;    // per set: the cell variant serves sets of up to 1 835 008 points (beyond: pruned scan)
 #ifndef VO_CS_NB
 #define VO_CS_NB 3
 #endif
 constexpr int CS_NB = VO_CS_NB;          // coarse bins per search workgroup (a strip along c1)
 constexpr int CS_THREADS = CS_NB == 1 ? 192 : (CS_NB == 2 ? 320 : 448);   // a coarse bin holds ~140 queries at 50k points
-constexpr int CS_SURV = 4;               // filter survivors a lane parks before it evaluates them
-constexpr int CS_CAP = CS_NB == 3 ? 2296 : 576 * (CS_NB + 2);   // tree points a search workgroup can stage (16 B each; ~140 per bin
-                                                                //   at 50k): with NB = 3 three workgroups share a CU's LDS
-static_assert(CS_CAP < 4096 && 3 * (CS_NB + 2) <= 16, "a parked survivor is (staged bin : 4 bits, LDS slot : 12 bits)");
+constexpr int CS_SURV = 2;               // further filter survivors a lane parks (beyond its first) before it decides them on the spot
+constexpr int CS_CAP = 2816;             // tree points a search workgroup can stage (8 B each; ~140 per bin at 50k)
+
+bool match_cells_supported(int nt, int nq) {
+  return (long long)nt <= (long long)CELL_MAX_SLICES * CELL_SLICE && (long long)nq <= (long long)CELL_MAX_SLICES * CELL_SLICE;
+}
 
 struct CellParams {
   int dim[HK];
   float lo[HK], scale[HK];
   int nc[HK];
   float R;
+  float qlo[4], qscale;    // filter words: quant8 of components 0..3
+  int T;                   // SAD threshold
 };
 
-__device__ CellParams make_cell_params(const float* lo_in, const float* hi_in, float radius) {
-  float span[10], lo[10];
+// s_lo / s_hi: per-component bounds in LDS (10 each); s_tmp: 16 floats of LDS scratch.  Indexed dynamically, hence in LDS:
+// private arrays would live in scratch memory.
+__device__ void make_cell_params(const float* s_lo, const float* s_hi, float* s_tmp, float radius, CellParams* out) {
+  float* span = s_tmp;                                   // [10]
   for (int k = 0; k < 10; ++k) {
-    lo[k] = lo_in[k];
-    const float sp = hi_in[k] - lo[k];
+    const float sp = s_hi[k] - s_lo[k];
     span[k] = (sp < INFINITY) ? sp : -1.f;               // empty / infinite / NaN ranges rank last
   }
-  auto top4 = [&](int k0, int* out) {                    // indices of the four largest spans in [k0, 10), descending
-    bool used[10] = {false, false, false, false, false, false, false, false, false, false};
+  auto top4 = [&](int k0, int* o) {                      // indices of the four largest spans in [k0, 10), descending
+    unsigned used = 0;
     for (int j = 0; j < HK; ++j) {
       int best = -1;
       for (int k = k0; k < 10; ++k)
-        if (!used[k] && (best < 0 || span[k] > span[best])) best = k;
-      used[best] = true;
-      out[j] = best;
+        if (!((used >> k) & 1u) && (best < 0 || span[k] > span[best])) best = k;
+      used |= 1u << best;
+      o[j] = best;
     }
   };
   int all4[HK], tail4[HK];
   top4(0, all4);
   top4(4, tail4);
   bool tail_ok = true;
+#pragma unroll
   for (int j = 0; j < HK; ++j) tail_ok = tail_ok && span[tail4[j]] >= 0.5f * span[all4[j]];
   CellParams cp;
   cp.R = radius * 1.001f;
+#pragma unroll
   for (int j = 0; j < HK; ++j) {
     const int k = tail_ok ? tail4[j] : all4[j];
     const float sp = span[k];
@@ -679,11 +706,31 @@ __device__ CellParams make_cell_params(const float* lo_in, const float* hi_in, f
       nc = f >= (float)HNC ? HNC : (int)f;
       if (nc < 1) nc = 1;
     }
-    cp.dim[j] = k; cp.lo[j] = lo[k]; cp.nc[j] = nc;
+    cp.dim[j] = k; cp.lo[j] = s_lo[k]; cp.nc[j] = nc;
     cp.scale[j] = sp > 0.f ? (float)nc / sp : 0.f;       // cell width sp / nc >= R
   }
-  return cp;
+  // filter words: one scale for components 0..3 (the L1 bound needs a common unit), from their largest finite spread
+  float wide = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { cp.qlo[k] = span[k] >= 0.f ? s_lo[k] : 0.f; wide = span[k] > wide ? span[k] : wide; }
+  cp.qscale = wide > 0.f ? 255.f / wide : 0.f;
+  {
+    const float t = 2.f * cp.R * cp.qscale;              // NaN / inf / huge -> every word passes (1020 is the largest SAD)
+    cp.T = (t >= 0.f && t < 1000.f) ? (int)t + 7 : 1020;
+  }
+  *out = cp;
 }
+
+__device__ __forceinline__ unsigned quant8(float x, float lo, float scale) {
+  float v = (x - lo) * scale;                            // monotone non-decreasing in x
+  v = fminf(fmaxf(v, 0.f), 255.f);                       // NaN -> 0, +-inf clamp
+  return (unsigned)v;                                    // truncation = floor (v >= 0)
+}
+__device__ __forceinline__ unsigned filter_word(float x0, float x1, float x2, float x3, const CellParams& cp) {
+  return quant8(x0, cp.qlo[0], cp.qscale) | (quant8(x1, cp.qlo[1], cp.qscale) << 8) |
+         (quant8(x2, cp.qlo[2], cp.qscale) << 16) | (quant8(x3, cp.qlo[3], cp.qscale) << 24);
+}
+__device__ __forceinline__ unsigned sad4(unsigned a, unsigned b) { return __builtin_amdgcn_sad_u8(a, b, 0u); }
 
 // component k of v (k is wave-uniform), selected with bit masks: an indexed read -- which is what the compiler makes
 // of a chain of selects -- would put v[] into scratch memory
@@ -696,22 +743,25 @@ __device__ __forceinline__ float pick10(const float* v, int k) {
 
 // per-frame workspace of the cell variant (bytes, every block 256-aligned)
 struct CellWs {
-  size_t tree_rec, tree_idx, t1_pre, t1_meta, q1_idx, block_hist, coarse_start, start_t, start_rel, cp, total;
+  size_t cp, dir, t1, ql1, coarse_start, tree_word, tree_idx, q1, start_t, start_rel, total;
 };
+constexpr int SROW = HCOARSE + 1;        // ints per coarse bin in the absolute start table (its fine bins + its own end)
+static int cell_slices(int n) { const int s = (n + CELL_SLICE - 1) / CELL_SLICE; return s < 1 ? 1 : s; }
 static CellWs cell_ws_layout(int nt, int nq) {
   CellWs w;
   size_t o = 0;
-  w.tree_rec = o; o += align256(sizeof(float) * 4 * (size_t)nt);      // filter prefix (components 0..3) in cell order
-  w.tree_idx = o; o += align256(sizeof(int) * (size_t)nt);            // original index of the sorted tree point
-  w.t1_pre = o; o += align256(sizeof(float) * 4 * (size_t)nt);        // level 1 (coarse order): tree prefix,
-  w.t1_meta = o; o += align256(sizeof(int) * 2 * (size_t)nt);         //   (original index, fine bin)
-  w.q1_idx = o; o += align256(sizeof(int) * (size_t)nq);              //   query indices grouped by coarse bin
-  w.block_hist = o; o += align256(sizeof(int) * (size_t)CELL_MAX_ROWS * 2 * HCPAD);
-  w.coarse_start = o; o += align256(sizeof(int) * 2 * (HCPAD + 1));
-  w.start_t = o; o += align256(sizeof(int) * (size_t)HBINS);          // first tree slot of every cell (+ end sentinel)
-  w.start_rel = o; o += align256(sizeof(unsigned short) * (size_t)HCOARSE * HROW);   // the same per coarse bin, relative to
-                                                                      //   the bin's first slot (16-bit, rows of HROW)
   w.cp = o; o += align256(sizeof(CellParams));
+  w.dir = o; o += align256(sizeof(unsigned) * (size_t)(cell_slices(nt) + cell_slices(nq)) * HCPAD);   // (count << 16 | offset) per (slice, bin)
+  w.t1 = o; o += align256(sizeof(uint4) * (size_t)nt);                // level 1: (filter word, original index, fine | coarse << 16, -) in slice order
+  w.ql1 = o; o += align256(sizeof(uint4) * (size_t)nq);               //   query records (below) in slice order
+  w.coarse_start = o; o += align256(sizeof(int) * 2 * (HCPAD + 1));
+  w.tree_word = o; o += align256(sizeof(unsigned) * (size_t)nt);      // sorted tree: filter word,
+  w.tree_idx = o; o += align256(sizeof(int) * (size_t)nt);            //   original index
+  w.q1 = o; o += align256(sizeof(uint4) * (size_t)nq);                // query records grouped by coarse bin: (original index, filter word,
+                                                                      //   box = cell(q - R) per component : 5 bits each, width - 1 : 2 bits each, coarse bin)
+  w.start_t = o; o += align256(sizeof(int) * (size_t)HCOARSE * SROW); // first tree slot of every cell, rows of SROW per coarse bin
+  w.start_rel = o; o += align256(sizeof(unsigned short) * (size_t)HCOARSE * HROW);   // the same relative to the bin's first slot
+                                                                      //   (16-bit, rows of HROW: what the search stages)
   w.total = o;
   return w;
 }
@@ -725,7 +775,7 @@ struct CellArgs {
   CellWs w;
   size_t ws_stride, tree_stride, qry_stride, best_stride;
   int n_frames;
-  int tb, qb;               // level-1 workgroups per frame over the tree / over the queries
+  int tb, qb;               // level-1 slices (workgroups) per frame over the tree / over the queries
   float radius, r2;
   unsigned long long* best;
   int* rs_offsets;          // radius search: [nq + 1] counts, then (after the scan) offsets
@@ -735,8 +785,8 @@ struct CellArgs {
 
 // XCD-aware decomposition of a 1-D grid of 8 * ceil(n_frames / 8) * per_frame workgroups.  Workgroups are dealt
 // round-robin over the 8 XCDs (observed; speed only, nothing depends on it), so giving every frame the workgroups of
-// ONE residue class of blockIdx.x mod 8 keeps a frame's working set (4 MB of input, <= 3.6 MB of sorted records) in one
-// XCD's L2: partial lines written by the frame's workgroups merge there, segments staged by neighbouring bins hit there.
+// ONE residue class of blockIdx.x mod 8 keeps a frame's working set (4 MB of input, ~2 MB of records) in one
+// XCD's L2: level 2 gathers what level 1 wrote there, segments staged by neighbouring strips hit there.
 __device__ __forceinline__ bool xcd_frame_block(int per_frame, int n_frames, int& frame, int& blk) {
   const unsigned L = blockIdx.x, s = L >> 3;
   frame = (int)(s / (unsigned)per_frame) * 8 + (int)(L & 7u);
@@ -754,8 +804,38 @@ __device__ __forceinline__ void cell_bins(const float* v, const CellParams& cp, 
   int c[HK];
 #pragma unroll
   for (int j = 0; j < HK; ++j) c[j] = cell_of(pick10(v, cp.dim[j]), cp.lo[j], cp.scale[j], cp.nc[j]);
-  coarse = c[0] * cp.nc[1] + c[1];
+  coarse = c[0] * HNC + c[1];          // fixed stride: a bin's number -- hence where its starts live -- does not depend on the grid
   fine = c[2] * cp.nc[3] + c[3];
+}
+// a query's box, per component j: cell(q - R) in bits 5j..5j+4, (last cell - first cell) in bits 20+2j..21+2j
+__device__ __forceinline__ unsigned query_box(const float* v, const CellParams& cp) {
+  unsigned box = 0;
+#pragma unroll
+  for (int j = 0; j < HK; ++j) {
+    const float x = pick10(v, cp.dim[j]);
+    const int lo = cell_of(x - cp.R, cp.lo[j], cp.scale[j], cp.nc[j]);
+    const int h = cell_of(x + cp.R, cp.lo[j], cp.scale[j], cp.nc[j]);
+    const int hi = h < lo + 2 ? h : lo + 2;
+    box |= ((unsigned)lo << (5 * j)) | ((unsigned)(hi - lo) << (20 + 2 * j));
+  }
+  return box;
+}
+
+// exclusive scan of HCPAD counters held two per thread (256 threads); returns the exclusive prefix of the thread's pair
+// and the grand total.  s_w: 4 ints of LDS.
+__device__ __forceinline__ int scan512(int c0, int c1, int* s_w, int& total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int v = c0 + c1;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int woff = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { const int c = s_w[w]; if (w < wave) woff += c; total += c; }
+  return woff + incl - v;
 }
 
 // grid bounds: one workgroup per frame, min/max per component over a strided sample of both sets -> CellParams
@@ -763,6 +843,7 @@ __global__ __launch_bounds__(1024) void cell_bounds_kernel(CellArgs a) {
   const int f = blockIdx.x;
   const float* tree = a.tree + f * a.tree_stride; const float* qry = a.qry + f * a.qry_stride;
   __shared__ float s_lo[16][10], s_hi[16][10];
+  __shared__ float s_flo[10], s_fhi[10], s_tmp[16];
   float lo[10], hi[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
@@ -789,68 +870,92 @@ __global__ __launch_bounds__(1024) void cell_bounds_kernel(CellArgs a) {
 #pragma unroll
     for (int k = 0; k < 10; ++k) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float l[10], h[10];
-    for (int k = 0; k < 10; ++k) {
-      l[k] = INFINITY; h[k] = -INFINITY;
-      for (int w = 0; w < 16; ++w) { l[k] = fminf(l[k], s_lo[w][k]); h[k] = fmaxf(h[k], s_hi[w][k]); }
-    }
-    *reinterpret_cast<CellParams*>(a.ws + f * a.ws_stride + a.w.cp) = make_cell_params(l, h, a.radius);
+  if (threadIdx.x < 10) {                                 // one component per thread over the 16 waves
+    const int k = threadIdx.x;
+    float l = INFINITY, h = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { l = fminf(l, s_lo[w][k]); h = fmaxf(h, s_hi[w][k]); }
+    s_flo[k] = l; s_fhi[k] = h;
   }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    make_cell_params(s_flo, s_fhi, s_tmp, a.radius, reinterpret_cast<CellParams*>(a.ws + f * a.ws_stride + a.w.cp));
 }
 
-// level 1: a.tb workgroups per frame take contiguous slices of the tree, a.qb of the queries (a row of block_hist each;
-// only the row's own half is non-zero).  The counts follow the set sizes (cell_level1_blocks) so that a slice fits the
-// LDS staging of the placement: 28 + 9 at 50k x 50k; beyond 48 x 1920 tree points the placement writes straight.
-constexpr int PL_TCAP = 1920;            // tree points a placement workgroup can order in LDS (24 B each)
-constexpr int PL_QCAP = 6400;            // queries (6 B each)
-static void cell_level1_blocks(int nt, int nq, int& tb, int& qb) {
-  tb = (nt + 1799) / 1800; tb = tb < 4 ? 4 : (tb > CELL_MAX_TB ? CELL_MAX_TB : tb);
-  qb = (nq + 5999) / 6000; qb = qb < 2 ? 2 : (qb > CELL_MAX_QB ? CELL_MAX_QB : qb);
-}
-__device__ __forceinline__ void cell_slice(int blk, int nt, int nq, int tb, int qb, bool& is_t, int& lo, int& hi) {
-  is_t = blk < tb;
-  const int n = is_t ? nt : nq, parts = is_t ? tb : qb, b = is_t ? blk : blk - tb;
-  const int per = (n + parts - 1) / parts;
-  lo = b * per < n ? b * per : n;
-  hi = lo + per < n ? lo + per : n;
-}
-
-__global__ __launch_bounds__(256) void cell_coarse_hist_kernel(CellArgs a) {
+// level 1: one pass.  a.tb workgroups per frame take the tree's slices, a.qb the queries'.  A workgroup reads its <= 1792
+// rows once (coalesced), ranks every point inside its coarse bin with an LDS atomic, scans the 512 counters, lays the
+// records out by bin in LDS and copies them to the slice's own range of t1 / ql1 in that order: the stores are contiguous
+// (round 2 wrote ~4 records into each of ~400 bins' runs).  The directory row tells level 2 where each bin's run starts.
+__global__ __launch_bounds__(256) void cell_place_kernel(CellArgs a) {
   int f, blk;
   if (!xcd_frame_block(a.tb + a.qb, a.n_frames, f, blk)) return;
   char* ws = a.ws + f * a.ws_stride;
+  const bool is_t = blk < a.tb;
+  const int n_set = is_t ? a.nt : a.nq;
+  const int lo = (is_t ? blk : blk - a.tb) * CELL_SLICE;
+  const int hi = lo + CELL_SLICE < n_set ? lo + CELL_SLICE : n_set;
+  const float* src = is_t ? a.tree + f * a.tree_stride : a.qry + f * a.qry_stride;
   __shared__ int s_h[HCPAD];
-  for (int k = threadIdx.x; k < HCPAD; k += 256) s_h[k] = 0;
+  __shared__ int s_w[4];
+  __shared__ uint4 s_rec[CELL_SLICE];
+  const int tid = threadIdx.x;
+  s_h[tid] = 0; s_h[tid + 256] = 0;
   const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
   __syncthreads();
-  bool is_t; int lo, hi;
-  cell_slice(blk, a.nt, a.nq, a.tb, a.qb, is_t, lo, hi);
-  const float* src = is_t ? a.tree + f * a.tree_stride : a.qry + f * a.qry_stride;
-  // only the two coarse components are needed here (wave-uniform column indices): two 4-byte loads per point instead of the row
-  const int d0 = cp.dim[0], d1 = cp.dim[1];
-  for (int i = lo + threadIdx.x; i < hi; i += 256) {
-    const float x0 = src[10 * (size_t)i + d0], x1 = src[10 * (size_t)i + d1];
-    const int coarse = cell_of(x0, cp.lo[0], cp.scale[0], cp.nc[0]) * cp.nc[1] + cell_of(x1, cp.lo[1], cp.scale[1], cp.nc[1]);
-    atomicAdd(&s_h[coarse], 1);
+  unsigned word[CELL_PPT], box[CELL_PPT];
+  int bins[CELL_PPT], rank[CELL_PPT];
+#pragma unroll
+  for (int k = 0; k < CELL_PPT; ++k) {
+    const int i = lo + k * 256 + tid;
+    bins[k] = -1; word[k] = 0; rank[k] = 0; box[k] = 0;
+    if (i < hi) {
+      float v10[10];
+      load10(src + 10 * (size_t)i, v10);
+      int coarse, fine;
+      cell_bins(v10, cp, coarse, fine);
+      bins[k] = fine | (coarse << 16);
+      word[k] = filter_word(v10[0], v10[1], v10[2], v10[3], cp);
+      if (!is_t) box[k] = query_box(v10, cp);
+      rank[k] = atomicAdd(&s_h[coarse], 1);
+    }
   }
   __syncthreads();
-  int* row = reinterpret_cast<int*>(ws + a.w.block_hist) + (size_t)blk * 2 * HCPAD;
-  for (int k = threadIdx.x; k < HCPAD; k += 256) { row[(is_t ? 0 : HCPAD) + k] = s_h[k]; row[(is_t ? HCPAD : 0) + k] = 0; }
+  const int c0 = s_h[2 * tid], c1 = s_h[2 * tid + 1];
+  int total;
+  const int ex = scan512(c0, c1, s_w, total);
+  __syncthreads();                                        // every thread has read its counters
+  s_h[2 * tid] = ex; s_h[2 * tid + 1] = ex + c0;          // first LDS slot of every bin
+  {
+    uint2* row = reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(ws + a.w.dir) + (size_t)blk * HCPAD);
+    row[tid] = make_uint2(((unsigned)c0 << 16) | (unsigned)ex, ((unsigned)c1 << 16) | (unsigned)(ex + c0));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < CELL_PPT; ++k) {
+    if (bins[k] >= 0) {
+      const int slot = s_h[bins[k] >> 16] + rank[k];
+      const int i = lo + k * 256 + tid;
+      s_rec[slot] = is_t ? make_uint4(word[k], (unsigned)i, (unsigned)bins[k], 0u) : make_uint4((unsigned)i, word[k], box[k], (unsigned)(bins[k] >> 16));
+    }
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(ws + (is_t ? a.w.t1 : a.w.ql1)) + lo;
+  for (int j = tid; j < hi - lo; j += 256) dst[j] = s_rec[j];
 }
 
-// level 1, offsets: grid 2 (tree half, query half) x HCPAD threads (one coarse bin each): exclusive scan over the
-// workgroups and over the bins -> coarse_start[2][HCPAD+1]; block_hist becomes per-(workgroup, bin) offsets
-__global__ __launch_bounds__(HCPAD) void cell_coarse_offsets_kernel(CellArgs a) {
+// offsets: grid (2 halves: tree, queries) x frames, HCPAD threads (one coarse bin each): column sums of the directory,
+// exclusive scan over the bins -> coarse_start[2][HCPAD + 1]
+__global__ __launch_bounds__(HCPAD) void cell_offsets_kernel(CellArgs a) {
   const int f = blockIdx.z;
   char* ws = a.ws + f * a.ws_stride;
-  int* block_hist = reinterpret_cast<int*>(ws + a.w.block_hist);
+  const unsigned* dir = reinterpret_cast<const unsigned*>(ws + a.w.dir);
   int* starts = reinterpret_cast<int*>(ws + a.w.coarse_start);
   __shared__ int s_w[HCPAD / 64];
   const int half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b_lo = half ? a.tb : 0, b_hi = half ? a.tb + a.qb : a.tb;          // the rows that hold this set
   int v = 0;
-  for (int b = b_lo; b < b_hi; ++b) v += block_hist[(size_t)b * 2 * HCPAD + half * HCPAD + tid];
+#pragma unroll 4
+  for (int b = b_lo; b < b_hi; ++b) v += (int)(dir[(size_t)b * HCPAD + tid] >> 16);
   int incl = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
@@ -859,163 +964,206 @@ __global__ __launch_bounds__(HCPAD) void cell_coarse_offsets_kernel(CellArgs a) 
   int woff = 0, tot = 0;
 #pragma unroll
   for (int w = 0; w < HCPAD / 64; ++w) { const int c = s_w[w]; if (w < wave) woff += c; tot += c; }
-  int run = woff + incl - v;
-  starts[half * (HCPAD + 1) + tid] = run;
+  starts[half * (HCPAD + 1) + tid] = woff + incl - v;
   if (tid == 0) starts[half * (HCPAD + 1) + HCPAD] = tot;
-  for (int b = b_lo; b < b_hi; ++b) {
-    int* slot = &block_hist[(size_t)b * 2 * HCPAD + half * HCPAD + tid];
-    const int h = *slot;
-    *slot = run;
-    run += h;
-  }
 }
 
-// level 1, placement in coarse order.  Tree: filter prefix + (original index, fine bin); queries: the index alone.
-// A workgroup's records land in ~400 bins, four or so per bin: written straight from the registers that is one
-// scattered 16/8/4-byte store per lane, and the L2 channels take those one request at a time (0.28 of the kernel's
-// 0.43 ms per 200 frames).  The workgroup therefore ORDERS its records by bin in LDS first (its own counts per bin are
-// the differences of consecutive rows of offsets) and then copies LDS -> global in that order: consecutive lanes write
-// consecutive addresses inside a bin's run, and the frame's workgroups share one XCD, whose L2 merges the runs.
-__global__ __launch_bounds__(256) void cell_coarse_place_kernel(CellArgs a) {
-  int f, blk;
-  if (!xcd_frame_block(a.tb + a.qb, a.n_frames, f, blk)) return;
-  char* ws = a.ws + f * a.ws_stride;
-  bool is_t; int lo, hi;
-  cell_slice(blk, a.nt, a.nq, a.tb, a.qb, is_t, lo, hi);
-  const float* src = is_t ? a.tree + f * a.tree_stride : a.qry + f * a.qry_stride;
-  const int half = is_t ? 0 : HCPAD, set = is_t ? 0 : 1;
-  const int* block_off = reinterpret_cast<const int*>(ws + a.w.block_hist);
-  const int* cstart = reinterpret_cast<const int*>(ws + a.w.coarse_start) + set * (HCPAD + 1);
-  float4* t1_pre = reinterpret_cast<float4*>(ws + a.w.t1_pre);
-  int2* t1_meta = reinterpret_cast<int2*>(ws + a.w.t1_meta);
-  int* q1_idx = reinterpret_cast<int*>(ws + a.w.q1_idx);
-  __shared__ int s_off[HCPAD];           // first global slot of this workgroup's records, per bin
-  __shared__ int s_cur[HCPAD];           // LDS cursor per bin (starts at the bin's first LDS slot)
-  __shared__ int s_delta[HCPAD];         // global slot - LDS slot, per bin
-  __shared__ int s_w[4];
-  __shared__ __attribute__((aligned(16))) unsigned char s_rec[PL_TCAP * 24];   // tree: float4 prefix[PL_TCAP] + int2 meta[PL_TCAP];
-                                                                               // queries: int idx[PL_QCAP] + ushort bin[PL_QCAP]
-  static_assert(PL_QCAP * 6 <= PL_TCAP * 24, "query staging must fit the tree staging");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool last_row = is_t ? blk == a.tb - 1 : blk == a.tb + a.qb - 1;
-  // this workgroup's count per bin = next row's offset (or the bin's end) - its own offset; two bins per thread
-  int off[2], cnt[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int k = 2 * tid + j;
-    off[j] = block_off[(size_t)blk * 2 * HCPAD + half + k];
-    const int nxt = last_row ? (k + 1 <= HCPAD ? cstart[k + 1] : off[j]) : block_off[(size_t)(blk + 1) * 2 * HCPAD + half + k];
-    cnt[j] = nxt - off[j];
-  }
-  const int v = cnt[0] + cnt[1];
-  int incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-  if (lane == 63) s_w[wave] = incl;
-  __syncthreads();
-  int woff = 0, total = 0;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) { const int c = s_w[w]; if (w < wave) woff += c; total += c; }
-  const int ex = woff + incl - v;
-  s_off[2 * tid] = off[0]; s_off[2 * tid + 1] = off[1];
-  s_cur[2 * tid] = ex; s_cur[2 * tid + 1] = ex + cnt[0];
-  s_delta[2 * tid] = off[0] - ex; s_delta[2 * tid + 1] = off[1] - (ex + cnt[0]);
-  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
-  const bool ordered = total == hi - lo && total <= (is_t ? PL_TCAP : PL_QCAP);     // else: straight stores
-  __syncthreads();
-  float4* r_pre = reinterpret_cast<float4*>(s_rec);
-  int2* r_meta = reinterpret_cast<int2*>(s_rec + (size_t)PL_TCAP * 16);
-  int* r_qidx = reinterpret_cast<int*>(s_rec);
-  unsigned short* r_qbin = reinterpret_cast<unsigned short*>(s_rec + (size_t)PL_QCAP * 4);
-  for (int i = lo + tid; i < hi; i += 256) {
-    float v10[10];
-    load10(src + 10 * (size_t)i, v10);
-    int coarse, fine;
-    cell_bins(v10, cp, coarse, fine);
-    if (ordered) {
-      const int slot = atomicAdd(&s_cur[coarse], 1);
-      if (is_t) {
-        r_pre[slot] = make_float4(v10[0], v10[1], v10[2], v10[3]);
-        r_meta[slot] = make_int2(i, fine | (coarse << 16));
-      } else {
-        r_qidx[slot] = i;
-        r_qbin[slot] = (unsigned short)coarse;
-      }
-    } else {
-      const int pos = atomicAdd(&s_off[coarse], 1);
-      if (is_t) { t1_pre[pos] = make_float4(v10[0], v10[1], v10[2], v10[3]); t1_meta[pos] = make_int2(i, fine); }
-      else q1_idx[pos] = i;
-    }
-  }
-  if (!ordered) return;
-  __syncthreads();
-  for (int i = tid; i < total; i += 256) {
-    if (is_t) {
-      const int2 m = r_meta[i];
-      const int dest = i + s_delta[m.y >> 16];
-      t1_pre[dest] = r_pre[i];
-      t1_meta[dest] = make_int2(m.x, m.y & 0xffff);
-    } else {
-      q1_idx[i + s_delta[r_qbin[i]]] = r_qidx[i];
-    }
-  }
-}
-
-// level 2 (tree): one workgroup per coarse bin: counting sort of the bin's points by fine bin in LDS, and the bin's
-// slice of the start table (absolute slots) -- the last coarse bin adds the sentinel
+// level 2: one workgroup per GROUP of FG consecutive coarse bins (c0, c1 .. c1 + FG - 1).  A slice's records are ordered by
+// coarse bin, so the group's points form ONE run per slice (directory columns coarse .. coarse + FG - 1): gather them,
+// counting-sort them by (bin, fine bin) in LDS, write the group's slice of the sorted tree (filter word, original index)
+// and of the start tables.  The group's query records are copied from their runs into one contiguous list.
+// The work of a bin is tiny and its time is barriers and DEPENDENT memory round trips, hence the grouping (FG bins share
+// every barrier and every round trip), and everything whose address is known up front (the grid, the group's starts, both
+// directory column groups) is requested at once; both gathers (tree records, query records) fly together.
+// The absolute start table (start_t) is what the search falls back to when a bin holds >= 32768 points (the 16-bit table
+// cannot express its slots): written for such bins only.  Bit 15 of a 16-bit entry says "a run of <= 3 cells starting
+// here holds more than 4 points": the search's first pass looks at four candidates per run and leaves such runs to its
+// second pass.
+constexpr int FG = 5;                    // coarse bins per level-2 workgroup (HNC is a multiple)
+constexpr int FINE_PPT = 4;              // tree records per thread kept in registers between counting and placing
+constexpr int FINE_QPT = 4;              // query records per thread
+constexpr int FCNT = 2048;               // counters: FG * n_fine <= 2000
+static_assert(HNC % FG == 0 && FG * HCOARSE <= FCNT, "");
 __global__ __launch_bounds__(256) void cell_fine_kernel(CellArgs a) {
-  int f, coarse;
-  if (!xcd_frame_block(HCOARSE, a.n_frames, f, coarse)) return;
+  int f, grp;
+  if (!xcd_frame_block(HCOARSE / FG, a.n_frames, f, grp)) return;
   char* ws = a.ws + f * a.ws_stride;
-  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
-  const int n_coarse = cp.nc[0] * cp.nc[1], n_fine = cp.nc[2] * cp.nc[3];
-  if (coarse >= n_coarse) return;
-  const int* cstart = reinterpret_cast<const int*>(ws + a.w.coarse_start);
-  const int begin = cstart[coarse], end = cstart[coarse + 1];
-  __shared__ int s_cnt[HCPAD];
-  __shared__ int s_w[4];
+  const int coarse = grp * FG;                             // first bin of the group (same c0 for all: HNC % FG == 0)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int k = tid; k < HCPAD; k += 256) s_cnt[k] = 0;
+  const unsigned* dir = reinterpret_cast<const unsigned*>(ws + a.w.dir);
+  const int* cstart = reinterpret_cast<const int*>(ws + a.w.coarse_start);
+  // round trip 1
+  auto dir_entry = [&](int row) {                           // the group's run in slice `row`: (points, first slot in the slice)
+    const unsigned* p = dir + (size_t)row * HCPAD + coarse;
+    unsigned cnt = 0;
+#pragma unroll
+    for (int k = 0; k < FG; ++k) cnt += p[k] >> 16;
+    return make_uint2(cnt, p[0] & 0xffffu);
+  };
+  const uint2 e_t0 = tid < a.tb ? dir_entry(tid) : make_uint2(0u, 0u);
+  const uint2 e_q0 = tid < a.qb ? dir_entry(a.tb + tid) : make_uint2(0u, 0u);
+  int bstart[FG + 1];
+#pragma unroll
+  for (int k = 0; k <= FG; ++k) bstart[k] = cstart[coarse + k];
+  const int begin = bstart[0], end = bstart[FG], n = end - begin;
+  int qstart[FG + 1];
+#pragma unroll
+  for (int k = 0; k <= FG; ++k) qstart[k] = cstart[HCPAD + 1 + coarse + k];
+  const int qn = qstart[FG] - qstart[0];
+  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
+  const int n_fine = cp.nc[2] * cp.nc[3];
+  const int c1_first = coarse % HNC;
+  if (coarse / HNC >= cp.nc[0] || c1_first >= cp.nc[1]) return;         // no bin of this grid in the group (it holds nothing)
+  const int bins_here = cp.nc[1] - c1_first < FG ? cp.nc[1] - c1_first : FG;
+  __shared__ int s_cnt[FCNT];
+  __shared__ int s_w[4];
+  __shared__ int s_rs[2][CELL_MAX_SLICES + 1], s_src[2][CELL_MAX_SLICES];   // per set and run: first element number, first source slot
+  __shared__ int s_carry;
+  __shared__ int s_qcur[FG];
+#pragma unroll
+  for (int k = 0; k < FCNT / 256; ++k) s_cnt[tid + 256 * k] = 0;
+  if (tid < FG) {
+    int v = qstart[0];
+#pragma unroll
+    for (int k = 1; k < FG; ++k) if (tid == k) v = qstart[k];
+    s_qcur[tid] = v;                                      // cursor of every bin's query list
+  }
+  // the runs of one set: rows [r0, r0 + nr) of the directory (the first 256 rows were requested above)
+  auto build_runs = [&](int set, int r0, int nr, uint2 e_first) {
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nr; b0 += 256) {
+      const int t = b0 + tid;
+      uint2 e = e_first;
+      if (b0 > 0) e = t < nr ? dir_entry(r0 + t) : make_uint2(0u, 0u);
+      const int cnt = (int)e.x;
+      int incl = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+      if (lane == 63) s_w[wave] = incl;
+      __syncthreads();
+      int woff = s_carry, tot = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { const int c = s_w[w]; if (w < wave) woff += c; tot += c; }
+      if (t < nr) { s_rs[set][t] = woff + incl - cnt; s_src[set][t] = t * CELL_SLICE + (int)e.y; }
+      __syncthreads();
+      if (tid == 0) s_carry += tot;
+      __syncthreads();
+    }
+    if (tid == 0) s_rs[set][nr] = s_carry;
+    __syncthreads();
+  };
+  // source slot of element i: the last run that starts at or before i (empty runs share a start with their successor and
+  // are skipped by "last")
+  auto source_of = [&](int set, int i, int nr) {
+    int lo = 0, hi = nr;                                  // invariant: s_rs[lo] <= i < s_rs[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_rs[set][mid] <= i) lo = mid; else hi = mid;
+    }
+    return s_src[set][lo] + (i - s_rs[set][lo]);
+  };
+  build_runs(0, 0, a.tb, e_t0);
+  build_runs(1, a.tb, a.qb, e_q0);
+  const uint4* t1 = reinterpret_cast<const uint4*>(ws + a.w.t1);
+  const uint4* ql1 = reinterpret_cast<const uint4*>(ws + a.w.ql1);
+  uint4* q1 = reinterpret_cast<uint4*>(ws + a.w.q1);
+  unsigned* tree_word = reinterpret_cast<unsigned*>(ws + a.w.tree_word);
+  int* tree_idx = reinterpret_cast<int*>(ws + a.w.tree_idx);
+  const bool in_regs = n <= 256 * FINE_PPT, q_in_regs = qn <= 256 * FINE_QPT;
+  // counter of a record: (its bin's place in the group) * n_fine + its fine bin
+  auto counter_of = [&](unsigned bins) { return (int)((bins >> 16) - (unsigned)coarse) * n_fine + (int)(bins & 0xffffu); };
+  // round trip 2: both gathers
+  uint4 rec[FINE_PPT], qrec[FINE_QPT];
+  int rk[FINE_PPT];
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < FINE_PPT; ++k) {
+      const int i = tid + 256 * k;
+      rec[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < n) rec[k] = t1[source_of(0, i, a.tb)];
+    }
+  }
+  if (q_in_regs) {
+#pragma unroll
+    for (int k = 0; k < FINE_QPT; ++k) {
+      const int i = tid + 256 * k;
+      qrec[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < qn) qrec[k] = ql1[source_of(1, i, a.qb)];
+    }
+  }
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < FINE_PPT; ++k) {
+      rk[k] = 0;
+      if (tid + 256 * k < n) rk[k] = atomicAdd(&s_cnt[counter_of(rec[k].z)], 1);
+    }
+  } else {
+    for (int i = tid; i < n; i += 256) atomicAdd(&s_cnt[counter_of(t1[source_of(0, i, a.tb)].z)], 1);
+  }
   __syncthreads();
-  const int2* t1_meta = reinterpret_cast<const int2*>(ws + a.w.t1_meta);
-  for (int i = begin + tid; i < end; i += 256) atomicAdd(&s_cnt[t1_meta[i].y], 1);
-  __syncthreads();
-  // exclusive scan of the HCPAD counters: two per thread
-  const int c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
-  const int v = c0 + c1;
-  int incl = v;
+  // exclusive scan of the FCNT counters, eight consecutive ones per thread
+  int c[FCNT / 256];
+  int sum = 0;
+#pragma unroll
+  for (int k = 0; k < FCNT / 256; ++k) { c[k] = s_cnt[(FCNT / 256) * tid + k]; sum += c[k]; }
+  int incl = sum;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
   if (lane == 63) s_w[wave] = incl;
   __syncthreads();
-  int woff = 0;
+  int run = begin + incl - sum;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) if (w < wave) woff += s_w[w];
-  const int ex = begin + woff + incl - v;
+  for (int w = 0; w < 4; ++w) if (w < wave) run += s_w[w];
+#pragma unroll
+  for (int k = 0; k < FCNT / 256; ++k) { s_cnt[(FCNT / 256) * tid + k] = run; run += c[k]; }   // cursors = absolute first slots
   __syncthreads();
-  s_cnt[2 * tid] = ex; s_cnt[2 * tid + 1] = ex + c0;               // cursors = absolute first slots
-  int* start_t = reinterpret_cast<int*>(ws + a.w.start_t) + (size_t)coarse * n_fine;
-  if (2 * tid < n_fine) start_t[2 * tid] = ex;
-  if (2 * tid + 1 < n_fine) start_t[2 * tid + 1] = ex + c0;
-  if (coarse == n_coarse - 1 && tid == 0) start_t[n_fine] = end;   // end sentinel (= nt)
-  // the same row relative to the bin's first slot, 16 bits per entry (what the search stages; a bin of >= 65536
-  // points saturates and is searched through the absolute table instead)
-  unsigned short* rel = reinterpret_cast<unsigned short*>(ws + a.w.start_rel) + (size_t)coarse * HROW;
-  {
-    const int r0 = ex - begin, r1 = ex + c0 - begin;
-    if (2 * tid < n_fine) rel[2 * tid] = (unsigned short)(r0 < 65535 ? r0 : 65535);
-    if (2 * tid + 1 < n_fine) rel[2 * tid + 1] = (unsigned short)(r1 < 65535 ? r1 : 65535);
-    if (tid == 0) { const int re = end - begin; rel[n_fine] = (unsigned short)(re < 65535 ? re : 65535); }
+  // the start tables of the group's bins.  Entry `fine` of bin b: first slot of cell (b, fine); entry n_fine: the bin's end.
+  for (int i = tid; i < bins_here * (n_fine + 1); i += 256) {
+    const int b = i / (n_fine + 1), fine = i - b * (n_fine + 1);
+    int b_begin = bstart[0], b_end = bstart[1];
+#pragma unroll
+    for (int k = 1; k < FG; ++k) if (b == k) { b_begin = bstart[k]; b_end = bstart[k + 1]; }
+    const int at = fine < n_fine ? s_cnt[b * n_fine + fine] : b_end;
+    const int ahead_i = fine + 3 < n_fine ? fine + 3 : n_fine;
+    const int ahead = ahead_i < n_fine ? s_cnt[b * n_fine + ahead_i] : b_end;
+    const int r = at - b_begin;
+    const bool big = b_end - b_begin >= 32768;
+    unsigned short* rel = reinterpret_cast<unsigned short*>(ws + a.w.start_rel) + (size_t)(coarse + b) * HROW;
+    rel[fine] = (unsigned short)(big ? 0x7fff : (r | (ahead - at > 4 ? 0x8000 : 0)));
+    if (big) reinterpret_cast<int*>(ws + a.w.start_t)[(size_t)(coarse + b) * SROW + fine] = at;
   }
   __syncthreads();
-  const float4* t1_pre = reinterpret_cast<const float4*>(ws + a.w.t1_pre);
-  float4* tree_pre = reinterpret_cast<float4*>(ws + a.w.tree_rec);
-  int* tree_idx = reinterpret_cast<int*>(ws + a.w.tree_idx);
-  for (int i = begin + tid; i < end; i += 256) {
-    const int2 m = t1_meta[i];
-    const int pos = atomicAdd(&s_cnt[m.y], 1);
-    tree_pre[pos] = t1_pre[i];
-    tree_idx[pos] = m.x;
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < FINE_PPT; ++k) {
+      const int i = tid + 256 * k;
+      if (i < n) {
+        const int pos = s_cnt[counter_of(rec[k].z)] + rk[k];
+        tree_word[pos] = rec[k].x;
+        tree_idx[pos] = (int)rec[k].y;
+      }
+    }
+  } else {
+    for (int i = tid; i < n; i += 256) {
+      const uint4 r = t1[source_of(0, i, a.tb)];
+      const int pos = atomicAdd(&s_cnt[counter_of(r.z)], 1);
+      tree_word[pos] = r.x;
+      tree_idx[pos] = (int)r.y;
+    }
+  }
+  // the group's queries, every bin's list contiguous (the order inside a bin's list is immaterial)
+  if (q_in_regs) {
+#pragma unroll
+    for (int k = 0; k < FINE_QPT; ++k) {
+      const int i = tid + 256 * k;
+      if (i < qn) q1[atomicAdd(&s_qcur[qrec[k].w - (unsigned)coarse], 1)] = qrec[k];
+    }
+  } else {
+    for (int i = tid; i < qn; i += 256) {
+      const uint4 r = ql1[source_of(1, i, a.qb)];
+      q1[atomicAdd(&s_qcur[r.w - (unsigned)coarse], 1)] = r;
+    }
   }
 }
 
@@ -1025,48 +1173,60 @@ __global__ __launch_bounds__(256) void cell_fine_kernel(CellArgs a) {
 // q1_idx, and their neighbourhoods overlap -- 3 x (CS_NB + 2) staged bins instead of 9 per bin.
 constexpr int CS_PLANES = 3 * (CS_NB + 2);
 constexpr int CS_STRIPS = (HNC + CS_NB - 1) / CS_NB;     // strips per c0 row, at most
+// a 40-byte appearance row (8-byte aligned) as three loads instead of five: every load instruction of a gather costs the
+// texture path one request per lane, whatever its width (global loads take any 4-byte alignment on gfx950)
+struct __attribute__((packed, aligned(8))) Row10 { float v[10]; };
+__device__ __forceinline__ Row10 load_row(const float* p) {
+  Row10 r;
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+  typedef float f2u __attribute__((ext_vector_type(2), aligned(8)));
+  const f4u a = *reinterpret_cast<const f4u*>(p), b = *reinterpret_cast<const f4u*>(p + 4);
+  const f2u c = *reinterpret_cast<const f2u*>(p + 8);
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  r.v[8] = c.x; r.v[9] = c.y;
+  return r;
+}
+
 template <int MODE>
-__global__ __launch_bounds__(CS_THREADS) void cell_search_kernel(CellArgs a) {
+__global__ __launch_bounds__(CS_THREADS, CS_THREADS * 4 / 256) void cell_search_kernel(CellArgs a) {
   int f, blk;
   if (!xcd_frame_block(HNC * CS_STRIPS, a.n_frames, f, blk)) return;
   char* ws = a.ws + f * a.ws_stride;
-  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
-  const int n0 = cp.nc[0], n1 = cp.nc[1], n2 = cp.nc[2], n3 = cp.nc[3];
-  const int n_fine = n2 * n3;
   const int c0 = blk / CS_STRIPS, c1f = (blk - c0 * CS_STRIPS) * CS_NB;
-  if (c0 >= n0 || c1f >= n1) return;
-  const int nb_here = n1 - c1f < CS_NB ? n1 - c1f : CS_NB;
-  const int coarse0 = c0 * n1 + c1f;
-  const int* __restrict__ cstart_t = reinterpret_cast<const int*>(ws + a.w.coarse_start);
+  const int nb_here = HNC - c1f < CS_NB ? HNC - c1f : CS_NB;
+  const int coarse0 = c0 * HNC + c1f;                     // bins are numbered c0 * HNC + c1 whatever the grid: nothing below
+  const int* __restrict__ cstart_t = reinterpret_cast<const int*>(ws + a.w.coarse_start);   // waits for the grid's parameters
   const int* __restrict__ cstart_q = cstart_t + (HCPAD + 1);
-  const int qb = cstart_q[coarse0], qe = cstart_q[coarse0 + nb_here];
-  if (qb >= qe) return;                                   // no query lives here: nothing to stage
-  const int* __restrict__ start_t = reinterpret_cast<const int*>(ws + a.w.start_t);
-  const float4* __restrict__ tree_pre = reinterpret_cast<const float4*>(ws + a.w.tree_rec);
-  const int* __restrict__ tree_idx = reinterpret_cast<const int*>(ws + a.w.tree_idx);
-  const int* __restrict__ q1_idx = reinterpret_cast<const int*>(ws + a.w.q1_idx);
-  const float* __restrict__ tree = a.tree + f * a.tree_stride;
-  const float* __restrict__ qry = a.qry + f * a.qry_stride;
-  unsigned long long* best = a.best + f * a.best_stride;
   const int tid = threadIdx.x;
-
-  __shared__ float4 s_pre[CS_CAP];                        // filter prefixes of the staged tree points (their indices stay in
-                                                          //   global memory: only the ~3 survivors per query need one)
+  __shared__ unsigned s_word[CS_CAP + 4];                 // filter words of the staged tree points (+4: a visit reads four slots)
+  __shared__ int s_idx[CS_CAP];                           // their original indices
   __shared__ __attribute__((aligned(16))) unsigned short s_start[CS_PLANES][HROW];   // cell starts of the staged bins, relative to each bin's first slot
   __shared__ int s_gbase[CS_PLANES], s_lbase[CS_PLANES + 1], s_len[CS_PLANES];   // per bin: first slot in the sorted tree, in LDS, length
-  __shared__ unsigned short s_surv[CS_SURV][CS_THREADS];  // parked filter survivors (LDS slots), lane-private columns
+  __shared__ int s_surv[CS_SURV][CS_THREADS];             // parked filter survivors (original indices), lane-private columns
+  // round trip 1: the strip's queries, the staged bins' segments, the grid -- all addressed by the block index alone.
   // staged bin `s` = (row, col): coarse bin (c0 - 1 + row, c1f - 1 + col); bins outside the grid have length 0
   if (tid < CS_PLANES) {
     const int p0 = c0 - 1 + tid / (CS_NB + 2), p1 = c1f - 1 + tid % (CS_NB + 2);
     int gb = 0, len = 0;
-    if (p0 >= 0 && p0 < n0 && p1 >= 0 && p1 < n1) { gb = cstart_t[p0 * n1 + p1]; len = cstart_t[p0 * n1 + p1 + 1] - gb; }
+    if (p0 >= 0 && p0 < HNC && p1 >= 0 && p1 < HNC) { gb = cstart_t[p0 * HNC + p1]; len = cstart_t[p0 * HNC + p1 + 1] - gb; }
     s_gbase[tid] = gb; s_len[tid] = len;
   }
-  // the first batch of queries: their (dependent) loads are in flight during the set-up and the staging
+  const int qb = cstart_q[coarse0], qe = cstart_q[coarse0 + nb_here];
+  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
+  if (qb >= qe) return;                                   // no query lives here: nothing to stage
+  const int n2 = cp.nc[2], n3 = cp.nc[3];
+  const int n_fine = n2 * n3;
+  const int* __restrict__ start_t = reinterpret_cast<const int*>(ws + a.w.start_t);
+  const unsigned* __restrict__ tree_word = reinterpret_cast<const unsigned*>(ws + a.w.tree_word);
+  const int* __restrict__ tree_idx = reinterpret_cast<const int*>(ws + a.w.tree_idx);
+  const uint4* __restrict__ q1 = reinterpret_cast<const uint4*>(ws + a.w.q1);
+  const float* __restrict__ tree = a.tree + f * a.tree_stride;
+  const float* __restrict__ qry = a.qry + f * a.qry_stride;
+  unsigned long long* best = a.best + f * a.best_stride;
+  // round trip 2: the first batch of query records (original index, filter word, box: written by level 1, which had the
+  // row in registers anyway) beside the staging loads.  The query's floats are not touched before a survivor is decided.
   int qi = qb + tid;
-  int qorig = qi < qe ? q1_idx[qi] : q1_idx[qb];
-  float q[10];
-  load10(qry + 10 * (size_t)qorig, q);
+  uint4 qrec = q1[qi < qe ? qi : qb];
   __syncthreads();
   int total = 0, longest = 0;
   if (tid == 0) s_lbase[0] = 0;
@@ -1077,7 +1237,7 @@ __global__ __launch_bounds__(CS_THREADS) void cell_search_kernel(CellArgs a) {
     longest = len > longest ? len : longest;
     if (tid == 0) s_lbase[s + 1] = total;
   }
-  const bool staged = total <= CS_CAP && longest < 65535;
+  const bool staged = total <= CS_CAP && longest < 32768;
   __syncthreads();
   if (staged) {
     // flattened over the staged bins: every thread's loads are independent, several in flight at once
@@ -1087,141 +1247,167 @@ __global__ __launch_bounds__(CS_THREADS) void cell_search_kernel(CellArgs a) {
 #pragma unroll
       for (int j = 1; j < CS_PLANES; ++j) s += (i >= s_lbase[j]) ? 1 : 0;   // empty bins share a base: the last one wins,
       const int g = s_gbase[s] + (i - s_lbase[s]);                          // and only a bin with points can own slot i
-      s_pre[i] = tree_pre[g];
+      s_word[i] = tree_word[g];
+      s_idx[i] = tree_idx[g];
     }
-    // the bins' rows of the 16-bit start table, eight entries per load
+    if (tid < 4) s_word[total + tid] = 0u;                // the read-ahead behind the last staged point
+    // the bins' rows of the 16-bit start table, eight entries per load; an empty bin's row reads as zeros (all its runs
+    // are empty), so the visits below need no test for it
     const uint4* rel = reinterpret_cast<const uint4*>(ws + a.w.start_rel);
     const int vec_per_row = (n_fine + 1 + 7) / 8;
 #pragma unroll 2
     for (int i = tid; i < CS_PLANES * (HROW / 8); i += CS_THREADS) {
       const int s = i / (HROW / 8), v = i - s * (HROW / 8);
-      if (s_len[s] > 0 && v < vec_per_row) {
-        const int cb = (c0 - 1 + s / (CS_NB + 2)) * n1 + (c1f - 1 + s % (CS_NB + 2));
-        reinterpret_cast<uint4*>(&s_start[s][0])[v] = rel[(size_t)cb * (HROW / 8) + v];
+      if (v < vec_per_row) {
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (s_len[s] > 0) {
+          const int cb = (c0 - 1 + s / (CS_NB + 2)) * HNC + (c1f - 1 + s % (CS_NB + 2));
+          r = rel[(size_t)cb * (HROW / 8) + v];
+        }
+        reinterpret_cast<uint4*>(&s_start[s][0])[v] = r;
       }
     }
   }
   __syncthreads();
 
+  const unsigned T = (unsigned)cp.T;
+#if defined(VO_CS_EXP) && VO_CS_EXP == 1
+  if (a.r2 >= 0.f) return;                                // experiment: staging only
+#endif
   for (; qi < qe; qi += CS_THREADS) {
-    if (qi >= qb + CS_THREADS) { qorig = q1_idx[qi]; load10(qry + 10 * (size_t)qorig, q); }   // later batches (rare)
+    if (qi >= qb + CS_THREADS) qrec = q1[qi];             // later batches (rare)
+    const int qorig = (int)qrec.x;
+    const unsigned qw = qrec.y;
     int c_lo[HK], c_hi[HK];
 #pragma unroll
     for (int j = 0; j < HK; ++j) {
-      const float x = pick10(q, cp.dim[j]);
-      c_lo[j] = cell_of(x - cp.R, cp.lo[j], cp.scale[j], cp.nc[j]);
-      const int h = cell_of(x + cp.R, cp.lo[j], cp.scale[j], cp.nc[j]);
-      c_hi[j] = h < c_lo[j] + 2 ? h : c_lo[j] + 2;
+      c_lo[j] = (int)((qrec.z >> (5 * j)) & 31u);
+      c_hi[j] = c_lo[j] + (int)((qrec.z >> (20 + 2 * j)) & 3u);
     }
-    float bd = a.r2, thr = a.r2 * PREFIX_SLACK;
+    const float* qrow = qry + 10 * (size_t)qorig;
+    float bd = a.r2;
     int bi = -1;
     int n_hit = 0;
     int out_at = 0;
     if (MODE == 2) out_at = a.rs_offsets[qorig];
     // the decision itself: the reference's unfused left-to-right sum (brute_force_search.h:34) over the whole row
-    auto decide = [&](const float4 ta, const int ti, const float2 r2v, const float2 r3v, const float2 r4v) {
-      float d = ta.x - q[0];
+    auto decide = [&](const int ti, const Row10& t, const Row10& q) {
+      float d = t.v[0] - q.v[0];
       float s = d * d;
-      d = ta.y - q[1]; s += d * d;
-      d = ta.z - q[2]; s += d * d;
-      d = ta.w - q[3]; s += d * d;
-      d = r2v.x - q[4]; s += d * d;
-      d = r2v.y - q[5]; s += d * d;
-      d = r3v.x - q[6]; s += d * d;
-      d = r3v.y - q[7]; s += d * d;
-      d = r4v.x - q[8]; s += d * d;
-      d = r4v.y - q[9]; s += d * d;
+#pragma unroll
+      for (int k = 1; k < 10; ++k) { d = t.v[k] - q.v[k]; s += d * d; }
       if (MODE == 0) {
-        if (s < bd || (s == bd && bi >= 0 && ti < bi)) { bd = s; thr = s * PREFIX_SLACK; bi = ti; }
+        if (s < bd || (s == bd && bi >= 0 && ti < bi)) { bd = s; bi = ti; }
       } else if (s < bd) {                               // bd stays radius^2: every point inside the ball
         if (MODE == 2 && out_at + n_hit < a.rs_capacity) a.rs_indices[out_at + n_hit] = ti;
         ++n_hit;
       }
     };
-    // conservative filter (fused, 4 terms): see PREFIX_SLACK.  <=: an exact tie with a lower original index must be seen
-    auto passes = [&](const float4 ta) {
-      const float d0 = ta.x - q[0], d1 = ta.y - q[1], d2 = ta.z - q[2], d3 = ta.w - q[3];
-      return __builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0))) <= thr;
-    };
-    auto consider = [&](const float4 ta, const int ti) {
-      if (passes(ta)) {
-        const float2* row = reinterpret_cast<const float2*>(tree + 10 * (size_t)ti);
-        decide(ta, ti, row[2], row[3], row[4]);
-      }
+    auto consider = [&](const unsigned w, const int ti, const Row10& q) {  // filter, then fetch the row and decide on the spot
+      if (sad4(w, qw) <= T) decide(ti, load_row(tree + 10 * (size_t)ti), q);
     };
     // the query's box in staged-bin coordinates
     const int row_lo = c_lo[0] - (c0 - 1), row_hi = c_hi[0] - (c0 - 1);
     const int col_lo = c_lo[1] - (c1f - 1), col_hi = c_hi[1] - (c1f - 1);
     if (staged && row_lo >= 0 && row_hi <= 2 && col_lo >= 0 && col_hi <= CS_NB + 1) {
-      // Walk first, decide afterwards.  A survivor of the filter needs the rest of its row from global memory (a
-      // miss of ~1 us); deciding it on the spot would stall the whole wave once per lane.  The walk therefore only
-      // PARKS survivors (their LDS slot); the rows of all lanes' k-th survivors are then fetched together.  The
-      // filter runs against radius^2 throughout (it cannot tighten before a decision): a few more survivors
-      // (~2.5 per query on uniform data), no different result -- every decision is order-independent
-      // (minimum of (d2, index)).  A lane whose list is full decides that survivor on the spot.
-      int n_surv = 0;
-      // <= 3 x 3 staged bins per lane; per bin the lane's three runs (c2 = lo..lo+2, contiguous along c3) are walked
-      // as ONE flattened sequence: the trip count of the wave is the largest sum of three run lengths among its
-      // lanes, not the sum of three maxima.  The next candidate is fetched while the current one is filtered.
+      // Phase 1, every lane in lockstep: visit the 27 runs (bin row i0, bin column i1, c2 = c_lo[2] + j; a run is
+      // contiguous along c3), FOUR candidates per visit (a run holds ~1.1 points): four filter words from LDS, four
+      // v_sad_u8, one minimum, one compare -- and one bit per run that holds a survivor.  Nothing is masked here: an index
+      // beyond the box is clamped onto its last cell (a run visited twice), and slots behind a short run belong to the next
+      // cells of the sorted tree; neither can produce a wrong result (a flagged run is re-examined below with exact bounds,
+      // and a point outside the box can never pass the decision).  Runs longer than four points take extra trips.
+      const int d2 = c_hi[2] - c_lo[2], d3 = c_hi[3] - c_lo[3];
+      int ia[3];                                          // byte offset of the run's first table entry inside a bin's row
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int c2 = c_lo[2] + (j < d2 ? j : d2);
+        ia[j] = 2 * (c2 * n3 + c_lo[3]);
+      }
+      unsigned hits = 0;
+      int sbin[3], scol[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        sbin[i] = (row_lo + i < row_hi ? row_lo + i : row_hi) * (CS_NB + 2);
+        scol[i] = col_lo + i < col_hi ? col_lo + i : col_hi;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(ia[j]));    // keep them: re-deriving one costs a v_mul_lo_u32 per run
+#pragma unroll
       for (int i0 = 0; i0 < 3; ++i0)
+#pragma unroll
         for (int i1 = 0; i1 < 3; ++i1) {
-          const bool in01 = row_lo + i0 <= row_hi && col_lo + i1 <= col_hi;
-          const int s = in01 ? (row_lo + i0) * (CS_NB + 2) + col_lo + i1 : 0;
-          // the three runs as plain scalars, and no lambda that captures them by reference: the compiler otherwise
-          // parks them in scratch memory and selects among their ADDRESSES
-          const bool in_s = in01 && s_len[s] > 0;
+          const int s = sbin[i0] + scol[i1];
           const int lb = s_lbase[s];
-          const int c2a = c_lo[2], c2b = c_lo[2] + 1, c2c = c_lo[2] + 2;
-          const bool ina = in_s && c2a <= c_hi[2], inb = in_s && c2b <= c_hi[2], inc = in_s && c2c <= c_hi[2];
-          const int sa0 = s_start[s][ina ? c2a * n3 + c_lo[3] : 0], sb0 = s_start[s][ina ? c2a * n3 + c_hi[3] + 1 : 0];
-          const int sa1 = s_start[s][inb ? c2b * n3 + c_lo[3] : 0], sb1 = s_start[s][inb ? c2b * n3 + c_hi[3] + 1 : 0];
-          const int sa2 = s_start[s][inc ? c2c * n3 + c_lo[3] : 0], sb2 = s_start[s][inc ? c2c * n3 + c_hi[3] + 1 : 0];
-          const int ln0 = ina ? sb0 - sa0 : 0, ln1 = inb ? sb1 - sa1 : 0, ln2 = inc ? sb2 - sa2 : 0;
-          const int l01 = ln0 + ln1, tot = l01 + ln2;
-          const int b0 = lb + sa0, b1 = lb + sa1 - ln0, b2 = lb + sa2 - l01;     // slot(k) = k + (b0 | b1 | b2)
-          int pos = b0;
-          pos = 0 >= ln0 ? b1 : pos;
-          pos = 0 >= l01 ? b2 : pos;
-          pos = tot > 0 ? pos : 0;
-          float4 ta = s_pre[pos];
-          for (int k = 0; k < tot; ++k) {
-            int base_n = b0;
-            base_n = k + 1 >= ln0 ? b1 : base_n;
-            base_n = k + 1 >= l01 ? b2 : base_n;
-            const int pos_n = k + 1 < tot ? base_n + k + 1 : pos;       // (always a valid slot: one unconditional read)
-            const float4 ta_n = s_pre[pos_n];
-            if (passes(ta)) {
-              if (n_surv < CS_SURV) { s_surv[n_surv][tid] = (unsigned short)(pos | (s << 12)); ++n_surv; }
-              else consider(ta, tree_idx[s_gbase[s] + pos - lb]);
-            }
-            pos = pos_n; ta = ta_n;
+          const char* trow = reinterpret_cast<const char*>(&s_start[0][0]) + __umul24((unsigned)s, (unsigned)(HROW * 2));
+          // the bin's three runs: ONE table entry each (first slot; bit 15: the run may hold more than four points -- then
+          // the second pass looks at all of it), four filter words, no branch
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const unsigned e = *reinterpret_cast<const unsigned short*>(trow + ia[j]);
+            const unsigned* w = &s_word[lb + (int)(e & 0x7fffu)];
+            unsigned m = sad4(w[0], qw);
+            { const unsigned m1 = sad4(w[1], qw), m2 = sad4(w[2], qw), m3 = sad4(w[3], qw);
+              m = m < m1 ? m : m1; m = m < m2 ? m : m2; m = m < m3 ? m : m3; }
+            m = e >= 0x8000u ? 0u : m;
+            hits |= m <= T ? (1u << (9 * i0 + 3 * i1 + j)) : 0u;   // (an empty run flagged by the slots behind it costs one empty visit below)
           }
         }
-      for (int k = 0; k < n_surv; k += 3) {               // three rows per lane in flight
-        const bool h1 = k + 1 < n_surv, h2 = k + 2 < n_surv;
-        const int ka = s_surv[k][tid], kb = s_surv[h1 ? k + 1 : k][tid], kc = s_surv[h2 ? k + 2 : k][tid];
-        const int pa = ka & 4095, pb = kb & 4095, pc = kc & 4095;            // LDS slots; bits 15:12 = the staged bin
-        const float4 fa = s_pre[pa], fb = s_pre[pb], fc = s_pre[pc];
-        const int ia = tree_idx[s_gbase[ka >> 12] + pa - s_lbase[ka >> 12]];
-        const int ib = tree_idx[s_gbase[kb >> 12] + pb - s_lbase[kb >> 12]];
-        const int ic = tree_idx[s_gbase[kc >> 12] + pc - s_lbase[kc >> 12]];
-        const float2* ra = reinterpret_cast<const float2*>(tree + 10 * (size_t)ia);
-        const float2* rb = reinterpret_cast<const float2*>(tree + 10 * (size_t)ib);
-        const float2* rc = reinterpret_cast<const float2*>(tree + 10 * (size_t)ic);
-        const float2 a2 = ra[2], a3 = ra[3], a4 = ra[4], b2 = rb[2], b3 = rb[3], b4 = rb[4], c2 = rc[2], c3 = rc[3], c4 = rc[4];
-        decide(fa, ia, a2, a3, a4);
-        if (h1) decide(fb, ib, b2, b3, b4);
-        if (h2) decide(fc, ic, c2, c3, c4);
+      // Phase 2: the flagged runs again, with exact bounds.  A survivor needs its row from global memory (a miss of ~1-2 us)
+      // and the query's: the query's row is requested before the runs are walked, the first survivor's row the moment it is
+      // found -- both fly while the remaining runs are examined -- and further survivors of MODE 0 are parked (their original
+      // index) and fetched together afterwards; the other modes decide on the spot.
+      const Row10 qv = load_row(qrow);
+      Row10 first_row;
+      int first_ti = -1;
+      int n_surv = 0;
+#if defined(VO_CS_EXP) && VO_CS_EXP == 2
+      if (a.r2 >= 0.f) hits = hits & 0x80000000u;         // experiment: no survivor is examined
+#endif
+      while (hits != 0u) {
+        const int bit = __builtin_ctz(hits);
+        hits &= hits - 1u;
+        const int i0 = bit / 9, i1 = (bit - 9 * i0) / 3, j = bit - 9 * i0 - 3 * i1;
+        if (row_lo + i0 > row_hi || col_lo + i1 > col_hi || j > d2) continue;     // a clamped duplicate
+        const int s = (row_lo + i0) * (CS_NB + 2) + col_lo + i1;
+        const int lb = s_lbase[s];
+        const int e0 = (c_lo[2] + j) * n3 + c_lo[3];
+        const int sa = s_start[s][e0] & 0x7fff, sb = s_start[s][e0 + d3 + 1] & 0x7fff;
+        for (int k = sa; k < sb; ++k) {
+          const unsigned w = s_word[lb + k];
+          if (sad4(w, qw) <= T) {
+            const int ti = s_idx[lb + k];
+            if (MODE == 0 && first_ti < 0) { first_ti = ti; first_row = load_row(tree + 10 * (size_t)ti); }
+            else if (MODE == 0 && n_surv < CS_SURV) { s_surv[n_surv][tid] = ti; ++n_surv; }
+            else decide(ti, load_row(tree + 10 * (size_t)ti), qv);
+          }
+        }
+      }
+      if (MODE == 0) {
+        if (first_ti >= 0) decide(first_ti, first_row, qv);
+        for (int k = 0; k < n_surv; k += 2) {             // two more rows per lane in flight
+          const bool h1 = k + 1 < n_surv;
+          const int ia_ = s_surv[k][tid], ib_ = s_surv[h1 ? k + 1 : k][tid];
+          const Row10 ra = load_row(tree + 10 * (size_t)ia_), rb = load_row(tree + 10 * (size_t)ib_);
+          decide(ia_, ra, qv);
+          if (h1) decide(ib_, rb, qv);
+        }
       }
     } else {
-      // the same walk on global memory (segments beyond the LDS budget, or a box beyond the staged bins)
+      // the same search on global memory (segments beyond the LDS budget, or a box beyond the staged bins)
+      const unsigned short* rel_g = reinterpret_cast<const unsigned short*>(ws + a.w.start_rel);
+      const Row10 qv = load_row(qrow);
       for (int x0 = c_lo[0]; x0 <= c_hi[0]; ++x0)
-        for (int x1 = c_lo[1]; x1 <= c_hi[1]; ++x1)
+        for (int x1 = c_lo[1]; x1 <= c_hi[1]; ++x1) {
+          const int cb = x0 * HNC + x1;
+          const int b_begin = cstart_t[cb];
+          const bool big = cstart_t[cb + 1] - b_begin >= 32768;          // its slots do not fit the 16-bit table
           for (int x2 = c_lo[2]; x2 <= c_hi[2]; ++x2) {
-            const int key0 = ((x0 * n1 + x1) * n2 + x2) * n3;
-            const int e = start_t[key0 + c_hi[3] + 1];
-            for (int p = start_t[key0 + c_lo[3]]; p < e; ++p) consider(tree_pre[p], tree_idx[p]);
+            const int k0 = x2 * n3 + c_lo[3], k1 = x2 * n3 + c_hi[3] + 1;
+            const int p0 = big ? start_t[(size_t)cb * SROW + k0] : b_begin + (rel_g[(size_t)cb * HROW + k0] & 0x7fff);
+            const int p1 = big ? start_t[(size_t)cb * SROW + k1] : b_begin + (rel_g[(size_t)cb * HROW + k1] & 0x7fff);
+            for (int p = p0; p < p1; ++p) consider(tree_word[p], tree_idx[p], qv);
           }
+        }
     }
     if (MODE == 0)
       best[qorig] = bi >= 0 ? (((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(unsigned)bi)
@@ -1238,15 +1424,14 @@ static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tr
   a.w = cell_ws_layout(nt, nq);
   a.ws_stride = a.w.total; a.tree_stride = tree_stride; a.qry_stride = qry_stride; a.best_stride = best_stride;
   a.n_frames = n_frames;
-  cell_level1_blocks(nt, nq, a.tb, a.qb);
+  a.tb = cell_slices(nt); a.qb = cell_slices(nq);
   a.radius = radius; a.r2 = r2; a.best = d_best;
   a.rs_offsets = nullptr; a.rs_indices = nullptr; a.rs_capacity = 0;
   const unsigned Z = (unsigned)n_frames;
   hipLaunchKernelGGL(cell_bounds_kernel, dim3(Z), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(cell_coarse_hist_kernel, dim3(xcd_grid(a.tb + a.qb, n_frames)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(cell_coarse_offsets_kernel, dim3(2, 1, Z), dim3(HCPAD), 0, st, a);
-  hipLaunchKernelGGL(cell_coarse_place_kernel, dim3(xcd_grid(a.tb + a.qb, n_frames)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(cell_fine_kernel, dim3(xcd_grid(HCOARSE, n_frames)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_place_kernel, dim3(xcd_grid(a.tb + a.qb, n_frames)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(cell_offsets_kernel, dim3(2, 1, Z), dim3(HCPAD), 0, st, a);
+  hipLaunchKernelGGL(cell_fine_kernel, dim3(xcd_grid(HCOARSE / FG, n_frames)), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

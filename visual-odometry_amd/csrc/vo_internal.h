@@ -158,6 +158,7 @@ hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const in
 // workspace of variant v holds match_workspace_bytes(v, nt, nq, n_frames) bytes
 size_t match_pruned_workspace_bytes(int nt, int nq, int n_frames);
 size_t match_cells_workspace_bytes(int nt, int nq, int n_frames);
+bool match_cells_supported(int nt, int nq);   // set sizes the cell-hash search takes (beyond: the bucket-pruned scan)
 inline size_t match_workspace_bytes(int variant, int nt, int nq, int n_frames) {
   return variant == 3 ? match_cells_workspace_bytes(nt, nq, n_frames)
        : variant == 2 ? match_pruned_workspace_bytes(nt, nq, n_frames) : 0;
