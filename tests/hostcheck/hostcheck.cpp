@@ -67,6 +67,15 @@ void hc_ldlt6_perm(const float* A_colmajor, const float* rhs, float* x) {
   ldlt6_solve_perm(full, rhs, scratch, x);
 }
 
+// the round kernels' solve since round 3: natural elimination order (H is positive definite)
+void hc_ldlt6_ordered(const float* A_colmajor, const float* rhs, float* x) {
+  float B[6][6], y[6];
+  for (int r = 0; r < 6; ++r) { y[r] = rhs[r]; for (int c = 0; c < 6; ++c) B[r][c] = A_colmajor[r + 6 * c]; }
+  ldlt6_solve_ordered(B, y);
+  for (int r = 0; r < 6; ++r) x[r] = y[r];
+}
+void hc_sincos_small(float v, float* s, float* c) { sincos_small(v, *s, *c); }
+
 void hc_ldlt2(const float* m, const float* rhs, float* x) { ldlt2_solve(m[0], m[1], m[3], rhs[0], rhs[1], x[0], x[1]); }
 
 int hc_triangulate_point(const float* d1, const float* d2, const float* p2, float* p) {

@@ -24,40 +24,47 @@ def test_whole_test_app():
         assert "EPIPOLAR" in r.stdout and "PICP" in r.stdout
 
 
-def test_vo_complete_on_example_data(tmp_path, o32):
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "apps"), "-s"])
-    r = subprocess.run([os.path.join(BIN, "vo_complete"), DATA, str(tmp_path)], capture_output=True, text=True, timeout=300)
+def _vo_complete(out_dir, *flags):
+    os.makedirs(out_dir, exist_ok=True)
+    r = subprocess.run([os.path.join(BIN, "vo_complete"), DATA, str(out_dir), *flags], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr
-    e = subprocess.run([os.path.join(BIN, "evaluate"), DATA, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    poses = np.loadtxt(os.path.join(out_dir, "poses_raw.txt"), dtype=np.float64).astype(np.float32).reshape(-1, 4, 4)
+    counts = np.array(re.findall(r"^meas-\d+\.dat: (\d+) matches, (\d+) model correspondences, (\d+) inliers", r.stdout, flags=re.M), dtype=int)
+    return poses, counts
+
+
+def test_vo_complete_on_example_data(tmp_path, o32):
+    """BASELINE configs[4] in the default (fast) arithmetic.  The parity evidence for this dataset is the reference-order
+    run (tests/test_gpu_exact.py: every count and every pose of the chain bit for bit).  The fast mode is judged against
+    THAT run frame by frame while the chain is young: the tail of this sequence is chaotic -- 119 chained solves with 6-32
+    inliers each, where a last-bit change of one pose flips a borderline z_far gate some frames later and moves the end-to-end
+    RMSE figures by tens of percent within the float32 oracle itself -- so end-to-end bounds on the fast mode's RMSE say
+    nothing (round-2 review, item 7)."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "apps"), "-s"])
+    fast, c_fast = _vo_complete(tmp_path / "fast")
+    exact, c_exact = _vo_complete(tmp_path / "exact", "--exact")
+    assert fast.shape == exact.shape == (121, 4, 4) and c_fast.shape == c_exact.shape == (119, 3)
+    # appearance matches do not depend on the pose: equal on all 119 frames; the joined correspondences follow the previous
+    # frame's triangulation: equal while the chain is young
+    assert np.array_equal(c_fast[:, 0], c_exact[:, 0])
+    assert np.array_equal(c_fast[:40, 1], c_exact[:40, 1])
+    assert np.array_equal(c_fast[:25], c_exact[:25])                       # inlier counts too
+    # per-frame relative pose against the reference-order run, first 40 frames (as tests/test_gpu_fullsize.py does for
+    # config 3): rounding-level
+    d = np.abs(fast[:41] - exact[:41]).reshape(41, -1).max(1)
+    assert d.max() < 5e-4, d
+    # the evaluation's scale (a median over all frames, hence robust) still reproduces the README's 1/r_t
+    e = subprocess.run([os.path.join(BIN, "evaluate"), DATA, str(tmp_path / "fast")], capture_output=True, text=True, timeout=60)
     assert e.returncode == 0, e.stdout + e.stderr
     val = {k: float(v) for k, v in re.findall(r"^(.*?):\s*([-0-9.e+]+)", e.stdout, flags=re.M)}
-    ratio, rmse_pos, rmse_map = val["ratio used for map correction"], val["RMSE position"], val["RMSE map"]
-    # README (README.md:74-79).  The sequence is a chain of 119 solves with 6-32 inliers each: any change of
-    # summation order flips a borderline z_far gate somewhere after frame ~35 and the tail of the trajectory
-    # moves by centimetres (measured over three reduction orders of this library and the float32 oracle:
-    # 1/r_t 0.4698-0.4734, RMSE_pos 0.140-0.177, RMSE_map 0.115-0.215; README 0.47337 / 0.145 / 0.184).
-    assert abs(ratio - README["inv_ratio"]) < 0.015 * README["inv_ratio"]
-    assert abs(rmse_pos - README["rmse_pos"]) < 0.30 * README["rmse_pos"]
-    assert 0.4 * README["rmse_points"] < rmse_map < 1.5 * README["rmse_points"]
-    # oracle run of the same loop: same matches/joins every frame, poses equal while the chain is young
+    assert abs(val["ratio used for map correction"] - README["inv_ratio"]) < 0.015 * README["inv_ratio"]
+    # and the oracle-side run of the loop agrees with the fast mode's first dozen robot positions
     res = vp.run_vo_complete(DATA, rounds=100, o=o32)
-    ev = vp.evaluate(DATA, res)
-    counts = re.findall(r"^meas-\d+\.dat: (\d+) matches, (\d+) model correspondences, (\d+) inliers", r.stdout, flags=re.M)
-    assert len(counts) == 119
-    got = np.array(counts, dtype=int)
-    exp = np.array(res["stats"], dtype=int)
-    assert np.array_equal(got[:, 0], exp[:, 0])                  # appearance matches: exact, all 119 frames
-    assert np.array_equal(got[:, 1], exp[:, 1])                  # joined correspondences: exact, all frames
-    assert np.array_equal(got[:25], exp[:25])                    # inlier counts: exact while the chain is young
-    # 119 chained solves with 6-32 inliers each amplify last-bit differences: later frames may flip a
-    # borderline z_far gate (measured: +-1 inlier in ~25 % of the frames after frame 44)
-    assert np.abs(got[:, 2] - exp[:, 2]).max() <= 8 and np.mean(got[:, 2] == exp[:, 2]) > 0.5
-    est = np.loadtxt(os.path.join(tmp_path, "trajectory_est_complete.txt"))
+    est = np.loadtxt(os.path.join(tmp_path / "fast", "trajectory_est_complete.txt"))
     ref = np.array([T[:3, 3] for T in vp.robot_trajectory(res["trajectory"], res["H"])])
     assert est.shape == ref.shape == (121, 3)
     assert np.abs(est[:12] - ref[:12]).max() < 2e-3
-    assert abs(ratio - ev["median_ratio_inv"]) < 0.015 * ev["median_ratio_inv"]
-    assert abs(rmse_pos - ev["rmse_position"]) < 0.35 * ev["rmse_position"]
+    assert np.array_equal(c_fast[:, 0], np.array(res["stats"], dtype=int)[:, 0])
 
 
 def test_cpp_batch_frames_app():

@@ -119,6 +119,62 @@ def test_ldlt6_bit_exact_with_oracle(hc, o32):
     assert np.array_equal(z, np.arange(6, dtype=np.float32) / np.float32(4.0))
 
 
+def test_ldlt6_without_pivoting_on_positive_definite_systems(hc, o32):
+    """The round kernels' solve since round 3 eliminates in the natural order: H = sum(lambda J^T J) + I is positive
+    definite, where LDL^T is backward stable in any order.  On SPD systems: float32-level backward error like the pivoted
+    variants; bit-identical to the pivot-simulating variant whenever the diagonal already descends (its permutation is the
+    identity then); on a PICP-shaped H (rotation block 1e3 x the translation block) the forward error stays comparable."""
+    rng = np.random.default_rng(5)
+    for k in range(200):
+        A = rng.normal(size=(9, 6)).astype(np.float32)
+        if k % 2:                                            # PICP-like scaling: columns 3..5 (rotation) dominate
+            A[:, 3:] *= np.float32(10.0) ** rng.uniform(1, 2.5)
+        S = (A.T @ A).astype(np.float32) + np.eye(6, dtype=np.float32)
+        if k % 5 == 0:                                       # descending diagonal: Eigen's order is the natural one
+            order = np.argsort(-np.diag(S), kind="stable")
+            S = np.ascontiguousarray(S[np.ix_(order, order)])
+        b = rng.normal(size=6).astype(np.float32)
+        xo, xp, xe = np.zeros(6, np.float32), np.zeros(6, np.float32), np.zeros(6, np.float32)
+        hc.hc_ldlt6_ordered(p(np.ascontiguousarray(S.T).ravel()), p(b), p(xo))
+        hc.hc_ldlt6_perm(p(np.ascontiguousarray(S.T).ravel()), p(b), p(xp))
+        hc.hc_ldlt6(p(np.ascontiguousarray(S.T).ravel()), p(b), p(xe))
+        d = np.diag(S)
+        if np.all(d[:-1] > d[1:]):
+            assert xo.tobytes() == xp.tobytes()
+        S64, b64 = S.astype(np.float64), b.astype(np.float64)
+        res = np.abs(S64 @ xo - b64).max()
+        assert res <= 2e-5 * (np.abs(S64).sum(1).max() * np.abs(xo).max() + np.abs(b64).max())
+        x64 = np.linalg.solve(S64, b64)
+        assert np.abs(xo - x64).max() <= 8 * max(np.abs(xe - x64).max(), 1e-6 * np.abs(x64).max())
+    z = np.ones(6, np.float32)
+    hc.hc_ldlt6_ordered(p(np.zeros(36, np.float32)), p(np.ones(6, np.float32)), p(z))
+    assert np.all(z == 0)
+    I6 = np.eye(6, dtype=np.float32) * np.float32(4.0)
+    hc.hc_ldlt6_ordered(p(I6.ravel()), p(np.arange(6, dtype=np.float32)), p(z))
+    assert np.array_equal(z, np.arange(6, dtype=np.float32) / np.float32(4.0))
+
+
+def test_small_angle_sincos(hc):
+    """sincos_small (the round kernels' sin / cos of a Gauss-Newton step): within 1.5 ulp of the correctly rounded values
+    on |x| <= 0.5, exact at 0"""
+    import ctypes
+    hc.hc_sincos_small.argtypes = [ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([rng.uniform(-0.5, 0.5, 20000), rng.uniform(-1e-3, 1e-3, 5000), [0.0, 0.5, -0.5, 1e-20, -1e-30]]).astype(np.float32)
+    worst_s = worst_c = 0.0
+    for x in xs:
+        s, c = ctypes.c_float(), ctypes.c_float()
+        hc.hc_sincos_small(float(x), ctypes.byref(s), ctypes.byref(c))
+        rs, rc = np.sin(np.float64(x)), np.cos(np.float64(x))
+        us = float(np.spacing(np.float32(abs(rs)))) if rs != 0 else 1e-45
+        worst_s = max(worst_s, abs(float(s.value) - rs) / us)
+        worst_c = max(worst_c, abs(float(c.value) - rc) / float(np.spacing(np.float32(rc))))
+    assert worst_s <= 1.5 and worst_c <= 1.5, (worst_s, worst_c)
+    s, c = ctypes.c_float(), ctypes.c_float()
+    hc.hc_sincos_small(0.0, ctypes.byref(s), ctypes.byref(c))
+    assert s.value == 0.0 and c.value == 1.0
+
+
 def test_ldlt2_and_triangulate_point_bit_exact(hc, o32):
     rng = np.random.default_rng(3)
     for _ in range(200):

@@ -133,7 +133,7 @@ __device__ __forceinline__ void store_pose12(float* p, const Pose& P) {
   for (int i = 0; i < 3; ++i) p[9 + i] = P.t[i];
 }
 
-// ---- tail of oneRound (picp_solver.cpp:102-110), latency-optimised -----------------
+// ---- tail of oneRound (picp_solver.cpp:102-110), Eigen's pivot order (rounds 1-2; -DVO_TAIL_SERIAL builds it for A/B) ----
 // Stage 1 (any 42 threads, before a workgroup barrier): expand the reduced
 // accumulators into the full symmetric H (+damping) and -b in LDS.
 // Stage 2 (all 64 lanes of ONE wave, redundantly and identically, so nothing
@@ -175,6 +175,60 @@ __device__ __forceinline__ Pose picp_tail_wave(float* s_sys, const Pose& T) {
   const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 2));
   const Pose dT = v2t_from_sincos(dx, sx, cx, sy, cy, sz, cz);
   return pose_mul(dT, T);                                  // picp_solver.cpp:110
+}
+
+// ---- the tail without pivoting and without LDS (round 3, the default) -------------------------------------------
+// H = sum(lambda J^T J) + damping * I is symmetric positive definite by construction, and an LDL^T of such a matrix is
+// backward stable in ANY pivot order (no element growth: Higham, Accuracy and Stability, thm 10.3) -- Eigen pivots because
+// its LDLT also serves semidefinite and indefinite matrices.  The fast mode therefore eliminates in the natural order: no
+// ranking, no permutation through LDS (two dependent round trips), no un-permutation.  The lower triangle and -b are taken
+// straight out of the lanes that hold them (27 v_readlane, compile-time lane numbers); factorisation and substitutions are
+// ldlt6_solve_ordered, redundant in all lanes; the three angles go through the small-angle sin / cos in three lanes.
+// Against the reference's arithmetic this is one more rounding-level deviation of the fast mode (vo_math.h), the
+// reference-order mode keeps Eigen's pivoted factorisation.
+__device__ __forceinline__ Pose picp_tail_direct(float val, const Pose& T) {
+  const int lane = threadIdx.x & 63;
+  float B[6][6], y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      B[i][j] = j <= i ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val), 6 * i + j)) : 0.f;
+    y[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val), 36 + i));
+  }
+  ldlt6_solve_ordered(B, y);
+  const int m = lane % 3;
+  const float ang = m == 0 ? y[3] : (m == 1 ? y[4] : y[5]);
+  float sn, cs;
+  if (__builtin_expect(!(fabsf(y[3]) <= 0.5f && fabsf(y[4]) <= 0.5f && fabsf(y[5]) <= 0.5f), 0)) sincosf(ang, &sn, &cs);
+  else sincos_small(ang, sn, cs);
+  const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 0));
+  const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 0));
+  const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 1));
+  const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 1));
+  const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 2));
+  const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 2));
+  const Pose dT = v2t_from_sincos(y, sx, cx, sy, cy, sz, cz);
+  return pose_mul(dT, T);                                  // picp_solver.cpp:110
+}
+
+// what lane l of the solving wave contributes: H(l / 6, l % 6) + damping on the diagonal from the reduced accumulators
+// (s_tot: NACC floats in LDS), -b(l - 36), 0 beyond.  Optionally publishes H (col-major) and b.
+__device__ __forceinline__ float picp_lane_value(const float* s_tot, float damping, float* H_out, float* b_out) {
+  const int lane = threadIdx.x & 63;
+  float val = 0.f;
+  if (lane < 36) {
+    const int r = (lane * 43) >> 8, c = lane - 6 * r;
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    val = s_tot[(13 * lo - lo * lo) / 2 + (hi - lo)];      // row-major upper triangle
+    if (r == c) val += 1.f * damping;                      // picp_solver.cpp:102
+    if (H_out) H_out[r + 6 * c] = val;
+  } else if (lane < 42) {
+    const float bv = s_tot[21 + (lane - 36)];
+    val = -bv;                                             // picp_solver.cpp:109 solve(-b)
+    if (b_out) b_out[lane - 36] = bv;
+  }
+  return val;
 }
 
 // ---- pack -------------------------------------------------------------------
@@ -243,7 +297,9 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
   }
   __shared__ __attribute__((aligned(16))) float s_acc[PICP_SACC];   // also the staging of the partial rows
   __shared__ float s_part[PICP_PARTS * 32];
+#ifdef VO_TAIL_SERIAL
   __shared__ float s_sys[PICP_BLOCK / 64][48];
+#endif
   __shared__ float s_stat[4];
   const int tid = threadIdx.x;
   VO_STAMP(0);
@@ -322,7 +378,10 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     // (+damping on the diagonal, picp_solver.cpp:102), lanes 36..41 -b, lanes 42..44 the
     // statistics.  Fixed order => every wave of every workgroup gets the same bits.
     const int wave = tid >> 6, lane = tid & 63;
+#ifdef VO_TAIL_SERIAL
     float* sys = s_sys[wave];
+#endif
+    float val = 0.f;                                         // this lane's entry of the system (picp_tail_direct)
     if (lane < 45) {
       int slot;
       bool diag = false;
@@ -339,21 +398,21 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
 #pragma unroll
       for (int k = 0; k < PICP_GROUPS / 4; ++k) { const float4 t4 = row[k]; tsum += t4.x; tsum += t4.y; tsum += t4.z; tsum += t4.w; }
       if (lane < 36) {
-        const float hv = diag ? tsum + 1.f * damping : tsum;
-        sys[lane] = hv;
-        if (FINISH && blockIdx.x == 0 && wave == 0) S->H[(lane % 6) * 6 + lane / 6] = hv;    // col-major
+        val = diag ? tsum + 1.f * damping : tsum;
+        if (FINISH && blockIdx.x == 0 && wave == 0) S->H[(lane % 6) * 6 + lane / 6] = val;    // col-major
       } else if (lane < 42) {
-        sys[lane] = -tsum;                                   // picp_solver.cpp:109 solve(-b)
+        val = -tsum;                                         // picp_solver.cpp:109 solve(-b)
         if (FINISH && blockIdx.x == 0 && wave == 0) S->b[lane - 36] = tsum;
       } else if (wave == 0) {
         s_stat[lane - 42] = tsum;
       }
     }
-    // the tail below reads what other lanes of THIS wave just wrote: LDS operations of a wave
-    // execute in order, the fence/wave_barrier only pin the compiler's order
+#ifdef VO_TAIL_SERIAL
+    if (lane < 42) sys[lane] = val;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
     VO_STAMP(2);
     {
       Pose Tprev;
@@ -361,7 +420,11 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
       Tprev.R[4] = pz1.x; Tprev.R[5] = pz1.y; Tprev.R[6] = pz1.z; Tprev.R[7] = pz1.w;
       Tprev.R[8] = pz2.x; Tprev.t[0] = pz2.y; Tprev.t[1] = pz2.z; Tprev.t[2] = pz2.w;
       const Pose Told = uniform_pose(Tprev);
+#ifdef VO_TAIL_SERIAL
       const Pose Tn = picp_tail_wave(sys, Told);
+#else
+      const Pose Tn = picp_tail_direct(val, Told);
+#endif
       if (tid == 0 && blockIdx.x == 0) {
         store_pose12(S->pose[FINISH ? 0 : (it & 1)], Tn);
         if (FINISH) {
@@ -469,7 +532,9 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_small_kernel(const PicpParams
   __shared__ __attribute__((aligned(16))) float s_acc[PICP_SACC];
   __shared__ float s_part[PICP_PARTS * 32];
   __shared__ float s_tot[32];
+#ifdef VO_TAIL_SERIAL
   __shared__ float s_sys[PICP_BLOCK / 64][48];
+#endif
   __shared__ float s_stat[4];
   const PackedCorr pk{const_cast<float*>(pk_base), pk_cap};
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -491,7 +556,10 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_small_kernel(const PicpParams
     if (tid < 32) s_tot[tid] = tid < NACC ? tot : 0.f;
     __syncthreads();
     // every wave builds the system and solves it on its own (as step (4) of picp_round_body)
+#ifdef VO_TAIL_SERIAL
     float* sys = s_sys[wave];
+#endif
+    float val = 0.f;
     if (lane < 45) {
       int slot;
       bool diag = false;
@@ -505,20 +573,24 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_small_kernel(const PicpParams
       }
       const float tsum = 0.f + s_tot[slot];              // what summing the one partial row and its zero padding gives
       if (lane < 36) {
-        const float hv = diag ? tsum + 1.f * damping : tsum;
-        sys[lane] = hv;
-        if (last && wave == 0) S->H[(lane % 6) * 6 + lane / 6] = hv;    // col-major
+        val = diag ? tsum + 1.f * damping : tsum;
+        if (last && wave == 0) S->H[(lane % 6) * 6 + lane / 6] = val;    // col-major
       } else if (lane < 42) {
-        sys[lane] = -tsum;
+        val = -tsum;
         if (last && wave == 0) S->b[lane - 36] = tsum;
       } else if (wave == 0) {
         s_stat[lane - 42] = tsum;
       }
     }
+#ifdef VO_TAIL_SERIAL
+    if (lane < 42) sys[lane] = val;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const Pose Tn = picp_tail_wave(sys, T);
+#else
+    const Pose Tn = picp_tail_direct(val, T);
+#endif
     if (last && tid == 0) {
       store_pose12(S->pose[0], Tn);
       float T16[16];
@@ -625,7 +697,9 @@ template <bool PINHOLE, bool KEEP>
 __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs a) {
   __shared__ float s_red[(PICP_BATCH_BLOCK / 64) * 4 * 32];
   __shared__ float s_tot[32];
+#ifdef VO_TAIL_SERIAL
   __shared__ float s_sys[48];
+#endif
   __shared__ float s_pose[12];
   const int tid = threadIdx.x;
   const int p = blockIdx.x;
@@ -722,10 +796,16 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
     const float tot = block_reduce_acc<PICP_BATCH_BLOCK / 64>(acc, s_red);
     if (tid < 32) s_tot[tid] = tot;
     __syncthreads();
+#ifdef VO_TAIL_SERIAL
     picp_tail_expand(s_tot, s_sys, a.damping, nullptr, nullptr);
     __syncthreads();
+#endif
     if (tid < 64) {
+#ifdef VO_TAIL_SERIAL
       const Pose Tn = picp_tail_wave(s_sys, T);
+#else
+      const Pose Tn = picp_tail_direct(picp_lane_value(s_tot, a.damping, nullptr, nullptr), T);
+#endif
       if (tid == 0) {
         store_pose12(s_pose, Tn);
         if (it == a.n_iters - 1 && a.stats_out) {

@@ -506,6 +506,67 @@ VO_HD void ldlt6_solve_perm(const float* full36, const float* rhs6, float* scrat
   for (int i = 0; i < 6; ++i) x[i] = scratch6[i];
 }
 
+// ---- the factorisation without pivoting (fast mode since round 3: picp.hip, picp_tail_direct) ----------------
+// B: lower triangle of a symmetric matrix in the order it is to be eliminated (B[i][j], j <= i), y: right-hand side; on
+// return y = solution.  The arithmetic of ldlt6_solve_perm after its gather, operation for operation: with B = P A P^T
+// it is that function; the kernels call it on H itself (H is positive definite: any order is backward stable).
+// (Measured and not kept: the bare v_rcp_f32 without its two Newton FMAs -- no change of the round time.)
+VO_HD void ldlt6_solve_ordered(float B[6][6], float y[6]) {
+  float inv[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (k > 0) {
+      float tmp[6];
+#pragma unroll
+      for (int j = 0; j < k; ++j) tmp[j] = B[j][j] * B[k][j];
+      float accd = 0.f;
+#pragma unroll
+      for (int j = 0; j < k; ++j) accd = vo_fma(B[k][j], tmp[j], accd);
+      B[k][k] -= accd;
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < k; ++j) sacc = vo_fma(B[i][j], tmp[j], sacc);
+        B[i][k] -= sacc;
+      }
+    }
+    const float akk = B[k][k];
+    inv[k] = (fabsf(akk) > 1.17549435e-38f) ? vo_recip(akk) : 0.f;
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) B[i][k] *= inv[k];
+  }
+#pragma unroll
+  for (int i = 1; i < 6; ++i) {
+    float sacc = y[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) sacc = vo_fma(-B[i][j], y[j], sacc);
+    y[i] = sacc;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] *= inv[i];
+#pragma unroll
+  for (int i = 4; i >= 0; --i) {
+    float sacc = y[i];
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) sacc = vo_fma(-B[j][i], y[j], sacc);
+    y[i] = sacc;
+  }
+}
+
+// sin and cos of a small angle, |x| <= 0.5 (a Gauss-Newton step; the callers fall back to sincosf beyond): minimax
+// polynomials on the reduced range of the classic single-precision kernels (Cephes sinf / cosf), <= 1 ulp there.
+// sincosf's general path (argument reduction, quadrant logic) is a quarter of the round's tail.
+VO_HD void sincos_small(float x, float& s, float& c) {
+  const float z = x * x;
+  float ps = vo_fma(-1.9515295891e-4f, z, 8.3321608736e-3f);
+  ps = vo_fma(ps, z, -1.6666654611e-1f);
+  s = vo_fma(ps * z, x, x);
+  float pc = vo_fma(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+  pc = vo_fma(pc, z, 4.166664568298827e-2f);
+  c = vo_fma(pc * z, z, vo_fma(-0.5f, z, 1.0f));
+}
+
 // R = Rx Ry Rz written out: the 3-term products of utils.h:64-78 with the
 // structural zeros/ones of the three factors removed (x*1, x+0 and 0*x are
 // exact), so the entries round exactly like the generic product.
