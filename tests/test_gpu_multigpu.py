@@ -1,0 +1,47 @@
+"""The N-rank routes, rehearsed with one rank on the 1-GPU box: (1) the native driver apps/batch_frames_mgpu (one process,
+one vo_ctx + one host thread per device, ncclCommInitAll, one ncclAllGather of the poses per pass); (2) the route the
+scaling run takes through bench.py: `python bench.py --gpus N` starting its own ranks (torch.distributed.run, RCCL
+process group, all-gather of the poses).  N > 1 cannot run on this box -- the same code paths, one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "apps", "bin")
+
+
+def test_native_multi_gpu_driver_with_one_rank():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "apps"), "-s"])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # 24 pairs x 3000 points, 20 rounds, 2 timed passes, in calls of 10 frames (24 = 10 + 10 + 4: the per-call bookkeeping)
+    r = subprocess.run([os.path.join(BIN, "batch_frames_mgpu"), "1", "24", "3000", "20", "2", "10"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["pairs_total"] == 24 and d["bad_frames"] == 0 and d["gather_mismatches"] == 0
+    assert d["worst_pose_err"] < 2e-3 and d["frames_per_sec"] > 0
+    # more GPUs than the node has: a clean refusal, no hang
+    r = subprocess.run([os.path.join(BIN, "batch_frames_mgpu"), "64", "64", "1000"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 2 and "GPUs asked for" in r.stderr
+
+
+def test_bench_self_launch_route_with_one_rank():
+    env = dict(os.environ, VO_BENCH_FORCE_LAUNCH="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-extras", "--steps", "20", "--warmup", "3"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["value"] > 10000 and d["pose_err_vs_gt"] < 1e-3
+    # and the sharded frame legs under the same launcher (weak: 8 pairs per rank; strong: 12 pairs over the ranks)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1", "--points", "4000",
+                        "--legs", "frame", "--frame-steps", "2", "--strong-pairs", "12", "--strong-per-call", "5", "--gen-workers", "1"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ranks_seen"] == 1 and d["batched_frames"]["frames_total"] == 200
+    assert d["batched_frames_strong"]["pairs_total"] == 12 and d["batched_frames_strong"]["calls_per_pass"] == 3
