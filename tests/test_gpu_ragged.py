@@ -1,0 +1,101 @@
+"""Frames of DIFFERENT sizes in one call (vo_match_appearances_batch_dev, vo_frames_batch_ragged_dev): the reference's own
+sequence has 14..127 points per frame (vo_complete.cpp:150-157).  Every frame of a ragged batch must come out exactly as
+its own single-frame calls do -- roles (which set is the tree) included."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vo_pipeline as vp
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(os.path.dirname(__file__), "golden", "example_data", "data")
+
+
+def _frames():
+    files, K, H, cam = vp._dataset(DATA)
+    return [vp.read_meas(os.path.join(DATA, f)) for f in files], K, cam
+
+
+def test_example_data_all_120_pairs_in_one_call(vo, ctx, o32):
+    """BASELINE configs[4]'s matcher stage: the 120 consecutive frame pairs of the reference's dataset matched in ONE call;
+    pairs equal to the per-frame calls, to the oracle, and (as sets) to the landmark-id overlap the data files carry."""
+    fr, K, cam = _frames()
+    assert len(fr) == 121
+    a1 = [fr[k][1] for k in range(120)]; a2 = [fr[k + 1][1] for k in range(120)]
+    sizes = {(len(x), len(y)) for x, y in zip(a1, a2)}
+    assert len(sizes) > 60 and any(x > y for x, y in sizes) and any(x < y for x, y in sizes)      # really ragged, both roles
+    got = vo.match_batch_ragged(ctx, a1, a2)
+    assert len(got) == 120
+    for k in range(120):
+        single = vo.compute_correspondences_images(a1[k], a2[k], ctx=ctx)
+        assert np.array_equal(got[k], single), k
+        assert np.array_equal(got[k], o32.match(a1[k], a2[k])), k
+        ids = vp.id_correspondences(fr[k][2], fr[k + 1][2])
+        assert {tuple(p) for p in got[k].tolist()} == {tuple(p) for p in ids.tolist()}, k
+    # the whole loop body for the same 120 pairs in one call: match + join against a per-frame model (here: a landmark per
+    # reference point, some withheld), no round, triangulation from the identity pose -- every stage equal to its
+    # single-frame call
+    rng = np.random.default_rng(3)
+    frames = []
+    for k in range(120):
+        n_ref = len(fr[k][0])
+        keep = np.sort(rng.permutation(n_ref)[: max(1, int(0.8 * n_ref))])
+        model = rng.uniform(-1, 1, (n_ref, 3)).astype(np.float32) + np.float32([0, 0, 3])
+        frames.append(dict(ref_app=fr[k][1], cur_app=fr[k + 1][1], ref_pts=fr[k][0], cur_pts=fr[k + 1][0], model=model,
+                           model_pairs=np.stack([keep, keep], 1).astype(np.int32)))
+    res = vo.frames_batch_ragged(ctx, frames, K, cam, n_iters=0)
+    for k, (f, r) in enumerate(zip(frames, res)):
+        m = vo.compute_correspondences_images(f["ref_app"], f["cur_app"], ctx=ctx)
+        assert np.array_equal(r["matches"], m), k
+        assert np.array_equal(r["joined"], vo.extract_correspondences_world(m, f["model_pairs"], ctx=ctx)), k
+        assert np.array_equal(r["pose"], np.eye(4, dtype=np.float32)), k
+        xyz, pairs, _ = vo.triangulate_points(K, np.eye(4), m, f["ref_pts"], f["cur_pts"], ctx=ctx)
+        assert np.array_equal(r["tri_pairs"], pairs) and np.array_equal(r["tri_xyz"], xyz), k
+
+
+def test_ragged_synthetic_frames_equal_their_single_frame_calls(vo, ctx, o32):
+    """random sizes 40..1500 with drops and distractors (so that either image may be the larger set), 8 rounds of the batched
+    solver in its one-workgroup form: every frame of the ragged call == the same frame alone through vo_frames_batch_dev,
+    bit for bit; matches / joins also == the oracle"""
+    rng = np.random.default_rng(11)
+    fps = [vo.synth.frame_pair(int(n), seed=600 + i, drop=0.15, distractors=int(n) // 10, model_drop=0.1)
+           for i, n in enumerate(rng.integers(40, 1500, 14))]
+    for i, f in enumerate(fps):                       # the generator's current image is always the larger one: cut every other one short
+        if i % 2:
+            m = int(0.8 * len(f["ref_app"]))
+            f["cur_app"], f["cur_pts"] = f["cur_app"][:m].copy(), f["cur_pts"][:m].copy()
+    assert any(len(f["ref_app"]) > len(f["cur_app"]) for f in fps) and any(len(f["ref_app"]) < len(f["cur_app"]) for f in fps)
+    assert ctx.lib.vo_picp_batch_set_form(ctx.h, 2) == 0
+    try:
+        cam = (fps[0]["rows"], fps[0]["cols"], fps[0]["z_near"], fps[0]["z_far"])
+        res = vo.frames_batch_ragged(ctx, fps, fps[0]["K"], cam, n_iters=8)
+        for k, (f, r) in enumerate(zip(fps, res)):
+            m = o32.match(f["ref_app"], f["cur_app"])
+            assert np.array_equal(r["matches"], m), k
+            assert np.array_equal(r["joined"], o32.join(m, f["model_pairs"])), k
+            bp = vo.BatchPipeline(ctx, [f], n_iters=8)
+            bp.run()
+            assert np.array_equal(bp.fetch("match", 0), r["matches"]) and np.array_equal(bp.fetch("join", 0), r["joined"]), k
+            assert np.array_equal(bp.poses()[0], r["pose"]), k
+            assert np.array_equal(bp.stats()[0][:3], r["stats"][:3]), k
+            assert np.array_equal(bp.fetch("tri_pairs", 0), r["tri_pairs"]) and np.array_equal(bp.fetch("tri_xyz", 0), r["tri_xyz"]), k
+            bp.close()
+            assert np.abs(r["pose"] - f["X_gt"]).max() < 5e-2, k
+    finally:
+        assert ctx.lib.vo_picp_batch_set_form(ctx.h, 0) == 0
+
+
+def test_ragged_edge_cases(vo, ctx):
+    """empty images, one point, equal sizes (the reference image is the tree on ties), sizes array of zeros"""
+    rng = np.random.default_rng(5)
+    base = rng.uniform(-1, 1, (50, 10)).astype(np.float32)
+    a1 = [base[:0], base[:1], base[:20], base[:50], base[:7]]
+    a2 = [base[:10], base[:1], base[:20][::-1].copy(), base[:0], base[3:30]]
+    got = vo.match_batch_ragged(ctx, a1, a2)
+    for k in range(5):
+        assert np.array_equal(got[k], vo.compute_correspondences_images(a1[k], a2[k], ctx=ctx)), k
+    assert len(got[0]) == 0 and len(got[3]) == 0 and got[1].tolist() == [[0, 0]]
+    assert sorted(got[2].tolist()) == [[i, 19 - i] for i in range(20)]
+    assert vo.match_batch_ragged(ctx, [], []) == []

@@ -91,8 +91,9 @@ def main():
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         lo, hi = vdist.shard_range(F - 1, rank, world)           # item k = the pair (k, k+1)
-        mine = [torch.from_numpy(vo.compute_correspondences_images(fr[k]["app"], fr[k + 1]["app"], ctx=ctx)).to(dev)
-                for k in range(lo, hi)]
+        # this rank's block of (k, k+1) pairs in ONE call, whatever the frames' sizes (vo_match_appearances_batch_dev)
+        mine = [torch.from_numpy(m).to(dev) for m in vo.match_batch_ragged(ctx, [fr[k]["app"] for k in range(lo, hi)],
+                                                                          [fr[k + 1]["app"] for k in range(lo, hi)])]
         every = vdist.gather_ragged(mine, device=dev)
         torch.cuda.synchronize()
         t1 = time.perf_counter()

@@ -6,7 +6,7 @@ The directory name carries a hyphen, so the package is loaded through
 `__graft_entry__.load_package()` under the module name `visual_odometry_amd`.
 """
 from . import synth  # noqa: F401  (data generation only)
-from .pipeline import BatchPipeline, FramePipeline, SequencePipeline  # noqa: F401
+from .pipeline import BatchPipeline, FramePipeline, SequencePipeline, frames_batch_ragged, match_batch_ragged  # noqa: F401
 from .api import (  # noqa: F401
     Camera,
     Context,

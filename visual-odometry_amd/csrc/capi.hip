@@ -989,8 +989,43 @@ int vo_match_appearances(vo_ctx* c, const float* a1, int n1, const float* a2, in
   return VO_OK;
 }
 
+// ---- many frame pairs' appearances at once, every pair its own sizes -------------------------
+int vo_match_appearances_batch_dev(vo_ctx* c, int n_frames, const float* d_a1, int cap1, const int* d_n1, const float* d_a2,
+                                   int cap2, const int* d_n2, float radius, int32_t* d_out_pairs, int* d_n_out) {
+  VO_REQUIRE(c && d_n_out, "null argument");
+  VO_REQUIRE(n_frames >= 0 && cap1 >= 0 && cap2 >= 0, "negative count");
+  if (n_frames == 0) return VO_OK;
+  VO_REQUIRE(n_frames <= 65535, "more than 65535 frames per call (the frame is a grid dimension)");
+  VO_REQUIRE((d_n1 == nullptr) == (d_n2 == nullptr), "per-frame sizes: give both arrays or neither");
+  const int q = cap1 < cap2 ? cap1 : cap2;
+  VO_REQUIRE((cap1 == 0 || d_a1) && (cap2 == 0 || d_a2) && (q == 0 || d_out_pairs), "null device array");
+  if (int r = set_device(c)) return r;
+  VO_HIP_CHECK(c->scratch.ensure(sizeof(int) * compaction_scratch_ints(q) * (size_t)n_frames, c->stream));
+  VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)(q ? q : 1) * (size_t)n_frames, c->stream));
+  const int nt = cap1 > cap2 ? cap1 : cap2;
+  const int variant = d_n1 ? 1 : match_variant(c, nt, q, n_frames);
+  void* ws = nullptr;
+  if (q > 0) if (int r = match_workspace(c, variant, nt, q, n_frames, &ws)) return r;
+  VO_HIP_CHECK(launch_match_batch(c->stream, d_a1, cap1, 10 * (size_t)cap1, d_a2, cap2, 10 * (size_t)cap2, radius, d_out_pairs,
+                                  (size_t)q, d_n_out, c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, n_frames,
+                                  variant, d_n1, d_n2));
+  return VO_OK;
+}
+
 // ---- batched frames -----------------------------------------------------------------------
-int vo_frames_batch_dev(vo_ctx* c, const vo_frame_batch* b) {
+static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes* sz);
+
+int vo_frames_batch_dev(vo_ctx* c, const vo_frame_batch* b) { return frames_batch(c, b, nullptr); }
+
+int vo_frames_batch_ragged_dev(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes* sizes) {
+  VO_REQUIRE(sizes, "null argument");
+  VO_REQUIRE(sizes->n_ref && sizes->n_cur && sizes->n_model_pairs, "null per-frame size array");
+  return frames_batch(c, b, sizes);
+}
+
+}  // extern "C"
+
+static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes* sz) {
   VO_REQUIRE(c && b, "null argument");
   const int F = b->n_frames;
   VO_REQUIRE(F >= 0 && b->n_ref >= 0 && b->n_cur >= 0 && b->n_model >= 0 && b->n_model_pairs >= 0 && b->n_iters >= 0,
@@ -1008,7 +1043,9 @@ int vo_frames_batch_dev(vo_ctx* c, const vo_frame_batch* b) {
   VO_HIP_CHECK(c->scratch.ensure(sizeof(int) * cs * (size_t)F, c->stream));
   VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)q * (size_t)F, c->stream));
   VO_HIP_CHECK(c->table.ensure(sizeof(int) * (size_t)(b->n_ref ? b->n_ref : 1) * (size_t)F, c->stream));
-  const int variant = match_variant(c, nt, q, F);
+  // ragged frames (sz): the counts of the struct are capacities (= strides), frame f holds sz->n_ref[f] / n_cur[f] points and
+  // n_model_pairs[f] model pairs; the matcher then runs its full scan with per-frame roles (vo_complete.cpp:15-20)
+  const int variant = sz ? 1 : match_variant(c, nt, q, F);
   void* ws = nullptr;
   if (int r = match_workspace(c, variant, nt, q, F, &ws)) return r;
   int* n_match = b->counts;
@@ -1017,9 +1054,11 @@ int vo_frames_batch_dev(vo_ctx* c, const vo_frame_batch* b) {
   // compute_correspondences_images, all frames                                  vo_complete.cpp:156
   VO_HIP_CHECK(launch_match_batch(c->stream, b->ref_app, b->n_ref, 10 * (size_t)b->n_ref, b->cur_app, b->n_cur,
                                   10 * (size_t)b->n_cur, b->radius, b->matches, (size_t)q, n_match,
-                                  c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, F, variant));
+                                  c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, F, variant,
+                                  sz ? sz->n_ref : nullptr, sz ? sz->n_cur : nullptr));
   // extract_correspondences_world                                               vo_complete.cpp:157
-  VO_HIP_CHECK(launch_join_batch(c->stream, b->matches, q, n_match, b->model_pairs, b->n_model_pairs, nullptr, b->n_ref,
+  VO_HIP_CHECK(launch_join_batch(c->stream, b->matches, q, n_match, b->model_pairs, b->n_model_pairs,
+                                 sz ? sz->n_model_pairs : nullptr, b->n_ref,
                                  b->joined, n_join, c->table.as<int>(), c->scratch.as<int>(), F, (size_t)q,
                                  (size_t)b->n_model_pairs, (size_t)q));
   // X_curr * triangulated_pc                                                    vo_complete.cpp:159
@@ -1036,6 +1075,8 @@ int vo_frames_batch_dev(vo_ctx* c, const vo_frame_batch* b) {
                                         (size_t)b->n_cur, (size_t)q));
   return VO_OK;
 }
+
+extern "C" {
 
 // ---- join ---------------------------------------------------------------------------------
 int vo_join_correspondences_dev(vo_ctx* c, const int32_t* d_img, int n_img, const int* d_n_img,

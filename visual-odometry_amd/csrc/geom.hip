@@ -527,13 +527,28 @@ struct MatchOutArgs {
   int32_t* out;
   int* counts;
   size_t best_stride, out_stride, counts_stride;   // per frame (blockIdx.y)
+  const int* d_n1; const int* d_n2;                // ragged frames: per-frame set sizes (null: nq / tree_is_1 for all)
 };
+
+// the frame's query count and roles: the larger set is the tree, a1 on ties (vo_complete.cpp:15-20)
+__device__ __forceinline__ void match_out_frame(const MatchOutArgs& a, int& nq, int& tree_is_1) {
+  nq = a.nq; tree_is_1 = a.tree_is_1;
+  if (a.d_n1) {
+    int n1 = a.d_n1[blockIdx.y], n2 = a.d_n2[blockIdx.y];
+    n1 = n1 < 0 ? 0 : n1; n2 = n2 < 0 ? 0 : n2;
+    tree_is_1 = n1 >= n2;
+    const int q = tree_is_1 ? n2 : n1;
+    nq = q < a.nq ? q : a.nq;
+  }
+}
 
 __global__ __launch_bounds__(CB) void match_count_kernel(MatchOutArgs a) {
   __shared__ int s_wave[CB / 64];
   const unsigned long long* best = a.best + blockIdx.y * a.best_stride;
   const int q = blockIdx.x * CB + threadIdx.x;
-  const bool ok = q < a.nq && (unsigned)(best[q] & 0xffffffffull) != 0xffffffffu;
+  int nq, tree_is_1;
+  match_out_frame(a, nq, tree_is_1);
+  const bool ok = q < nq && (unsigned)(best[q] & 0xffffffffull) != 0xffffffffu;
   int total;
   block_rank(ok, s_wave, total);
   if (threadIdx.x == 0) a.counts[blockIdx.y * a.counts_stride + blockIdx.x] = total;
@@ -544,24 +559,26 @@ __global__ __launch_bounds__(CB) void match_scatter_kernel(MatchOutArgs a) {
   const unsigned long long* best = a.best + blockIdx.y * a.best_stride;
   int32_t* out = a.out + 2 * blockIdx.y * a.out_stride;
   const int q = blockIdx.x * CB + threadIdx.x;
+  int nq, tree_is_1;
+  match_out_frame(a, nq, tree_is_1);
   unsigned idx = 0xffffffffu;
-  if (q < a.nq) idx = (unsigned)(best[q] & 0xffffffffull);
+  if (q < nq) idx = (unsigned)(best[q] & 0xffffffffull);
   const bool ok = idx != 0xffffffffu;
   int total;
   const int r = block_rank(ok, s_wave, total);
   if (ok) {
     const size_t dst = (size_t)a.counts[blockIdx.y * a.counts_stride + blockIdx.x] + r;
-    out[2 * dst] = a.tree_is_1 ? (int)idx : q;
-    out[2 * dst + 1] = a.tree_is_1 ? q : (int)idx;
+    out[2 * dst] = tree_is_1 ? (int)idx : q;
+    out[2 * dst + 1] = tree_is_1 ? q : (int)idx;
   }
 }
 
 hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best, int nq, int tree_is_1,
                                 int32_t* d_out, int* d_n_out, int* d_scratch, int n_frames, size_t best_stride,
-                                size_t out_stride) {
+                                size_t out_stride, const int* d_n1, const int* d_n2) {
   const int nb = (nq + CB - 1) / CB;
   const size_t cs = n_frames > 1 ? compaction_scratch_ints(nq) : 0;
-  MatchOutArgs a{d_best, nq, tree_is_1, d_out, d_scratch, best_stride, n_frames > 1 ? out_stride : 0, cs};
+  MatchOutArgs a{d_best, nq, tree_is_1, d_out, d_scratch, best_stride, n_frames > 1 ? out_stride : 0, cs, d_n1, d_n2};
   if (nb > 0) hipLaunchKernelGGL(match_count_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);
   hipError_t e = launch_scan(st, d_scratch, nb, d_n_out, nullptr, n_frames, cs);
   if (e != hipSuccess) return e;

@@ -33,7 +33,7 @@ namespace vo {
 
 hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best, int nq, int tree_is_1,
                                 int32_t* d_out, int* d_n_out, int* d_scratch, int n_frames, size_t best_stride,
-                                size_t out_stride);
+                                size_t out_stride, const int* d_n1, const int* d_n2);
 
 constexpr int MB = 256;       // threads per workgroup
 constexpr int QPT = 2;        // queries per thread (full scan)
@@ -55,12 +55,24 @@ __global__ __launch_bounds__(256) void match_init_kernel(unsigned long long* bes
   if (q < nq) best[q] = ((unsigned long long)__float_as_uint(r2) << 32) | 0xffffffffull;
 }
 
+// RAGGED: frame z has its own set sizes d_n1[z] <= n1, d_n2[z] <= n2 (the arguments are then the capacities, i.e. the
+// strides) and its own roles -- the larger set is the tree, a1 on ties (vo_complete.cpp:15-20) -- so `tree` / `qry` arrive
+// as (a1, a2) and are told apart here.
+template <bool RAGGED>
 __global__ __launch_bounds__(MB) void match_kernel(const float* __restrict__ tree, int nt,
                                                    const float* __restrict__ qry, int nq,
                                                    int chunk, float r2,
                                                    unsigned long long* __restrict__ best, size_t tree_stride,
-                                                   size_t qry_stride, size_t best_stride) {
+                                                   size_t qry_stride, size_t best_stride,
+                                                   const int* __restrict__ d_n1, const int* __restrict__ d_n2) {
   tree += blockIdx.z * tree_stride; qry += blockIdx.z * qry_stride; best += blockIdx.z * best_stride;
+  if (RAGGED) {
+    int n1 = d_n1[blockIdx.z], n2 = d_n2[blockIdx.z];
+    n1 = n1 < 0 ? 0 : (n1 > nt ? nt : n1); n2 = n2 < 0 ? 0 : (n2 > nq ? nq : n2);
+    if (n1 >= n2) { nt = n1; nq = n2; }
+    else { const float* t = tree; tree = qry; qry = t; nt = n2; nq = n1; }
+    if ((int)(blockIdx.x * MB * QPT) >= nq || (int)(blockIdx.y * chunk) >= nt) return;     // (uniform: before any barrier)
+  }
   __shared__ __attribute__((aligned(16))) float s_t[TILE * TP];
   const int tid = threadIdx.x;
   const int q0 = (blockIdx.x * MB + tid) * QPT;
@@ -1467,7 +1479,29 @@ hipError_t launch_radius_search(hipStream_t st, const float* d_tree, int nt, con
 hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t a1_stride, const float* d_a2, int n2,
                               size_t a2_stride, float radius, int32_t* d_out_pairs, size_t out_stride, int* d_n_out,
                               unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws, int n_frames,
-                              int variant) {
+                              int variant, const int* d_n1, const int* d_n2) {
+  if (d_n1 && d_n2) {
+    // ragged frames: every frame its own sizes and roles; full scan (the sorted searches lay their workspaces out for one
+    // size).  q = min(n1, n2) is the room per frame in d_best / d_out_pairs.
+    const int q = n1 < n2 ? n1 : n2;
+    const float r2 = radius * radius;
+    if (q > 0) {
+      hipLaunchKernelGGL(match_init_kernel, dim3((q + 255) / 256, 1, (unsigned)n_frames), dim3(256), 0, st, d_best, q, r2, (size_t)q);
+      const int big = n1 > n2 ? n1 : n2;
+      const int qblocks = (q + MB * QPT - 1) / (MB * QPT);      // either set may be the queries, but never more than q of them
+      int want = (8 * (n_cu > 0 ? n_cu : 256) + qblocks * n_frames - 1) / (qblocks * n_frames);
+      const int tiles = (big + TILE - 1) / TILE;
+      if (want > tiles) want = tiles;
+      if (want < 1) want = 1;
+      const int chunk = ((tiles + want - 1) / want) * TILE;
+      const int nchunks = (big + chunk - 1) / chunk;
+      hipLaunchKernelGGL(match_kernel<true>, dim3(qblocks, nchunks, (unsigned)n_frames), dim3(MB), 0, st, d_a1, n1, d_a2, n2, chunk, r2,
+                         d_best, a1_stride, a2_stride, (size_t)q, d_n1, d_n2);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_match_compact(st, d_best, q, 1, d_out_pairs, d_n_out, d_scratch, n_frames, (size_t)q, out_stride, d_n1, d_n2);
+  }
   const int tree_is_1 = n1 >= n2;                 // vo_complete.cpp:15-20 (ties: a1 is the tree)
   const float* tree = tree_is_1 ? d_a1 : d_a2;
   const float* qry = tree_is_1 ? d_a2 : d_a1;
@@ -1496,21 +1530,21 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
       const int tiles_per_chunk = (tiles + want - 1) / want;
       const int chunk = tiles_per_chunk * TILE;
       const int nchunks = (nt + chunk - 1) / chunk;
-      hipLaunchKernelGGL(match_kernel, dim3(qblocks, nchunks, Z), dim3(MB), 0, st, tree, nt, qry, nq, chunk, r2, d_best,
-                         n_frames > 1 ? ts : 0, n_frames > 1 ? qs : 0, best_stride);
+      hipLaunchKernelGGL(match_kernel<false>, dim3(qblocks, nchunks, Z), dim3(MB), 0, st, tree, nt, qry, nq, chunk, r2, d_best,
+                         n_frames > 1 ? ts : 0, n_frames > 1 ? qs : 0, best_stride, nullptr, nullptr);
     }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_match_compact(st, d_best, nq, tree_is_1, d_out_pairs, d_n_out, d_scratch, n_frames, best_stride,
-                              out_stride);
+                              out_stride, nullptr, nullptr);
 }
 
 hipError_t launch_match(hipStream_t st, const float* d_a1, int n1, const float* d_a2, int n2,
                         float radius, int32_t* d_out_pairs, int* d_n_out,
                         unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws, int variant) {
   return launch_match_batch(st, d_a1, n1, 0, d_a2, n2, 0, radius, d_out_pairs, 0, d_n_out, d_best, d_scratch, n_cu,
-                            d_prune_ws, 1, variant);
+                            d_prune_ws, 1, variant, nullptr, nullptr);
 }
 
 }  // namespace vo

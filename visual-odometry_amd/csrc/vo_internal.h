@@ -165,10 +165,12 @@ inline size_t match_workspace_bytes(int variant, int nt, int nq, int n_frames) {
 }
 // n_frames frames of identical set sizes, frame f at base + f*stride (strides in floats / pairs);
 // d_best: n_frames*min(n1,n2) keys; d_scratch: n_frames * compaction_scratch_ints(min(n1,n2)) ints; d_n_out[n_frames]
+// d_n1 / d_n2 (both or neither): ragged frames -- frame f holds d_n1[f] <= n1 and d_n2[f] <= n2 points (n1, n2 are then the
+// capacities, the strides must be >= them) and picks its own tree (its larger set); always the full scan
 hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t a1_stride, const float* d_a2, int n2,
                               size_t a2_stride, float radius, int32_t* d_out_pairs, size_t out_stride, int* d_n_out,
                               unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws, int n_frames,
-                              int variant);
+                              int variant, const int* d_n1 = nullptr, const int* d_n2 = nullptr);
 hipError_t launch_transform_batch(hipStream_t st, const float* d_T16, const float* d_in, int n, size_t stride,
                                   float* d_out, int n_frames);
 hipError_t launch_triangulate_batch(hipStream_t st, const float K[9], const Pose* X_host, const float* d_X16,

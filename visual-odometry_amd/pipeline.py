@@ -263,6 +263,88 @@ class BatchPipeline:
             self.ctx.free(d)
 
 
+class _FrameSizes(C.Structure):
+    """vo_frame_sizes of include/vo_hip.h"""
+    _fields_ = [("n_ref", C.c_void_p), ("n_cur", C.c_void_p), ("n_model_pairs", C.c_void_p)]
+
+
+def _pad_stack(arrs, cap, width, dtype):
+    out = np.zeros((len(arrs), max(cap, 1), width), dtype)
+    for i, a in enumerate(arrs):
+        a = np.asarray(a, dtype).reshape(-1, width)
+        out[i, : len(a)] = a
+    return out
+
+
+def match_batch_ragged(ctx: Context, apps1, apps2, radius: float = 0.1):
+    """compute_correspondences_images (vo_complete.cpp:12-49) for many pairs of appearance sets of DIFFERENT sizes in one call
+    (vo_match_appearances_batch_dev): returns the list of (n_i, 2) int32 pair arrays.  The up-front matching of a sequence."""
+    F = len(apps1)
+    assert F == len(apps2)
+    if F == 0:
+        return []
+    n1 = np.array([len(a) for a in apps1], np.int32); n2 = np.array([len(a) for a in apps2], np.int32)
+    cap1, cap2 = int(max(n1.max(), 1)), int(max(n2.max(), 1))
+    q = min(cap1, cap2)
+    d_a1, d_a2 = ctx.to_device(_pad_stack(apps1, cap1, 10, np.float32)), ctx.to_device(_pad_stack(apps2, cap2, 10, np.float32))
+    d_n1, d_n2 = ctx.to_device(n1), ctx.to_device(n2)
+    d_out, d_cnt = ctx.alloc(F * q * 8), ctx.alloc(F * 4)
+    try:
+        _chk(ctx.lib.vo_match_appearances_batch_dev(ctx.h, C.c_int(F), C.c_void_p(d_a1), C.c_int(cap1), C.c_void_p(d_n1),
+                                                    C.c_void_p(d_a2), C.c_int(cap2), C.c_void_p(d_n2), C.c_float(radius),
+                                                    C.c_void_p(d_out), C.c_void_p(d_cnt)))
+        cnt = np.zeros(F, np.int32); ctx.d2h(cnt, d_cnt)
+        out = np.zeros((F, q, 2), np.int32); ctx.d2h(out, d_out)
+    finally:
+        for d in (d_a1, d_a2, d_n1, d_n2, d_out, d_cnt):
+            ctx.free(d)
+    return [out[f, : cnt[f]].copy() for f in range(F)]
+
+
+def frames_batch_ragged(ctx: Context, frames, K, cam, n_iters: int = 50, kernel_threshold: float = 10000.0, radius: float = 0.1,
+                        keep_outliers: bool = False, X_prev=None):
+    """The loop body of vo_complete.cpp:150-179 for many frames of DIFFERENT sizes in ONE call (vo_frames_batch_ragged_dev).
+    frames: dicts with ref_app, cur_app, ref_pts, cur_pts, model, model_pairs; cam = (rows, cols, z_near, z_far).
+    Returns per frame a dict(matches, joined, pose, stats, tri_xyz, tri_pairs)."""
+    F = len(frames)
+    keys = (("ref_app", np.float32, 10), ("cur_app", np.float32, 10), ("ref_pts", np.float32, 2), ("cur_pts", np.float32, 2),
+            ("model", np.float32, 3), ("model_pairs", np.int32, 2))
+    n = {k: np.array([len(np.asarray(f[k]).reshape(-1, w)) for f in frames], np.int32) for k, _, w in keys}
+    assert np.array_equal(n["ref_app"], n["ref_pts"]) and np.array_equal(n["cur_app"], n["cur_pts"])
+    cap = {k: int(max(v.max(), 1)) for k, v in n.items()}
+    q = min(cap["ref_app"], cap["cur_app"])
+    dev = {k: ctx.to_device(_pad_stack([f[k] for f in frames], cap[k], w, dt)) for k, dt, w in keys}
+    d_n = {k: ctx.to_device(n[k]) for k in ("ref_app", "cur_app", "model_pairs")}
+    a = ctx.alloc
+    out = dict(matches=a(F * q * 8), joined=a(F * q * 8), moved=a(F * cap["model"] * 12), poses=a(F * 64), stats=a(F * 16),
+               tri_xyz=a(F * q * 12), tri_pairs=a(F * q * 8), counts=a(3 * F * 4))
+    d_X = ctx.to_device(np.ascontiguousarray(np.stack([_colmajor(X, 4) for X in X_prev]))) if X_prev is not None else None
+    b = _FrameBatch()
+    b.n_frames, b.n_ref, b.n_cur, b.n_model, b.n_model_pairs = F, cap["ref_app"], cap["cur_app"], cap["model"], cap["model_pairs"]
+    b.ref_app, b.cur_app, b.ref_pts, b.cur_pts = dev["ref_app"], dev["cur_app"], dev["ref_pts"], dev["cur_pts"]
+    b.model, b.model_pairs, b.X_prev = dev["model"], dev["model_pairs"], d_X
+    b.rows, b.cols, b.z_near, b.z_far = (int(x) for x in cam)
+    b.K[:] = _colmajor(K, 3).tolist()
+    b.kernel_threshold, b.keep_outliers, b.n_iters, b.radius = kernel_threshold, int(keep_outliers), n_iters, radius
+    b.matches, b.joined, b.model_moved, b.poses, b.stats = out["matches"], out["joined"], out["moved"], out["poses"], out["stats"]
+    b.tri_xyz, b.tri_pairs, b.tri_app, b.counts = out["tri_xyz"], out["tri_pairs"], None, out["counts"]
+    sz = _FrameSizes(d_n["ref_app"], d_n["cur_app"], d_n["model_pairs"])
+    try:
+        _chk(ctx.lib.vo_frames_batch_ragged_dev(ctx.h, C.byref(b), C.byref(sz)))
+        cnt = np.zeros((3, F), np.int32); ctx.d2h(cnt, out["counts"])
+        m = np.zeros((F, q, 2), np.int32); ctx.d2h(m, out["matches"])
+        j = np.zeros((F, q, 2), np.int32); ctx.d2h(j, out["joined"])
+        T = np.zeros((F, 16), np.float32); ctx.d2h(T, out["poses"])
+        st = np.zeros((F, 4), np.float32); ctx.d2h(st, out["stats"])
+        xyz = np.zeros((F, q, 3), np.float32); ctx.d2h(xyz, out["tri_xyz"])
+        tp = np.zeros((F, q, 2), np.int32); ctx.d2h(tp, out["tri_pairs"])
+    finally:
+        for d in list(dev.values()) + list(d_n.values()) + list(out.values()) + ([d_X] if d_X else []):
+            ctx.free(d)
+    return [dict(matches=m[f, : cnt[0, f]].copy(), joined=j[f, : cnt[1, f]].copy(), pose=T[f].reshape(4, 4).T.copy(), stats=st[f].copy(),
+                 tri_xyz=xyz[f, : cnt[2, f]].copy(), tri_pairs=tp[f, : cnt[2, f]].copy()) for f in range(F)]
+
+
 class SequencePipeline:
     """A whole sequence in the manner of vo_complete.cpp:97-181 with everything resident in HBM
     (SURVEY 8(d) config 3): all measurement files are uploaded up front; the first pair is matched,
