@@ -259,6 +259,45 @@ def _pmc_traffic(kernel, grid_threads):
                "FETCH_SIZE + WRITE_SIZE as reported (4-B/lane loads: uncalibrated width)") + ", from " + os.path.basename(path)
 
 
+FP32_VECTOR_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 (vector)
+
+
+def _pmc_valu(kernels, pick=max):
+    """executed VALU wave-instructions per launch (SQ_INSTS_VALU) of the named kernels from the committed counter summary
+    (profiles/rNN_pmc_valu.json: one rocprofv3 --pmc pass of this script, tools/collect_profiles.sh), summed; for a kernel
+    that ran at several launch geometries `pick` (max / min) chooses the largest / smallest grid -- the 200-frame call /
+    the single frame.  (None, None, reason) when missing."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_valu.json")))
+    if not files:
+        return None, None, "no committed VALU counter summary"
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+        total, util_w = 0.0, 0.0
+        for k in kernels:
+            g = ks[k]["by_grid"]
+            e = g[pick(g, key=lambda x: int(x))]
+            total += e["valu_insts_per_launch"]
+            util_w += e["valu_insts_per_launch"] * e["lane_utilisation"]
+        return total, util_w / max(total, 1.0), "SQ_INSTS_VALU from " + os.path.basename(files[-1])
+    except (OSError, KeyError, ValueError, TypeError) as e:
+        return None, None, f"counter summary lacks {e!r}"
+
+
+def _valu_roofline(kernels, seconds, scope, pick=max):
+    """the matcher is FP32-VALU-bound -- executed VALU wave-instructions x 64 lanes x 2 flop (each counted as
+    an FMA) over the live-measured time, against the FP32 vector peak"""
+    insts, util, note = _pmc_valu(kernels, pick)
+    if insts is None:
+        return {"bound": "valu", "achieved": None, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "note": note}
+    tf = insts * 128.0 / seconds / 1e12
+    return {"bound": "valu", "scope": scope, "kernels": list(kernels), "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / FP32_VECTOR_PEAK_TFLOPS, "valu_wave_instructions": insts, "lane_utilisation": util,
+            "note": "achieved = executed VALU wave-instructions (" + note + ") x 64 lanes x 2 flop / live time of the stage: the share "
+                    "of the FP32 vector issue rate the instruction stream occupies (an instruction is counted as an FMA with all "
+                    "lanes active; lane_utilisation says how many are)"}
+
+
 def _pmc_frames_call():
     """HBM bytes of one whole vo_frames_batch_dev call (200 x 50k), summed over its kernels, from the same summary"""
     try:
@@ -367,12 +406,27 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
         assert torch.equal(all_poses[rank * frames:(rank + 1) * frames], poses_t)
     ms = sec * 1e3
     err = _check_batches(bp, args.points)
+    # the matcher chain of the same frames alone (vo_match_appearances_batch_dev: bounds, level 1, offsets, level 2, search, compaction)
+    bp.match_only(); ctx.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(3):
+        bp.match_only()
+    e1.record(stream)
+    ctx.synchronize()
+    match_ms = e0.elapsed_time(e1) / 3
+    assert int(bp.counts()[0].min()) == args.points
     bp.close()
     alg = _frame_alg_bytes(args.points, args.iters) * frames
     gbs = alg / sec / 1e9
     return {"frames_per_gpu": frames, "n_gpus": world, "frames_total": frames * world, "ms_per_batch": ms, "scaling": "weak",
             "frames_per_sec": frames * world / (ms * 1e-3), "us_per_frame_per_gpu": ms * 1e3 / frames, "pose_err_vs_gt": err,
             "seeds": f"4000+p, p = {frames * rank}..{frames * rank + frames - 1} on this rank",
+            "matcher_ms_per_batch": match_ms,
+            "matcher_roofline": _valu_roofline(("vo::cell_bounds_kernel", "vo::cell_place_kernel", "vo::cell_offsets_kernel", "vo::cell_fine_kernel",
+                                                "vo::cell_search_kernel<0>", "vo::match_count_kernel", "vo::match_scatter_kernel"),
+                                               match_ms * 1e-3, f"matcher chain of {frames} frames (cell-hash search), one call")
+            if (frames, args.points) == (200, 50000) else None,
             "roofline": {"bound": "hbm", "scope": "whole frame (all stages of one vo_frames_batch_dev call)", "achieved": gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": _pmc_frames_call()[0] if (frames, args.points, args.iters) == (200, 50000, 50) else None,
@@ -487,8 +541,15 @@ def frame_leg(torch, ctx, stream, pipe, fp, args, vo_mod=None):
     c = pipe.counts().tolist()
     n1, n2 = pipe.n_ref, pipe.n_cur
     match_flops = 30.0 * n1 * n2                     # 30 flop per (tree, query) pair
+    roofs = {}
+    if (n1, n2) == (50000, 50000):
+        roofs = {"match_full_scan_roofline": _valu_roofline(("vo::match_init_kernel", "vo::match_kernel", "vo::match_count_kernel", "vo::match_scatter_kernel"),
+                                                            stages["match_full_scan_ms"] * 1e-3, "one frame, every (query, tree point) pair visited", min),
+                 "match_roofline": _valu_roofline(("vo::match_minmax_kernel", "vo::match_bucket_hist_kernel", "vo::match_bucket_offsets_kernel",
+                                                   "vo::match_bucket_place_kernel", "vo::match_pruned_kernel", "vo::match_count_kernel",
+                                                   "vo::match_scatter_kernel"), stages["match_ms"] * 1e-3, "one frame, bucket-pruned scan (default)", min)}
     return {"frames_per_sec": args.frame_steps / dt, "ms_per_frame": dt * 1e3 / args.frame_steps, 
-            "counts": {"matches": c[0], "joined": c[1], "triangulated": c[2]}, **stages,
+            "counts": {"matches": c[0], "joined": c[1], "triangulated": c[2]}, **stages, **roofs,
             "match_full_scan_equiv_tflops": match_flops / (stages["match_full_scan_ms"] * 1e-3) / 1e12,
             "match_note": "match_ms: default (bucket-pruned exact scan); match_full_scan_ms: every pair visited, "
                           "bit-exact 3-term early exit; equiv_tflops = 30*N1*N2 flop / time (brute-force-equivalent "

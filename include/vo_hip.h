@@ -338,7 +338,8 @@ typedef struct vo_frame_batch {
   /* outputs; q = min(n_ref, n_cur) items of room per frame */
   int32_t *matches;                 /* [n_frames][q][2]  (ref index, cur index) */
   int32_t *joined;                  /* [n_frames][q][2]  (cur index, model index) */
-  float *model_moved;               /* [n_frames][n_model][3]  X_prev * model (also the solver's world points) */
+  float *model_moved;               /* [n_frames][n_model][3]  X_prev * model, or NULL: the moved cloud is not wanted -- the solver
+                                     * then moves the points it gathers itself (same arithmetic, one pass and 12 B per model point less) */
   float *poses;                     /* [n_frames][16] */
   float *stats;                     /* [n_frames][4]: chi_inliers, chi_outliers, num_inliers, bad-index pairs dropped (may be NULL) */
   float *tri_xyz;                   /* [n_frames][q][3] */

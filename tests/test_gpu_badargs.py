@@ -135,7 +135,7 @@ def test_misuse_of_capture_allocation_and_batches(vo, o32):
     b = bp.b
     for field, bad in (("n_frames", -1), ("n_ref", -1), ("n_cur", -5), ("n_model", -1), ("n_model_pairs", -2), ("n_iters", -1),
                        ("ref_app", None), ("cur_pts", None), ("model", None), ("model_pairs", None), ("matches", None), ("joined", None),
-                       ("model_moved", None), ("poses", None), ("tri_xyz", None), ("tri_pairs", None), ("counts", None)):
+                       ("poses", None), ("tri_xyz", None), ("tri_pairs", None), ("counts", None)):
         keep = getattr(b, field)
         setattr(b, field, bad)
         rc = lib.vo_frames_batch_dev(h, C.byref(b))

@@ -186,6 +186,39 @@ def test_batched_frames_equal_single_frames(vo, o32, n, F):
     bp.close(); c.close()
 
 
+def test_moved_cloud_is_an_optional_output(vo, ctx, o32):
+    """vo_frame_batch.model_moved == NULL: the solver's gather applies X_prev itself (PointCloud.h:80, the transform kernel's
+    arithmetic) -- every result bit for bit what the call with the moved cloud gives, and the moved cloud, where asked
+    for, is X_prev * model"""
+    fps = [vo.synth.frame_pair(1500, seed=9100 + k) for k in range(9)]
+    rng = np.random.default_rng(4)
+    Xs, moved = [], []
+    for f in fps:                                   # model given in another frame: model = X^-1 * (model), X_prev = X
+        ang = rng.uniform(-0.3, 0.3, 3); t = rng.uniform(-0.5, 0.5, 3)
+        X = np.eye(4, dtype=np.float32)
+        X[:3, :3] = o32.v2t_euler(np.concatenate([np.zeros(3), ang]).astype(np.float32))[:3, :3]
+        X[:3, 3] = t
+        Xi = np.linalg.inv(X.astype(np.float64)).astype(np.float32)
+        f["model"] = o32.transform_points(Xi, f["model"])
+        Xs.append(X); moved.append(o32.transform_points(X, f["model"]))
+    res = {}
+    for with_moved in (True, False):
+        bp = vo.BatchPipeline(ctx, fps, n_iters=12, with_moved=with_moved, X_prev=Xs)
+        bp.run()
+        res[with_moved] = (bp.poses().copy(), bp.stats().copy(), bp.counts().copy(), [bp.fetch("tri_xyz", f) for f in range(len(fps))])
+        if with_moved:
+            got = np.zeros((len(fps), len(fps[0]["model"]), 3), np.float32)
+            ctx.d2h(got, bp.d_moved)
+            for f in range(len(fps)):
+                assert np.array_equal(got[f], moved[f]), f
+        bp.close()
+    a, b = res[True], res[False]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+    for f, T in enumerate(a[0]):
+        assert np.abs(T - fps[f]["X_gt"]).max() < 5e-3, f      # (the moved model is the model the pair was generated with, to rounding)
+
+
 def test_device_pose_reset_and_in_place_pose(vo, ctx, o32):
     """vo_picp_set_pose_dev takes effect at the next solve (folded into the gather launch, or a launch of
     its own when the correspondences are cached); vo_picp_pose_dev_ptr exposes the result in place."""

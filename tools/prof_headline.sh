@@ -10,6 +10,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-extras --steps $STEPS > $OUT/line.json 2> $OUT/stderr.log
+python3 $R/bench.py --no-extras --steps $STEPS > $OUT/line_untraced.json 2>> $OUT/stderr.log     # the same command without the tracer
 cd $R
 python3 - <<PY | tee $OUT/check.txt
 import csv, glob, json
@@ -23,5 +24,9 @@ avg_us = float(k["AverageNs"]) / 1e3
 it = line["config"]["iters_per_step"]
 print("round kernel average %.3f us x %d = %.1f us ; ms_per_step (same run) %.1f us ; roofline.launch_us %.3f (%.1f %% off the trace average)"
       % (avg_us, it, avg_us * it, line["ms_per_step"] * 1e3, line["roofline"]["launch_us"], 100 * (line["roofline"]["launch_us"] / avg_us - 1)))
-print("value %.0f iter/s" % line["value"])
+print("value under the tracer %.0f iter/s" % line["value"])
+un = json.loads([l for l in open("$OUT/line_untraced.json") if l.startswith("{")][-1])
+print("untraced run of the same command: value %.0f iter/s, ms_per_step %.1f us, roofline.launch_us %.3f (%.1f %% off the trace average of the kernel)"
+      % (un["value"], un["ms_per_step"] * 1e3, un["roofline"]["launch_us"], 100 * (un["roofline"]["launch_us"] / avg_us - 1)))
+print("(the tracer adds ~2.5 us of host/dispatch overhead per launch to the step: event times of a traced run are not kernel times)")
 PY

@@ -55,6 +55,37 @@ json.dump({"batched_frames_call": call, "command": "rocprofv3 --kernel-trace --p
                     "coalesced streaming reads (MI355X_MICROARCH.md, HBM) -> doubled where wide_16B_loads is true; other "
                     "access widths are uncalibrated and reported as counted",
            "kernels": out}, open(dst + "_pmc_fetch_write.json", "w"), indent=1, sort_keys=True)
+# executed VALU instructions per launch (third pass of tools/collect_profiles.sh): the matcher kernels are VALU-bound by design
+vf = glob.glob(f"{src}/VALU/*/*counter_collection.csv")
+if vf:
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(vf[0])):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if not name.startswith("vo::"):
+            continue
+        key = (name, int(r["Grid_Size"]))
+        agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r["Counter_Name"] == "SQ_WAVES":
+            agg[key]["dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    valu = {}
+    for (k, grid), c in agg.items():
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        valu.setdefault(k, {"by_grid": {}})["by_grid"][str(grid)] = {
+            "valu_insts_per_launch": m.get("SQ_INSTS_VALU", 0.0), "waves": m.get("SQ_WAVES", 0.0),
+            "lane_utilisation": m.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(1.0, 64.0 * m.get("SQ_ACTIVE_INST_VALU", 0.0)),
+            "dur_us_under_pmc": m.get("dur_ns", 0.0) / 1e3, "launches": len(c.get("SQ_WAVES", []))}
+        d = valu[k]["by_grid"][str(grid)]
+        # wave-instructions x 64 lanes x 2 flop (every instruction counted as an FMA) per second against 157.3 TFLOP/s
+        d["valu_tflops_equiv_under_pmc"] = d["valu_insts_per_launch"] * 128.0 / max(d["dur_us_under_pmc"], 1e-9) / 1e6
+        d["valu_frac_of_fp32_peak_under_pmc"] = d["valu_tflops_equiv_under_pmc"] / 157.3
+    json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES "
+                          "--output-format csv -- python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 --frame-steps 3 --seq-frames 6 "
+                          "--seq-points 5000 --strong-pairs 0 --gen-workers 1   (tools/collect_profiles.sh, third pass)",
+               "units": "valu_insts_per_launch = SQ_INSTS_VALU (wave-instructions, summed over all waves of a launch); "
+                        "tflops_equiv = insts x 64 lanes x 2 flop / kernel time: what the kernel would deliver if every VALU "
+                        "instruction were an FMA with all lanes active -- the share of the FP32 vector peak (157.3 TFLOP/s, "
+                        "MI355X_MICROARCH.md) its instruction stream occupies",
+               "kernels": valu}, open(dst + "_pmc_valu.json", "w"), indent=1, sort_keys=True)
 shutil.copy(glob.glob(f"{src}/stats/*/*kernel_stats.csv")[0], dst + "_bench_kernel_stats.csv")
 for k in ("vo::picp_batch_kernel<true, false>", "vo::picp_round_kernel<true, false, true, false>"):
     if k in out:

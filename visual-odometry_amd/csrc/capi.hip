@@ -848,11 +848,27 @@ int vo_picp_batch_set_form(vo_ctx* c, int form) {
   return VO_OK;
 }
 
+static int picp_solve_batch(vo_ctx* c, int n_problems, int rows, int cols, int z_near, int z_far,
+                            const float K[9], float thr, int keep_outliers, const float* d_world,
+                            size_t world_stride, const float* d_meas, size_t meas_stride,
+                            const int32_t* d_pairs, size_t pairs_stride, const int* d_n_pairs,
+                            const float* d_T0, int n_iters, float* d_T_out, float* d_stats_out, const float* d_X_world);
+
 int vo_picp_solve_batch_dev(vo_ctx* c, int n_problems, int rows, int cols, int z_near, int z_far,
                             const float K[9], float thr, int keep_outliers, const float* d_world,
                             size_t world_stride, const float* d_meas, size_t meas_stride,
                             const int32_t* d_pairs, size_t pairs_stride, const int* d_n_pairs,
                             const float* d_T0, int n_iters, float* d_T_out, float* d_stats_out) {
+  return picp_solve_batch(c, n_problems, rows, cols, z_near, z_far, K, thr, keep_outliers, d_world, world_stride, d_meas, meas_stride,
+                          d_pairs, pairs_stride, d_n_pairs, d_T0, n_iters, d_T_out, d_stats_out, nullptr);
+}
+
+// d_X_world (n_problems x 16, or null): rigid transform applied to every world point the gather fetches
+static int picp_solve_batch(vo_ctx* c, int n_problems, int rows, int cols, int z_near, int z_far,
+                            const float K[9], float thr, int keep_outliers, const float* d_world,
+                            size_t world_stride, const float* d_meas, size_t meas_stride,
+                            const int32_t* d_pairs, size_t pairs_stride, const int* d_n_pairs,
+                            const float* d_T0, int n_iters, float* d_T_out, float* d_stats_out, const float* d_X_world) {
   VO_REQUIRE(c && K, "null argument");
   VO_REQUIRE(n_problems >= 0 && n_iters >= 0, "negative count");
   VO_REQUIRE(n_problems <= 65535, "more than 65535 problems per call (the problem is a grid dimension)");
@@ -880,6 +896,7 @@ int vo_picp_solve_batch_dev(vo_ctx* c, int n_problems, int rows, int cols, int z
     a.n_bad = c->batch_bad.as<int>();
   }
   a.states = nullptr; a.partials = nullptr; a.params = nullptr; a.grid = 0; a.exact = 0;
+  a.X_world = d_X_world;
   static const int env_form = [] { const char* e = getenv("VO_PICP_BATCH_FORM"); return e ? atoi(e) : 0; }();
   const int form = c->batch_form ? c->batch_form : env_form;
   a.exact = form == 3;
@@ -1035,14 +1052,13 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
   const int q = b->n_ref < b->n_cur ? b->n_ref : b->n_cur;
   VO_REQUIRE(q > 0 && b->n_model > 0, "empty frames");
   VO_REQUIRE(b->ref_app && b->cur_app && b->ref_pts && b->cur_pts && b->model && b->model_pairs, "null input array");
-  VO_REQUIRE(b->matches && b->joined && b->model_moved && b->poses && b->tri_xyz && b->tri_pairs && b->counts,
-             "null output array");
+  VO_REQUIRE(b->matches && b->joined && b->poses && b->tri_xyz && b->tri_pairs && b->counts, "null output array");
   if (int r = set_device(c)) return r;
   const int nt = b->n_ref > b->n_cur ? b->n_ref : b->n_cur;
   const size_t cs = compaction_scratch_ints(q);
   VO_HIP_CHECK(c->scratch.ensure(sizeof(int) * cs * (size_t)F, c->stream));
   VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)q * (size_t)F, c->stream));
-  VO_HIP_CHECK(c->table.ensure(sizeof(int) * (size_t)(b->n_ref ? b->n_ref : 1) * (size_t)F, c->stream));
+  VO_HIP_CHECK(c->table.ensure(sizeof(unsigned long long) * (size_t)(b->n_ref ? b->n_ref : 1) * (size_t)F, c->stream));
   // ragged frames (sz): the counts of the struct are capacities (= strides), frame f holds sz->n_ref[f] / n_cur[f] points and
   // n_model_pairs[f] model pairs; the matcher then runs its full scan with per-frame roles (vo_complete.cpp:15-20)
   const int variant = sz ? 1 : match_variant(c, nt, q, F);
@@ -1059,14 +1075,24 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
   // extract_correspondences_world                                               vo_complete.cpp:157
   VO_HIP_CHECK(launch_join_batch(c->stream, b->matches, q, n_match, b->model_pairs, b->n_model_pairs,
                                  sz ? sz->n_model_pairs : nullptr, b->n_ref,
-                                 b->joined, n_join, c->table.as<int>(), c->scratch.as<int>(), F, (size_t)q,
+                                 b->joined, n_join, c->table.as<unsigned long long>(), c->scratch.as<int>(), F, (size_t)q,
                                  (size_t)b->n_model_pairs, (size_t)q));
   // X_curr * triangulated_pc                                                    vo_complete.cpp:159
-  VO_HIP_CHECK(launch_transform_batch(c->stream, b->X_prev, b->model, b->n_model, (size_t)b->n_model, b->model_moved, F));
+  // The moved cloud as an output is optional: without it the solver's gather applies X_prev to the points it fetches (the
+  // same arithmetic, PointCloud.h:80) and the pass that writes n_model points per frame only to re-read the joined ones
+  // is gone (117 MB written + 37 us per 200 x 50k frames).
+  const float* world = b->model;
+  const float* X_world = nullptr;
+  if (b->model_moved) {
+    VO_HIP_CHECK(launch_transform_batch(c->stream, b->X_prev, b->model, b->n_model, (size_t)b->n_model, b->model_moved, F));
+    world = b->model_moved;
+  } else {
+    X_world = b->X_prev;                              // (null: identity -- the points are used as they are)
+  }
   // solver.init(identity) + n rounds                                            vo_complete.cpp:161-164
-  if (int r = vo_picp_solve_batch_dev(c, F, b->rows, b->cols, b->z_near, b->z_far, b->K, b->kernel_threshold,
-                                      b->keep_outliers, b->model_moved, (size_t)b->n_model, b->cur_pts, (size_t)b->n_cur,
-                                      b->joined, (size_t)q, n_join, nullptr, b->n_iters, b->poses, b->stats))
+  if (int r = picp_solve_batch(c, F, b->rows, b->cols, b->z_near, b->z_far, b->K, b->kernel_threshold,
+                               b->keep_outliers, world, (size_t)b->n_model, b->cur_pts, (size_t)b->n_cur,
+                               b->joined, (size_t)q, n_join, nullptr, b->n_iters, b->poses, b->stats, X_world))
     return r;
   // triangulate_points with the new pose                                        vo_complete.cpp:172-173
   VO_HIP_CHECK(launch_triangulate_batch(c->stream, b->K, nullptr, b->poses, b->matches, q, n_match, b->ref_pts, b->n_ref,
@@ -1087,9 +1113,9 @@ int vo_join_correspondences_dev(vo_ctx* c, const int32_t* d_img, int n_img, cons
   VO_REQUIRE((n_img == 0 || (d_img && d_out)) && (n_world == 0 || d_world), "null pair array");
   if (int r = set_device(c)) return r;
   if (int r = ensure_scratch(c, n_img)) return r;
-  VO_HIP_CHECK(c->table.ensure(sizeof(int) * (size_t)(n_ref ? n_ref : 1), c->stream));
+  VO_HIP_CHECK(c->table.ensure(sizeof(unsigned long long) * (size_t)(n_ref ? n_ref : 1), c->stream));
   VO_HIP_CHECK(launch_join(c->stream, d_img, n_img, d_n_img, d_world, n_world, d_n_world, n_ref, d_out,
-                           d_n_out, c->table.as<int>(), c->scratch.as<int>()));
+                           d_n_out, c->table.as<unsigned long long>(), c->scratch.as<int>()));
   return VO_OK;
 }
 

@@ -399,20 +399,22 @@ hipError_t launch_triangulate(hipStream_t st, const float K[9], const Pose* X_ho
 }
 
 // ---- join ---------------------------------------------------------------------------
-// table[ref] = position of the FIRST world pair whose .first == ref
-// (vo_complete.cpp:57-62 scans from the start and breaks on the first hit).
-constexpr int JOIN_EMPTY = 0x7f7f7f7f;   // byte pattern of the memset
+// table[ref] = (position of the FIRST world pair whose .first == ref) << 32 | that pair's .second
+// (vo_complete.cpp:57-62 scans from the start and breaks on the first hit): the minimum over the positions, taken by a
+// 64-bit atomicMin so that the partner's world index rides along -- the lookups then cost ONE random read per image pair
+// instead of two dependent ones (table, then the world pair).
+constexpr unsigned long long JOIN_EMPTY = 0x7f7f7f7f7f7f7f7full;   // byte pattern of the memset
 
 __global__ __launch_bounds__(256) void join_build_kernel(const int32_t* __restrict__ world, int n_max,
                                                          const int* __restrict__ d_n, int n_ref,
-                                                         int* table, size_t world_stride) {
+                                                         unsigned long long* table, size_t world_stride) {
   world += 2 * blockIdx.y * world_stride;            // frame = blockIdx.y
   table += (size_t)blockIdx.y * n_ref;
   if (d_n) d_n += blockIdx.y;
   const int n = clamp_count(d_n, n_max);
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    const int ref = world[2 * (size_t)j];
-    if (ref >= 0 && ref < n_ref) atomicMin(&table[ref], j);
+    const int2 pr = reinterpret_cast<const int2*>(world)[j];
+    if (pr.x >= 0 && pr.x < n_ref) atomicMin(&table[pr.x], ((unsigned long long)(unsigned)j << 32) | (unsigned)pr.y);
   }
 }
 
@@ -420,7 +422,7 @@ struct JoinArgs {
   const int32_t* img; int n_max; const int* d_n;
   const int32_t* world;
   int n_ref;
-  const int* table;
+  const unsigned long long* table;
   int32_t* out;
   int* counts;
   size_t img_stride, world_stride, out_stride, counts_stride;   // per frame, in pairs / ints
@@ -439,12 +441,12 @@ __device__ __forceinline__ JoinArgs join_frame(JoinArgs a, int frame) {
 }
 
 __device__ __forceinline__ bool join_eval(const JoinArgs& a, int i, int& cur, int& w) {
-  const int ref = a.img[2 * (size_t)i];
-  cur = a.img[2 * (size_t)i + 1];
-  if (ref < 0 || ref >= a.n_ref) return false;
-  const int j = a.table[ref];
-  if (j == JOIN_EMPTY) return false;
-  w = a.world[2 * (size_t)j + 1];
+  const int2 pr = reinterpret_cast<const int2*>(a.img)[i];
+  cur = pr.y;
+  if (pr.x < 0 || pr.x >= a.n_ref) return false;
+  const unsigned long long e = a.table[pr.x];
+  if (e == JOIN_EMPTY) return false;
+  w = (int)(unsigned)(e & 0xffffffffull);
   return true;
 }
 
@@ -483,15 +485,15 @@ __global__ __launch_bounds__(CB) void join_scatter_kernel(JoinArgs a0) {
 
 // n_frames > 1: frame f joins d_img + f*img_stride (d_n_img[f] pairs) with d_world + f*world_stride
 // (d_n_world[f] pairs, or n_world when null) into d_out + f*out_stride, count in d_n_out[f];
-// d_table: n_frames*n_ref ints, d_scratch: n_frames*compaction_scratch_ints(n_img) ints.
+// d_table: n_frames*n_ref 64-bit words, d_scratch: n_frames*compaction_scratch_ints(n_img) ints.
 hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, const int* d_n_img,
                              const int32_t* d_world, int n_world, const int* d_n_world, int n_ref, int32_t* d_out,
-                             int* d_n_out, int* d_table, int* d_scratch, int n_frames, size_t img_stride,
+                             int* d_n_out, unsigned long long* d_table, int* d_scratch, int n_frames, size_t img_stride,
                              size_t world_stride, size_t out_stride) {
   const bool batched = n_frames > 1;
   hipError_t e = hipSuccess;
   if (n_ref > 0) {
-    e = hipMemsetAsync(d_table, 0x7f, sizeof(int) * (size_t)n_ref * (size_t)n_frames, st);
+    e = hipMemsetAsync(d_table, 0x7f, sizeof(unsigned long long) * (size_t)n_ref * (size_t)n_frames, st);
     if (e != hipSuccess) return e;
   }
   if (n_world > 0 && n_ref > 0) {
@@ -513,7 +515,7 @@ hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, co
 
 hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const int* d_n_img,
                        const int32_t* d_world, int n_world, const int* d_n_world, int n_ref,
-                       int32_t* d_out, int* d_n_out, int* d_table, int* d_scratch) {
+                       int32_t* d_out, int* d_n_out, unsigned long long* d_table, int* d_scratch) {
   return launch_join_batch(st, d_img, n_img, d_n_img, d_world, n_world, d_n_world, n_ref, d_out, d_n_out, d_table,
                            d_scratch, 1, 0, 0, 0);
 }

@@ -186,7 +186,21 @@ __device__ __forceinline__ Pose picp_tail_wave(float* s_sys, const Pose& T) {
 // ldlt6_solve_ordered, redundant in all lanes; the three angles go through the small-angle sin / cos in three lanes.
 // Against the reference's arithmetic this is one more rounding-level deviation of the fast mode (vo_math.h), the
 // reference-order mode keeps Eigen's pivoted factorisation.
-__device__ __forceinline__ Pose picp_tail_direct(float val, const Pose& T) {
+// The pose composition T <- v2t(dx) * T (picp_solver.cpp:110) is done ACROSS lanes: lane l < 12 computes entry l of the new
+// pose (l = r + 3c: R(r,c) for c < 3, t(r) for c = 3) as one 3-term product a . b with a = row r of dR (three selects from
+// the uniform dR) and b = column c of the old pose, which the lane holds in (b0, b1, b2) -- the round kernel loads them
+// straight from the previous launch's pose (one 12-byte load per lane at kernel start), the in-launch forms select them from
+// their uniform copy (pose_lane_operands).  Same products, same order (dot3, + dt for the translation) as pose_mul: the same
+// bits, in ~20 instead of ~63 instructions of every lane.
+__device__ __forceinline__ void pose_lane_operands(const Pose& T, float& b0, float& b1, float& b2) {
+  const int lane = threadIdx.x & 63;
+  const int c = lane < 3 ? 0 : (lane < 6 ? 1 : (lane < 9 ? 2 : 3));
+  b0 = c == 0 ? T.R[0] : (c == 1 ? T.R[3] : (c == 2 ? T.R[6] : T.t[0]));
+  b1 = c == 0 ? T.R[1] : (c == 1 ? T.R[4] : (c == 2 ? T.R[7] : T.t[1]));
+  b2 = c == 0 ? T.R[2] : (c == 1 ? T.R[5] : (c == 2 ? T.R[8] : T.t[2]));
+}
+
+__device__ __forceinline__ Pose picp_tail_direct(float val, float b0, float b1, float b2) {
   const int lane = threadIdx.x & 63;
   float B[6][6], y[6];
 #pragma unroll
@@ -209,7 +223,19 @@ __device__ __forceinline__ Pose picp_tail_direct(float val, const Pose& T) {
   const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 2));
   const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 2));
   const Pose dT = v2t_from_sincos(y, sx, cx, sy, cy, sz, cz);
-  return pose_mul(dT, T);                                  // picp_solver.cpp:110
+  // entry l = r + 3c of v2t(dx) * T in lane l < 12
+  const float a0 = m == 0 ? dT.R[0] : (m == 1 ? dT.R[1] : dT.R[2]);
+  const float a1 = m == 0 ? dT.R[3] : (m == 1 ? dT.R[4] : dT.R[5]);
+  const float a2 = m == 0 ? dT.R[6] : (m == 1 ? dT.R[7] : dT.R[8]);
+  float e = dot3(a0, b0, a1, b1, a2, b2);
+  const float dt = m == 0 ? dT.t[0] : (m == 1 ? dT.t[1] : dT.t[2]);
+  e = lane >= 9 ? e + dt : e;
+  Pose Tn;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Tn.R[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), i));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Tn.t[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 9 + i));
+  return Tn;
 }
 
 // what lane l of the solving wave contributes: H(l / 6, l % 6) + damping on the diagonal from the reduced accumulators
@@ -311,9 +337,11 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
   // written by workgroups on all eight XCDs: Infinity-Cache/HBM round trips that must
   // overlap, not chain).
   float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
-  // The previous round's pose (written by workgroup 0 of the previous launch, i.e. on another XCD for most readers)
-  // goes out with the partial rows, as VECTOR loads: left to the compiler it becomes a scalar load sunk to just before
-  // its use at the end of the solve, and that miss (it shares lgkmcnt with the LDS reads there) then sits on the chain.
+  // The previous round's pose (written by workgroup 0 of the previous launch, i.e. on another XCD for most readers) goes out
+  // with the partial rows, as VECTOR loads: lane l fetches the column of the old pose it will multiply by in the tail
+  // (picp_tail_direct: entries 3c .. 3c+2 of the 12 floats, c = l / 3 clamped to 3).
+  float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f;
+#ifdef VO_TAIL_SERIAL
   typedef float f4v __attribute__((ext_vector_type(4)));
   f4v pz0 = {0.f, 0.f, 0.f, 0.f}, pz1 = pz0, pz2 = pz0;
   if (PRE) {
@@ -322,6 +350,14 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     const f4v* pp = reinterpret_cast<const f4v*>(S->pose[(it - 1) & 1]) + lane_zero;
     pz0 = pp[0]; pz1 = pp[1]; pz2 = pp[2];
   }
+#else
+  if (PRE) {
+    const int l = tid & 63;
+    const int c3 = l < 3 ? 0 : (l < 6 ? 3 : (l < 9 ? 6 : 9));
+    const float* pp = S->pose[(it - 1) & 1] + c3;
+    pb0 = pp[0]; pb1 = pp[1]; pb2 = pp[2];
+  }
+#endif
   if (PRE) {
     const int nb_pad = (nb + 255) & ~255;
     const float* prev = partials + (size_t)((it - 1) & 1) * nb_pad * PICP_PSTRIDE;
@@ -415,15 +451,15 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
 #endif
     VO_STAMP(2);
     {
+#ifdef VO_TAIL_SERIAL
       Pose Tprev;
       Tprev.R[0] = pz0.x; Tprev.R[1] = pz0.y; Tprev.R[2] = pz0.z; Tprev.R[3] = pz0.w;
       Tprev.R[4] = pz1.x; Tprev.R[5] = pz1.y; Tprev.R[6] = pz1.z; Tprev.R[7] = pz1.w;
       Tprev.R[8] = pz2.x; Tprev.t[0] = pz2.y; Tprev.t[1] = pz2.z; Tprev.t[2] = pz2.w;
       const Pose Told = uniform_pose(Tprev);
-#ifdef VO_TAIL_SERIAL
       const Pose Tn = picp_tail_wave(sys, Told);
 #else
-      const Pose Tn = picp_tail_direct(val, Told);
+      const Pose Tn = picp_tail_direct(val, pb0, pb1, pb2);
 #endif
       if (tid == 0 && blockIdx.x == 0) {
         store_pose12(S->pose[FINISH ? 0 : (it & 1)], Tn);
@@ -589,7 +625,9 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_small_kernel(const PicpParams
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const Pose Tn = picp_tail_wave(sys, T);
 #else
-    const Pose Tn = picp_tail_direct(val, T);
+    float b0, b1, b2;
+    pose_lane_operands(T, b0, b1, b2);
+    const Pose Tn = picp_tail_direct(val, b0, b1, b2);
 #endif
     if (last && tid == 0) {
       store_pose12(S->pose[0], Tn);
@@ -666,11 +704,19 @@ __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
     a.states[p].pose[0][k] = v;
   }
   const float qnan = __int_as_float((int)VO_DROPPED_BITS);
+  Pose Xw;
+  if (a.X_world) {
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = a.X_world[16 * (size_t)p + k];
+    Xw = pose_from_T16(t);
+  }
   for (int i = fb.b * 256 + threadIdx.x; i < n; i += fb.nb * 256) {
     const int m = pairs[2 * i], w = pairs[2 * i + 1];
     float x = qnan, y = 0.f, z = 0.f, u = 0.f, v = 0.f;
     if (m >= 0 && m < a.n_meas && w >= 0 && w < a.n_world) {
       x = world[3 * (size_t)w]; y = world[3 * (size_t)w + 1]; z = world[3 * (size_t)w + 2];
+      if (a.X_world) { const float px = x, py = y, pz = z; pose_apply(Xw, px, py, pz, x, y, z); }   // PointCloud.h:80, as transform_batch_kernel
       u = meas[2 * (size_t)m]; v = meas[2 * (size_t)m + 1];
     } else if (a.n_bad) {
       atomicAdd(&a.n_bad[p], 1);        // dropped (marker) and counted: reported in stats_out[4p + 3]
@@ -804,7 +850,9 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
 #ifdef VO_TAIL_SERIAL
       const Pose Tn = picp_tail_wave(s_sys, T);
 #else
-      const Pose Tn = picp_tail_direct(picp_lane_value(s_tot, a.damping, nullptr, nullptr), T);
+      float b0, b1, b2;
+      pose_lane_operands(T, b0, b1, b2);
+      const Pose Tn = picp_tail_direct(picp_lane_value(s_tot, a.damping, nullptr, nullptr), b0, b1, b2);
 #endif
       if (tid == 0) {
         store_pose12(s_pose, Tn);

@@ -101,6 +101,8 @@ struct BatchArgs {
   int pack_gx;         // workgroups per problem of the gather pass
   int* n_bad;          // n_problems counters (zeroed by the caller): correspondences dropped for a bad index, or null
   int exact;           // reference-order form (picp_exact_kernel): one workgroup per problem, sequential sums
+  const float* X_world;  // n_problems x 16 (column-major) or null: the gather applies X * p to every world point it fetches
+                         //   (X_curr * triangulated_pc of vo_complete.cpp:159 without the pass that writes the moved cloud)
 };
 hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a);
 // when is the launch-per-round form the faster one?  (measured: DESIGN.md section 4.1)
@@ -151,7 +153,7 @@ hipError_t launch_triangulate(hipStream_t st, const float K[9], const Pose* X_ho
 
 hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const int* d_n_img,
                        const int32_t* d_world, int n_world, const int* d_n_world, int n_ref,
-                       int32_t* d_out, int* d_n_out, int* d_table /* n_ref ints */,
+                       int32_t* d_out, int* d_n_out, unsigned long long* d_table /* n_ref words */,
                        int* d_scratch);
 
 // matcher variants: 1 = full scan (no workspace), 2 = bucket-pruned scan, 3 = cell-hash search; the
@@ -180,7 +182,7 @@ hipError_t launch_triangulate_batch(hipStream_t st, const float K[9], const Pose
                                     size_t pairs_stride, size_t p1_stride, size_t p2_stride, size_t out_stride);
 hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, const int* d_n_img,
                              const int32_t* d_world, int n_world, const int* d_n_world, int n_ref, int32_t* d_out,
-                             int* d_n_out, int* d_table, int* d_scratch, int n_frames, size_t img_stride,
+                             int* d_n_out, unsigned long long* d_table, int* d_scratch, int n_frames, size_t img_stride,
                              size_t world_stride, size_t out_stride);
 
 // in-place exclusive scan of nb ints per frame (one workgroup per frame), total to total[frame] (and total2[frame])

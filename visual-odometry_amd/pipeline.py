@@ -167,9 +167,12 @@ class BatchPipeline:
 
     def __init__(self, ctx: Context, fps, n_iters: int = 50, kernel_threshold: float = 10000.0,
                  with_appearance: bool = True, poses_ptr: int | None = None, n_frames: int | None = None,
-                 upload_block: int = 100, frames_per_call: int | None = None):
+                 upload_block: int = 100, frames_per_call: int | None = None, with_moved: bool = False, X_prev=None):
         """poses_ptr: optional device buffer (n_frames*16 floats, e.g. a torch tensor's data_ptr) that
-        receives the poses directly, so that a collective can read them without a copy."""
+        receives the poses directly, so that a collective can read them without a copy.
+        with_moved: also produce X_prev * model as an output array (vo_frame_batch.model_moved); without it the solver's
+        gather moves the points it fetches itself.  X_prev: optional (F, 4, 4) poses of the previous frames
+        (vo_complete.cpp:159); default: identity."""
         self.ctx, self.lib = ctx, ctx.lib
         gen = fps if callable(fps) else (lambda lo, hi: fps[lo:hi])
         F = self.F = int(n_frames if n_frames is not None else len(fps))
@@ -200,7 +203,9 @@ class BatchPipeline:
         q = self.q
         self.d_matches, self.d_joined = a(F * q * 8), a(F * q * 8)
         self._own_poses = poses_ptr is None
-        self.d_moved, self.d_poses, self.d_stats = a(F * self.n_model * 12), (a(F * 64) if poses_ptr is None else poses_ptr), a(F * 16)
+        self.d_moved = a(F * self.n_model * 12) if with_moved else 0
+        self.d_X = ctx.to_device(np.ascontiguousarray(np.stack([_colmajor(X, 4) for X in X_prev]))) if X_prev is not None else 0
+        self.d_poses, self.d_stats = (a(F * 64) if poses_ptr is None else poses_ptr), a(F * 16)
         self.d_tri_xyz, self.d_tri_pairs = a(F * q * 12), a(F * q * 8)
         self.d_tri_app = a(F * q * 40) if with_appearance else 0
         self.d_counts = a(3 * F * 4)
@@ -212,12 +217,13 @@ class BatchPipeline:
             b.n_frames, b.n_ref, b.n_cur, b.n_model, b.n_model_pairs = hi - lo, self.n_ref, self.n_cur, self.n_model, self.n_mp
             (b.ref_app, b.cur_app, b.ref_pts, b.cur_pts, b.model, b.model_pairs) = \
                 [d + lo * per[k] * w * 4 for d, (k, _, w) in zip(self._in, self._IN)]
-            b.X_prev = None
+            b.X_prev = (self.d_X + lo * 64) if self.d_X else None
             b.rows, b.cols, b.z_near, b.z_far = int(f0["rows"]), int(f0["cols"]), int(f0["z_near"]), int(f0["z_far"])
             b.K[:] = _colmajor(f0["K"], 3).tolist()
             b.kernel_threshold, b.keep_outliers, b.n_iters, b.radius = kernel_threshold, 0, n_iters, 0.1
             b.matches, b.joined = self.d_matches + lo * q * 8, self.d_joined + lo * q * 8
-            b.model_moved, b.poses, b.stats = self.d_moved + lo * self.n_model * 12, self.d_poses + lo * 64, self.d_stats + lo * 16
+            b.model_moved = (self.d_moved + lo * self.n_model * 12) if self.d_moved else None
+            b.poses, b.stats = self.d_poses + lo * 64, self.d_stats + lo * 16
             b.tri_xyz, b.tri_pairs = self.d_tri_xyz + lo * q * 12, self.d_tri_pairs + lo * q * 8
             b.tri_app = (self.d_tri_app + lo * q * 40) if self.d_tri_app else None
             b.counts = self.d_counts + 3 * lo * 4        # this call's [3][hi - lo] block
@@ -227,6 +233,13 @@ class BatchPipeline:
     def run(self):
         for _, _, b in self.calls:
             _chk(self.lib.vo_frames_batch_dev(self.ctx.h, C.byref(b)))
+
+    def match_only(self):
+        """the matcher stage of every call alone (vo_match_appearances_batch_dev on the same inputs, into the same outputs)"""
+        for _, _, b in self.calls:
+            _chk(self.lib.vo_match_appearances_batch_dev(self.ctx.h, C.c_int(b.n_frames), C.c_void_p(b.ref_app), C.c_int(b.n_ref), None,
+                                                         C.c_void_p(b.cur_app), C.c_int(b.n_cur), None, C.c_float(b.radius),
+                                                         C.c_void_p(b.matches), C.c_void_p(b.counts)))
 
     def counts(self):
         raw = np.zeros(3 * self.F, np.int32)
@@ -257,8 +270,9 @@ class BatchPipeline:
         return out
 
     def close(self):
-        for d in self._in + [self.d_matches, self.d_joined, self.d_moved, self.d_stats, self.d_tri_xyz,
+        for d in self._in + [self.d_matches, self.d_joined, self.d_stats, self.d_tri_xyz,
                              self.d_tri_pairs, self.d_counts] + ([self.d_tri_app] if self.d_tri_app else []) + \
+                ([self.d_moved] if self.d_moved else []) + ([self.d_X] if self.d_X else []) + \
                 ([self.d_poses] if self._own_poses else []):
             self.ctx.free(d)
 
