@@ -543,7 +543,7 @@ def frame_leg(torch, ctx, stream, pipe, fp, args, vo_mod=None):
     match_flops = 30.0 * n1 * n2                     # 30 flop per (tree, query) pair
     roofs = {}
     if (n1, n2) == (50000, 50000):
-        roofs = {"match_full_scan_roofline": _valu_roofline(("vo::match_init_kernel", "vo::match_kernel", "vo::match_count_kernel", "vo::match_scatter_kernel"),
+        roofs = {"match_full_scan_roofline": _valu_roofline(("vo::match_init_kernel", "vo::match_kernel<false>", "vo::match_count_kernel", "vo::match_scatter_kernel"),
                                                             stages["match_full_scan_ms"] * 1e-3, "one frame, every (query, tree point) pair visited", min),
                  "match_roofline": _valu_roofline(("vo::match_minmax_kernel", "vo::match_bucket_hist_kernel", "vo::match_bucket_offsets_kernel",
                                                    "vo::match_bucket_place_kernel", "vo::match_pruned_kernel", "vo::match_count_kernel",

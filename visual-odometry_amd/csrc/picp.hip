@@ -193,11 +193,16 @@ __device__ __forceinline__ Pose picp_tail_wave(float* s_sys, const Pose& T) {
 // their uniform copy (pose_lane_operands).  Same products, same order (dot3, + dt for the translation) as pose_mul: the same
 // bits, in ~20 instead of ~63 instructions of every lane.
 __device__ __forceinline__ void pose_lane_operands(const Pose& T, float& b0, float& b1, float& b2) {
+  // plain scalars and one select per step: a chain of selects over the members of T makes the compiler park T in scratch
+  // memory and select among ADDRESSES (the trap of DESIGN.md section 4.2)
   const int lane = threadIdx.x & 63;
-  const int c = lane < 3 ? 0 : (lane < 6 ? 1 : (lane < 9 ? 2 : 3));
-  b0 = c == 0 ? T.R[0] : (c == 1 ? T.R[3] : (c == 2 ? T.R[6] : T.t[0]));
-  b1 = c == 0 ? T.R[1] : (c == 1 ? T.R[4] : (c == 2 ? T.R[7] : T.t[1]));
-  b2 = c == 0 ? T.R[2] : (c == 1 ? T.R[5] : (c == 2 ? T.R[8] : T.t[2]));
+  const float r0 = T.R[0], r1 = T.R[1], r2 = T.R[2], r3 = T.R[3], r4 = T.R[4], r5 = T.R[5], r6 = T.R[6], r7 = T.R[7], r8 = T.R[8];
+  const float t0 = T.t[0], t1 = T.t[1], t2 = T.t[2];
+  const bool c1 = lane >= 3, c2 = lane >= 6, c3 = lane >= 9;
+  b0 = r0; b1 = r1; b2 = r2;
+  b0 = c1 ? r3 : b0; b1 = c1 ? r4 : b1; b2 = c1 ? r5 : b2;
+  b0 = c2 ? r6 : b0; b1 = c2 ? r7 : b1; b2 = c2 ? r8 : b2;
+  b0 = c3 ? t0 : b0; b1 = c3 ? t1 : b1; b2 = c3 ? t2 : b2;
 }
 
 __device__ __forceinline__ Pose picp_tail_direct(float val, float b0, float b1, float b2) {
@@ -212,9 +217,12 @@ __device__ __forceinline__ Pose picp_tail_direct(float val, float b0, float b1, 
   }
   ldlt6_solve_ordered(B, y);
   const int m = lane % 3;
-  const float ang = m == 0 ? y[3] : (m == 1 ? y[4] : y[5]);
+  const float y3 = y[3], y4 = y[4], y5 = y[5];
+  float ang = y3;
+  ang = m == 1 ? y4 : ang;
+  ang = m == 2 ? y5 : ang;
   float sn, cs;
-  if (__builtin_expect(!(fabsf(y[3]) <= 0.5f && fabsf(y[4]) <= 0.5f && fabsf(y[5]) <= 0.5f), 0)) sincosf(ang, &sn, &cs);
+  if (__builtin_expect(!(fabsf(y3) <= 0.5f && fabsf(y4) <= 0.5f && fabsf(y5) <= 0.5f), 0)) sincosf(ang, &sn, &cs);
   else sincos_small(ang, sn, cs);
   const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 0));
   const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 0));
@@ -224,11 +232,13 @@ __device__ __forceinline__ Pose picp_tail_direct(float val, float b0, float b1, 
   const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 2));
   const Pose dT = v2t_from_sincos(y, sx, cx, sy, cy, sz, cz);
   // entry l = r + 3c of v2t(dx) * T in lane l < 12
-  const float a0 = m == 0 ? dT.R[0] : (m == 1 ? dT.R[1] : dT.R[2]);
-  const float a1 = m == 0 ? dT.R[3] : (m == 1 ? dT.R[4] : dT.R[5]);
-  const float a2 = m == 0 ? dT.R[6] : (m == 1 ? dT.R[7] : dT.R[8]);
+  const float d0 = dT.R[0], d1 = dT.R[1], d2 = dT.R[2], d3 = dT.R[3], d4 = dT.R[4], d5 = dT.R[5], d6 = dT.R[6], d7 = dT.R[7], d8 = dT.R[8];
+  const float u0 = dT.t[0], u1 = dT.t[1], u2 = dT.t[2];
+  const bool m1 = m == 1, m2 = m == 2;
+  float a0 = d0, a1 = d3, a2 = d6, dt = u0;
+  a0 = m1 ? d1 : a0; a1 = m1 ? d4 : a1; a2 = m1 ? d7 : a2; dt = m1 ? u1 : dt;
+  a0 = m2 ? d2 : a0; a1 = m2 ? d5 : a1; a2 = m2 ? d8 : a2; dt = m2 ? u2 : dt;
   float e = dot3(a0, b0, a1, b1, a2, b2);
-  const float dt = m == 0 ? dT.t[0] : (m == 1 ? dT.t[1] : dT.t[2]);
   e = lane >= 9 ? e + dt : e;
   Pose Tn;
 #pragma unroll
