@@ -3,7 +3,10 @@
 #pragma once
 #include <cmath>
 #include <cstdio>
+#include <regex>
+#include <set>
 #include <string>
+#include <vector>
 
 #include "vo/vo.hpp"
 
@@ -65,6 +68,32 @@ inline float max_error_vs_gt(const IsometryVector& trajectory, const Isometry3f&
       for (int c = 0; c < 4; ++c) err = std::fmax(err, std::fabs(H(r, c) * (c == 3 ? scale : 1.f) - gt[i](r, c)));
   }
   return err;
+}
+
+// Everything the known-association drivers read before their frame loop: the measurement file names (sorted), the camera
+// (files.hpp readers), and -- when asked for -- the landmark map of world.dat.  Prints the reason and returns false when a
+// file is missing.
+struct Dataset {
+  std::vector<std::string> meas_files;
+  Matrix3f K;
+  Isometry3f cameraInRobot;
+  int rows = 0, cols = 0, z_near = 0, z_far = 0;
+  Vector3fVector landmarks;            // world.dat positions, indexed by landmark id
+  Camera camera() const { return Camera(rows, cols, z_near, z_far, K); }
+};
+
+inline bool load_dataset(const std::string& dir, Dataset& d, bool with_landmarks) {
+  std::set<std::string> names;
+  if (!get_file_names(dir, names, std::regex("^meas-\\d.*\\.dat$"))) { std::printf("unable to open directory %s\n", dir.c_str()); return false; }
+  d.meas_files.assign(names.begin(), names.end());
+  std::vector<int> ints;               // z_near, z_far, width, height (files_utils.cpp:94-134)
+  if (!get_camera_params(dir + "camera.dat", ints, d.K, d.cameraInRobot) || ints.size() < 4) { std::printf("unable to read %scamera.dat\n", dir.c_str()); return false; }
+  d.z_near = ints[0]; d.z_far = ints[1]; d.cols = ints[2]; d.rows = ints[3];
+  if (with_landmarks) {
+    Vector10fVector unused_appearances;
+    if (!get_meas_content(dir + "world.dat", unused_appearances, d.landmarks, true)) { std::printf("unable to read %sworld.dat\n", dir.c_str()); return false; }
+  }
+  return true;
 }
 
 struct Args {

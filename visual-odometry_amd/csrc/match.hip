@@ -665,9 +665,10 @@ constexpr int CELL_MAX_SLICES = 1024;    // per set: the cell variant serves set
 #define VO_CS_NB 3
 #endif
 constexpr int CS_NB = VO_CS_NB;          // coarse bins per search workgroup (a strip along c1)
-constexpr int CS_THREADS = CS_NB == 1 ? 192 : (CS_NB == 2 ? 320 : 448);   // a coarse bin holds ~140 queries at 50k points
+constexpr int CS_THREADS = CS_NB == 1 ? 192 : (CS_NB == 2 ? 320 : (CS_NB == 3 ? 448 : (CS_NB == 4 ? 576 : 704)));   // a coarse bin holds ~140 queries at 50k points
+constexpr int CS_WG_PER_CU = CS_NB == 2 ? 5 : (CS_NB <= 3 ? 4 : (CS_NB == 4 ? 3 : 2));        // resident search workgroups per CU the registers are budgeted for
 constexpr int CS_SURV = 2;               // further filter survivors a lane parks (beyond its first) before it decides them on the spot
-constexpr int CS_CAP = 2816;             // tree points a search workgroup can stage (8 B each; ~140 per bin at 50k)
+constexpr int CS_CAP = CS_NB == 2 ? 2304 : (CS_NB <= 3 ? 2816 : (CS_NB == 4 ? 3328 : 3840));             // tree points a search workgroup can stage (8 B each; ~140 per bin at 50k)
 
 bool match_cells_supported(int nt, int nq) {
   return (long long)nt <= (long long)CELL_MAX_SLICES * CELL_SLICE && (long long)nq <= (long long)CELL_MAX_SLICES * CELL_SLICE;
@@ -1200,7 +1201,7 @@ __device__ __forceinline__ Row10 load_row(const float* p) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(CS_THREADS, CS_THREADS * 4 / 256) void cell_search_kernel(CellArgs a) {
+__global__ __launch_bounds__(CS_THREADS, CS_THREADS * CS_WG_PER_CU / 256) void cell_search_kernel(CellArgs a) {
   int f, blk;
   if (!xcd_frame_block(HNC * CS_STRIPS, a.n_frames, f, blk)) return;
   char* ws = a.ws + f * a.ws_stride;
