@@ -353,14 +353,13 @@ int vo_frames_batch_dev(vo_ctx *ctx, const vo_frame_batch *batch);
  * capacities (= the strides between frames); frame f really holds sizes->n_ref[f] <= n_ref and n_cur[f] <= n_cur points and
  * n_model_pairs[f] <= n_model_pairs model pairs (device int arrays of n_frames entries).  Every frame picks its own tree --
  * its larger set, the reference image on ties -- exactly like the single-frame call (vo_complete.cpp:15-20); the matcher
- * runs its full scan (the sorted searches lay their workspaces out for one size).  Outputs, counts and strides as above. */
+ * runs its full scan or, from the sizes on where sorting pays, the cell-hash search.  Outputs, counts and strides as above. */
 typedef struct vo_frame_sizes {
   const int *n_ref, *n_cur, *n_model_pairs;
 } vo_frame_sizes;
 int vo_frames_batch_ragged_dev(vo_ctx *ctx, const vo_frame_batch *batch, const vo_frame_sizes *sizes);
 /* The matcher alone for n_frames pairs of appearance sets: frame f = d_a1 + f*cap1*10 (d_n1[f] <= cap1 rows) against
- * d_a2 + f*cap2*10 (d_n2[f] <= cap2 rows); d_n1 = d_n2 = NULL: every frame holds cap1 / cap2 rows (and the sorted searches
- * may run).  d_out_pairs: [n_frames][min(cap1, cap2)][2] (ref index, cur index), d_n_out[f] = pairs found.  Replaces
+ * d_a2 + f*cap2*10 (d_n2[f] <= cap2 rows); d_n1 = d_n2 = NULL: every frame holds cap1 / cap2 rows.  d_out_pairs: [n_frames][min(cap1, cap2)][2] (ref index, cur index), d_n_out[f] = pairs found.  Replaces
  * n_frames calls of compute_correspondences_images (vo_complete.cpp:12-49): the up-front matching of a whole sequence. */
 int vo_match_appearances_batch_dev(vo_ctx *ctx, int n_frames, const float *d_a1, int cap1, const int *d_n1,
                                    const float *d_a2, int cap2, const int *d_n2, float radius, int32_t *d_out_pairs,

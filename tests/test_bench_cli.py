@@ -72,3 +72,25 @@ def test_strong_pairs_fewer_than_ranks_is_rejected_up_front():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--strong-pairs", "3"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "every rank needs at least one pair" in r.stderr and r.stdout.strip() == ""
+
+
+def test_committed_counter_summaries_feed_the_roofline_objects():
+    """bench.py takes counter-derived figures (HBM traffic, executed VALU instructions) from the newest summaries under
+    profiles/: the kernel names and launch geometries it asks for must exist there, or a roofline object silently loses its
+    `traffic` / `achieved`"""
+    b = _bench()
+    traffic, note = b._pmc_traffic("vo::picp_round_kernel<true, false, true, false>", 256 * ((50000 + 255) // 256))
+    assert traffic is not None and 0.3e6 < traffic < 3e6, note            # one round over a 50k pair: ~0.75 MB
+    t2, note2 = b._pmc_traffic("vo::picp_batch_kernel<true, false>", 768 * 200)
+    assert t2 is not None and 5e9 < t2 < 12e9, note2                      # 200 x 50k x 50 rounds: ~9 GB
+    call, _ = b._pmc_frames_call()
+    assert call is not None and 10e9 < call < 20e9                        # one 200-frame call: ~13.9 GB
+    for kernels, pick in ((("vo::match_init_kernel", "vo::match_kernel<false>", "vo::match_count_kernel", "vo::match_scatter_kernel"), min),
+                          (("vo::match_minmax_kernel", "vo::match_bucket_hist_kernel", "vo::match_bucket_offsets_kernel",
+                            "vo::match_bucket_place_kernel", "vo::match_pruned_kernel", "vo::match_count_kernel", "vo::match_scatter_kernel"), min),
+                          (("vo::cell_bounds_kernel", "vo::cell_place_kernel", "vo::cell_offsets_kernel", "vo::cell_fine_kernel",
+                            "vo::cell_search_kernel<0>", "vo::match_count_kernel", "vo::match_scatter_kernel"), max)):
+        insts, util, why = b._pmc_valu(kernels, pick)
+        assert insts is not None and insts > 1e6 and 0.5 < util <= 1.0, (kernels, why)
+    r = b._valu_roofline(("vo::match_init_kernel", "vo::match_kernel<false>"), 0.6e-3, "test", min)
+    assert r["bound"] == "valu" and 0.3 < r["frac"] < 0.8                 # the full scan: about half the FP32 vector peak

@@ -99,3 +99,43 @@ def test_ragged_edge_cases(vo, ctx):
     assert len(got[0]) == 0 and len(got[3]) == 0 and got[1].tolist() == [[0, 0]]
     assert sorted(got[2].tolist()) == [[i, 19 - i] for i in range(20)]
     assert vo.match_batch_ragged(ctx, [], []) == []
+
+
+def test_ragged_frames_through_the_cell_hash_search(vo, o32):
+    """frames of different sizes AND roles through the sorted search (forced: mode 3; at these sizes the automatic choice is
+    the full scan): per-frame sizes down to empty and one-point images next to frames of thousands of points, on uniform and
+    clustered appearances -- every frame equal to the oracle"""
+    c = vo.Context(0)
+    assert c.lib.vo_match_set_mode(c.h, 3) == 0
+    rng = np.random.default_rng(23)
+    a1, a2 = [], []
+    for k, n in enumerate([3000, 1, 0, 2500, 700, 4096, 1792, 1793, 5000]):
+        base = rng.uniform(-1, 1, (max(n, 1), 10)).astype(np.float32)
+        if k % 3 == 2:                                         # clustered: most points in a few cells
+            base[: len(base) // 2] = (rng.normal(0.2, 0.02, (len(base) // 2, 10))).astype(np.float32)
+        x = base[:n]
+        perm = rng.permutation(n)
+        y = (x[perm].astype(np.float64) + rng.normal(0, 2e-3, (n, 10))).astype(np.float32)
+        extra = rng.uniform(-1, 1, (int(rng.integers(0, 400)), 10)).astype(np.float32)
+        if k % 2:
+            a1.append(np.concatenate([x, extra])); a2.append(y)       # the reference image is the larger set
+        else:
+            a1.append(x); a2.append(np.concatenate([y, extra]))
+    a2[2] = rng.uniform(-1, 1, (40, 10)).astype(np.float32)            # empty against non-empty
+    got = vo.match_batch_ragged(c, a1, a2)
+    for k in range(len(a1)):
+        exp = o32.match(a1[k], a2[k]) if len(a1[k]) and len(a2[k]) else np.zeros((0, 2), np.int32)
+        assert np.array_equal(got[k], exp), (k, len(a1[k]), len(a2[k]), len(got[k]), len(exp))
+    assert sum(len(g) for g in got) > 15000
+    c.close()
+
+
+def test_large_ragged_frames_pick_the_cell_hash_search_by_themselves(vo, ctx):
+    """10 frames of 20k..26k points with different sizes: the automatic choice is the sorted search; pairs = the generator's
+    permutation, and equal to every frame's own single-frame call"""
+    fps = [vo.synth.frame_pair(20000 + 700 * k, seed=880 + k) for k in range(10)]
+    got = vo.match_batch_ragged(ctx, [f["ref_app"] for f in fps], [f["cur_app"] for f in fps])
+    for k, f in enumerate(fps):
+        assert np.array_equal(got[k], f["gt_matches"]), k
+        if k in (0, 9):
+            assert np.array_equal(got[k], vo.compute_correspondences_images(f["ref_app"], f["cur_app"], ctx=ctx)), k

@@ -954,6 +954,13 @@ static int match_variant(const vo_ctx* c, int nt, int nq, int n_frames) {
   return (n_frames >= 8 && cells_ok) ? 3 : 2;
 }
 
+// frames of different sizes: the full scan, or -- from the sizes on where a sorted search pays -- the cell-hash search (its
+// workspace is then laid out for the larger capacity in both roles); the bucket-pruned scan takes one size only
+static int ragged_variant(const vo_ctx* c, int nt_cap, int q_cap, int n_frames) {
+  const int v = match_variant(c, nt_cap, q_cap, n_frames);
+  return (v == 1 || !match_cells_supported(nt_cap, nt_cap)) ? 1 : 3;
+}
+
 int vo_match_set_mode(vo_ctx* c, int mode) {
   VO_REQUIRE(c, "ctx is null");
   VO_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (auto), 1 (full scan), 2 (bucket-pruned scan) or 3 (cell-hash search)");
@@ -1020,9 +1027,9 @@ int vo_match_appearances_batch_dev(vo_ctx* c, int n_frames, const float* d_a1, i
   VO_HIP_CHECK(c->scratch.ensure(sizeof(int) * compaction_scratch_ints(q) * (size_t)n_frames, c->stream));
   VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)(q ? q : 1) * (size_t)n_frames, c->stream));
   const int nt = cap1 > cap2 ? cap1 : cap2;
-  const int variant = d_n1 ? 1 : match_variant(c, nt, q, n_frames);
+  const int variant = d_n1 ? ragged_variant(c, nt, q, n_frames) : match_variant(c, nt, q, n_frames);
   void* ws = nullptr;
-  if (q > 0) if (int r = match_workspace(c, variant, nt, q, n_frames, &ws)) return r;
+  if (q > 0) if (int r = match_workspace(c, variant, nt, d_n1 ? nt : q, n_frames, &ws)) return r;
   VO_HIP_CHECK(launch_match_batch(c->stream, d_a1, cap1, 10 * (size_t)cap1, d_a2, cap2, 10 * (size_t)cap2, radius, d_out_pairs,
                                   (size_t)q, d_n_out, c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, n_frames,
                                   variant, d_n1, d_n2));
@@ -1060,10 +1067,10 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
   VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)q * (size_t)F, c->stream));
   VO_HIP_CHECK(c->table.ensure(sizeof(unsigned long long) * (size_t)(b->n_ref ? b->n_ref : 1) * (size_t)F, c->stream));
   // ragged frames (sz): the counts of the struct are capacities (= strides), frame f holds sz->n_ref[f] / n_cur[f] points and
-  // n_model_pairs[f] model pairs; the matcher then runs its full scan with per-frame roles (vo_complete.cpp:15-20)
-  const int variant = sz ? 1 : match_variant(c, nt, q, F);
+  // n_model_pairs[f] model pairs; the matcher (full scan or cell-hash search) picks every frame's roles itself (vo_complete.cpp:15-20)
+  const int variant = sz ? ragged_variant(c, nt, q, F) : match_variant(c, nt, q, F);
   void* ws = nullptr;
-  if (int r = match_workspace(c, variant, nt, q, F, &ws)) return r;
+  if (int r = match_workspace(c, variant, nt, sz ? nt : q, F, &ws)) return r;
   int* n_match = b->counts;
   int* n_join = b->counts + F;
   int* n_tri = b->counts + 2 * (size_t)F;

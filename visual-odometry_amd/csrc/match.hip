@@ -779,7 +779,7 @@ static CellWs cell_ws_layout(int nt, int nq) {
   return w;
 }
 size_t match_cells_workspace_bytes(int nt, int nq, int n_frames) {
-  return (size_t)n_frames * cell_ws_layout(nt, nq).total;
+  return (size_t)n_frames * cell_ws_layout(nt, nq).total;   // (ragged frames: call with nt = nq = the larger capacity)
 }
 
 struct CellArgs {
@@ -794,7 +794,20 @@ struct CellArgs {
   int* rs_offsets;          // radius search: [nq + 1] counts, then (after the scan) offsets
   int32_t* rs_indices;      // radius search: tree indices, room for rs_capacity
   int rs_capacity;
+  const int* d_n1; const int* d_n2;   // ragged frames (or null): per-frame sizes of set 1 / set 2; tree / qry / nt / nq above are
+                                      //   then set 1 / set 2 and their capacities, and every frame picks its roles (cell_sets)
 };
+
+// the two sets of frame f with their roles: the larger one is the tree, set 1 on ties (vo_complete.cpp:15-20)
+__device__ __forceinline__ void cell_sets(const CellArgs& a, int f, const float*& tree, const float*& qry, int& nt, int& nq) {
+  tree = a.tree + f * a.tree_stride; qry = a.qry + f * a.qry_stride; nt = a.nt; nq = a.nq;
+  if (a.d_n1) {
+    int n1 = a.d_n1[f], n2 = a.d_n2[f];
+    n1 = n1 < 0 ? 0 : (n1 > a.nt ? a.nt : n1); n2 = n2 < 0 ? 0 : (n2 > a.nq ? a.nq : n2);
+    if (n1 >= n2) { nt = n1; nq = n2; }
+    else { const float* t = tree; tree = qry; qry = t; nt = n2; nq = n1; }
+  }
+}
 
 // XCD-aware decomposition of a 1-D grid of 8 * ceil(n_frames / 8) * per_frame workgroups.  Workgroups are dealt
 // round-robin over the 8 XCDs (observed; speed only, nothing depends on it), so giving every frame the workgroups of
@@ -854,14 +867,15 @@ __device__ __forceinline__ int scan512(int c0, int c1, int* s_w, int& total) {
 // grid bounds: one workgroup per frame, min/max per component over a strided sample of both sets -> CellParams
 __global__ __launch_bounds__(1024) void cell_bounds_kernel(CellArgs a) {
   const int f = blockIdx.x;
-  const float* tree = a.tree + f * a.tree_stride; const float* qry = a.qry + f * a.qry_stride;
+  const float* tree; const float* qry; int nt, nq;
+  cell_sets(a, f, tree, qry, nt, nq);
   __shared__ float s_lo[16][10], s_hi[16][10];
   __shared__ float s_flo[10], s_fhi[10], s_tmp[16];
   float lo[10], hi[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
-  const int st_t = (a.nt + CELL_SAMPLE - 1) / CELL_SAMPLE, st_q = (a.nq + CELL_SAMPLE - 1) / CELL_SAMPLE;
-  const int ns_t = st_t ? (a.nt + st_t - 1) / st_t : 0, ns_q = st_q ? (a.nq + st_q - 1) / st_q : 0;
+  const int st_t = (nt + CELL_SAMPLE - 1) / CELL_SAMPLE, st_q = (nq + CELL_SAMPLE - 1) / CELL_SAMPLE;
+  const int ns_t = st_t ? (nt + st_t - 1) / st_t : 0, ns_q = st_q ? (nq + st_q - 1) / st_q : 0;
   for (int i = threadIdx.x; i < ns_t + ns_q; i += 1024) {
     const float* row = i < ns_t ? tree + 10 * (size_t)i * st_t : qry + 10 * (size_t)(i - ns_t) * st_q;
     const float2* p = reinterpret_cast<const float2*>(row);
@@ -904,10 +918,13 @@ __global__ __launch_bounds__(256) void cell_place_kernel(CellArgs a) {
   if (!xcd_frame_block(a.tb + a.qb, a.n_frames, f, blk)) return;
   char* ws = a.ws + f * a.ws_stride;
   const bool is_t = blk < a.tb;
-  const int n_set = is_t ? a.nt : a.nq;
-  const int lo = (is_t ? blk : blk - a.tb) * CELL_SLICE;
+  const float* tree; const float* qry; int nt, nq;
+  cell_sets(a, f, tree, qry, nt, nq);
+  const int n_set = is_t ? nt : nq;
+  const int lo0 = (is_t ? blk : blk - a.tb) * CELL_SLICE;
+  const int lo = lo0 < n_set ? lo0 : n_set;                // (ragged frames: a slice beyond the frame's set is empty)
   const int hi = lo + CELL_SLICE < n_set ? lo + CELL_SLICE : n_set;
-  const float* src = is_t ? a.tree + f * a.tree_stride : a.qry + f * a.qry_stride;
+  const float* src = is_t ? tree : qry;
   __shared__ int s_h[HCPAD];
   __shared__ int s_w[4];
   __shared__ uint4 s_rec[CELL_SLICE];
@@ -1233,8 +1250,8 @@ __global__ __launch_bounds__(CS_THREADS, CS_THREADS * CS_WG_PER_CU / 256) void c
   const unsigned* __restrict__ tree_word = reinterpret_cast<const unsigned*>(ws + a.w.tree_word);
   const int* __restrict__ tree_idx = reinterpret_cast<const int*>(ws + a.w.tree_idx);
   const uint4* __restrict__ q1 = reinterpret_cast<const uint4*>(ws + a.w.q1);
-  const float* __restrict__ tree = a.tree + f * a.tree_stride;
-  const float* __restrict__ qry = a.qry + f * a.qry_stride;
+  const float* tree; const float* qry;
+  { int nt_f, nq_f; cell_sets(a, f, tree, qry, nt_f, nq_f); }
   unsigned long long* best = a.best + f * a.best_stride;
   // round trip 2: the first batch of query records (original index, filter word, box: written by level 1, which had the
   // row in registers anyway) beside the staging loads.  The query's floats are not touched before a survivor is decided.
@@ -1431,13 +1448,16 @@ __global__ __launch_bounds__(CS_THREADS, CS_THREADS * CS_WG_PER_CU / 256) void c
 
 static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tree, int nt, const float* qry, int nq,
                                     float radius, float r2, unsigned long long* d_best, void* ws, int n_frames,
-                                    size_t tree_stride, size_t qry_stride, size_t best_stride) {
+                                    size_t tree_stride, size_t qry_stride, size_t best_stride, const int* d_n1 = nullptr,
+                                    const int* d_n2 = nullptr) {
   a.tree = tree; a.qry = qry; a.nt = nt; a.nq = nq;
+  a.d_n1 = d_n1; a.d_n2 = d_n2;
   a.ws = static_cast<char*>(ws);
-  a.w = cell_ws_layout(nt, nq);
+  if (d_n1) { const int cap = nt > nq ? nt : nq; a.w = cell_ws_layout(cap, cap); }   // ragged: either set may play either role
+  else a.w = cell_ws_layout(nt, nq);
   a.ws_stride = a.w.total; a.tree_stride = tree_stride; a.qry_stride = qry_stride; a.best_stride = best_stride;
   a.n_frames = n_frames;
-  a.tb = cell_slices(nt); a.qb = cell_slices(nq);
+  a.tb = cell_slices(d_n1 ? (nt > nq ? nt : nq) : nt); a.qb = cell_slices(d_n1 ? (nt > nq ? nt : nq) : nq);
   a.radius = radius; a.r2 = r2; a.best = d_best;
   a.rs_offsets = nullptr; a.rs_indices = nullptr; a.rs_capacity = 0;
   const unsigned Z = (unsigned)n_frames;
@@ -1450,10 +1470,11 @@ static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tr
 
 static hipError_t launch_match_cells(hipStream_t st, const float* tree, int nt, const float* qry, int nq,
                                      float radius, float r2, unsigned long long* d_best, void* ws, int n_frames,
-                                     size_t tree_stride, size_t qry_stride, size_t best_stride) {
+                                     size_t tree_stride, size_t qry_stride, size_t best_stride, const int* d_n1 = nullptr,
+                                     const int* d_n2 = nullptr) {
   CellArgs a;
   hipError_t e = launch_cells_sort(st, a, tree, nt, qry, nq, radius, r2, d_best, ws, n_frames, tree_stride, qry_stride,
-                                   best_stride);
+                                   best_stride, d_n1, d_n2);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(cell_search_kernel<0>, dim3(xcd_grid(HNC * CS_STRIPS, n_frames)), dim3(CS_THREADS), 0, st, a);
   return hipGetLastError();
@@ -1482,11 +1503,16 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
                               unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws, int n_frames,
                               int variant, const int* d_n1, const int* d_n2) {
   if (d_n1 && d_n2) {
-    // ragged frames: every frame its own sizes and roles; full scan (the sorted searches lay their workspaces out for one
-    // size).  q = min(n1, n2) is the room per frame in d_best / d_out_pairs.
+    // ragged frames: every frame its own sizes and roles; full scan or (variant 3) the cell-hash search.
+    // q = min(n1, n2) is the room per frame in d_best / d_out_pairs.
     const int q = n1 < n2 ? n1 : n2;
     const float r2 = radius * radius;
-    if (q > 0) {
+    if (q > 0 && variant == 3 && d_prune_ws) {
+      // the cell-hash search with per-frame sizes and roles (workspace laid out for max(n1, n2) in both roles)
+      hipError_t ec = launch_match_cells(st, d_a1, n1, d_a2, n2, radius, r2, d_best, d_prune_ws, n_frames, a1_stride, a2_stride,
+                                         (size_t)q, d_n1, d_n2);
+      if (ec != hipSuccess) return ec;
+    } else if (q > 0) {
       hipLaunchKernelGGL(match_init_kernel, dim3((q + 255) / 256, 1, (unsigned)n_frames), dim3(256), 0, st, d_best, q, r2, (size_t)q);
       const int big = n1 > n2 ? n1 : n2;
       const int qblocks = (q + MB * QPT - 1) / (MB * QPT);      // either set may be the queries, but never more than q of them
