@@ -66,6 +66,7 @@ __device__ __forceinline__ float block_reduce_acc(float acc[NACC], float* s_red)
   return out;
 }
 
+// (rounds 1-2; -DVO_REDUCE_LDS builds it for A/B -- round 3 uses block_reduce_quad below: 4.70 -> 4.59 us per round)
 // Workgroup reduction of the round kernel (256 threads) through LDS only: on
 // the critical path (one wave per SIMD, ~5 cycles per issued instruction) the
 // instruction count matters more than LDS bandwidth.  Every thread stores its
@@ -97,6 +98,53 @@ __device__ __forceinline__ float block_reduce_lds256(const float acc[NACC], floa
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < 32; ++j) s += src[j * ACC_STRIDE];
+  s_part[part * 32 + slot] = s;
+  __syncthreads();
+  float out = 0.f;
+  if (tid < 32) {
+#pragma unroll
+    for (int g = 0; g < PICP_PARTS; ++g) out += s_part[g * 32 + tid];
+  }
+  return out;
+}
+
+// The same reduction with a quad pre-reduction in registers: two DPP adds per accumulator leave every quad's sum in its four
+// lanes, lane q of the quad then stores accumulators 8q .. 8q+7 -- TWO 16-byte LDS writes per lane instead of eight (a
+// ds_write_b128 costs ~13 cycles of the wave's LDS path whatever it holds, and the four waves share that path) -- and the
+// first stage adds 8 rows per part instead of 32.  Rows: one per quad (PICP_BLOCK / 4), stride ACC_STRIDE.  Fixed order:
+// bitwise reproducible, and the same function serves the round kernels and the one-launch small-problem kernel.
+__device__ __forceinline__ float block_reduce_quad(float acc[NACC], float* s_acc, float* s_part) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    acc[k] += dpp_mov<0xB1>(acc[k]);    // quad_perm [1,0,3,2]
+    acc[k] += dpp_mov<0x4E>(acc[k]);    // quad_perm [2,3,0,1]
+  }
+  const int q = tid & 3;
+  const bool q1 = q == 1, q2 = q == 2, q3 = q == 3;
+  float w[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    // (the operands are made opaque: the compiler turns a select chain over acc[8q + j] into an INDEXED read of acc[],
+    // i.e. parks the accumulators in scratch memory)
+    float a0 = acc[j], a1 = acc[8 + j], a2 = acc[16 + j], a3 = 24 + j < NACC ? acc[24 + j < NACC ? 24 + j : 0] : 0.f;
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    float v = a0;
+    v = q1 ? a1 : v;
+    v = q2 ? a2 : v;
+    v = q3 ? a3 : v;
+    w[j] = v;
+  }
+  float4* row = reinterpret_cast<float4*>(s_acc + (tid >> 2) * ACC_STRIDE + 8 * q);
+  row[0] = make_float4(w[0], w[1], w[2], w[3]);
+  row[1] = make_float4(w[4], w[5], w[6], w[7]);
+  __syncthreads();
+  constexpr int ROWS_PER_PART = (PICP_BLOCK / 4) / PICP_PARTS;      // 8
+  const int slot = tid & 31, part = tid >> 5;
+  const float* src = s_acc + (part * ROWS_PER_PART) * ACC_STRIDE + slot;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < ROWS_PER_PART; ++j) s += src[j * ACC_STRIDE];
   s_part[part * 32 + slot] = s;
   __syncthreads();
   float out = 0.f;
@@ -512,7 +560,11 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     picp_accumulate_t<PINHOLE, KEEP>(cam, T, thr, cx, cy, cz, cu, cv, acc);
   }
   VO_STAMP(4);
+#ifdef VO_REDUCE_LDS
   const float tot = block_reduce_lds256(acc, s_acc, s_part);
+#else
+  const float tot = block_reduce_quad(acc, s_acc, s_part);
+#endif
   VO_STAMP(5);
   if (tid < PICP_PSTRIDE) {
     float o = tot;   // slot 29 (inlier count) is an exact integer in float: < 2^24 correspondences
@@ -598,7 +650,11 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_small_kernel(const PicpParams
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
     if (have) picp_accumulate_t<PINHOLE, KEEP>(cam, T, thr, x, y, z, u, v, acc);
+#ifdef VO_REDUCE_LDS
     const float tot = block_reduce_lds256(acc, s_acc, s_part);
+#else
+    const float tot = block_reduce_quad(acc, s_acc, s_part);
+#endif
     if (tid < 32) s_tot[tid] = tid < NACC ? tot : 0.f;
     __syncthreads();
     // every wave builds the system and solves it on its own (as step (4) of picp_round_body)
