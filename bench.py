@@ -71,6 +71,8 @@ def launch_ranks(args):
     import subprocess
     import torch                                     # device_count() does not initialise the GPU on this image
     have = torch.cuda.device_count()
+    if os.environ.get("VO_BENCH_SHARE_GPU") == "1":  # rehearsal: all ranks on device 0 (see main)
+        have = max(have, args.gpus) if have > 0 else 0
     if have < args.gpus:
         print(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have}", file=sys.stderr)
         return 2
@@ -105,14 +107,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (or plain `python bench.py --gpus N`)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # REHEARSAL of the N-rank path on a box with ONE GPU (VO_BENCH_SHARE_GPU=1): every rank drives device 0 and the collectives
+    # go through gloo (RCCL refuses two ranks on one device; dist.gather_poses stages through the host then).  Sharding,
+    # padding, gathers and slice checks are exactly the N-GPU code; the rates are NOT scaling numbers (the ranks share a chip)
+    # and the line says so.
+    share_gpu = os.environ.get("VO_BENCH_SHARE_GPU") == "1"
+    gpu_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     # under torch.distributed.run (RANK set) the RCCL path runs even with one rank, so that a
     # 1-GPU box exercises exactly the code the N-GPU launch uses
-    dist = vdist.init("nccl", local_rank) if (world > 1 or "RANK" in os.environ) else None
+    dist = vdist.init("gloo" if share_gpu else "nccl", gpu_index) if (world > 1 or "RANK" in os.environ) else None
 
     stream = torch.cuda.Stream(device=dev)
-    ctx = vo.Context(local_rank, stream.cuda_stream)
+    ctx = vo.Context(gpu_index, stream.cuda_stream)
     dev_name, n_cu = ctx.device_info()
     lib = ctx.lib
 
@@ -169,6 +177,7 @@ def main():
     alg_bytes = BYTES_PER_CORR_ITER * args.points
     achieved = alg_bytes / (per_round_us * 1e-6) / 1e9
     out = {
+        **({"rehearsal": "VO_BENCH_SHARE_GPU=1: all ranks on ONE GPU, gloo collectives -- not a scaling measurement"} if share_gpu else {}),
         "metric": "PICP iterations/sec @50k pts",
         "value": value, "unit": "iter/s", "n_gpus": world, "ranks_seen": (dist.get_world_size() if dist is not None else 1),
         "steps": args.steps, "warmup": args.warmup,

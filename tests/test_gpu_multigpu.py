@@ -45,3 +45,21 @@ def test_bench_self_launch_route_with_one_rank():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["ranks_seen"] == 1 and d["batched_frames"]["frames_total"] == 200
     assert d["batched_frames_strong"]["pairs_total"] == 12 and d["batched_frames_strong"]["calls_per_pass"] == 3
+
+
+def test_two_ranks_rehearsed_on_the_one_gpu():
+    """`python bench.py --gpus 2` end to end with TWO ranks -- both on this box's one GPU (VO_BENCH_SHARE_GPU=1: gloo collectives
+    staged through the host, because RCCL refuses two ranks on one device): the self-launch, the per-rank sharding (13 pairs =
+    7 + 6: padded blocks), both gathers and every slice check run exactly as they will on a multi-GPU node.  The rates are not
+    scaling numbers and the line says so."""
+    env = dict(os.environ, VO_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--points", "4000",
+                        "--legs", "frame", "--frame-steps", "2", "--strong-pairs", "13", "--strong-per-call", "4", "--gen-workers", "1"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and "rehearsal" in d
+    assert d["value"] > 10000 and d["pose_err_vs_gt"] < 1e-3
+    assert d["batched_frames"]["frames_total"] == 400 and d["batched_frames"]["n_gpus"] == 2
+    s = d["batched_frames_strong"]
+    assert s["pairs_total"] == 13 and s["pairs_this_rank"] == 7 and s["calls_per_pass"] == 2 and s["n_gpus"] == 2

@@ -70,6 +70,12 @@ def gather_poses(local_poses):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
+    if dist.get_backend() == "gloo" and local_poses.is_cuda:
+        # rehearsal on a shared GPU (bench.py, VO_BENCH_SHARE_GPU=1): gloo gathers host tensors
+        host = local_poses.detach().contiguous().cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        return torch.cat(parts, 0).to(local_poses.device)
     out = torch.empty((world * local_poses.shape[0],) + tuple(local_poses.shape[1:]),
                       dtype=local_poses.dtype, device=local_poses.device)
     dist.all_gather_into_tensor(out, local_poses.contiguous())
@@ -79,6 +85,8 @@ def gather_poses(local_poses):
 def max_over_ranks(value: float, device) -> float:
     import torch
     import torch.distributed as dist
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
