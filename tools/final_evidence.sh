@@ -10,4 +10,4 @@ tools/collect_profiles.sh $TAG > gpurun_out/${TAG}_collect.log 2>&1
 tools/prof_headline.sh ${TAG}h 200 | tail -4
 tools/pmc_frames.sh $TAG 200 > gpurun_out/${TAG}_sq_frames.txt
 head -8 gpurun_out/${TAG}_sq_frames.txt
-tools/run_fuzz_campaigns.sh ${TAG}b $FZ 71
+tools/run_fuzz_campaigns.sh ${TAG}c $FZ 91

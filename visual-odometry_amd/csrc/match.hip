@@ -611,18 +611,18 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
 // nc_k = clamp(floor(spread_k / R), 1, 20) cells of width >= R each (R = 1.001 radius).  The spreads come
 // from a strided SAMPLE of both sets (<= CELL_SAMPLE points each): any bounds give a correct grid, because
 // the cell function is monotone and clamps -- points beyond the sampled range fall into the edge cells.
-// The tree is counting-sorted by the cell key ((c0*nc1 + c1)*nc2 + c2)*nc3 + c3 (<= 160 000 cells) in two
-// levels, both on LDS histograms (a global atomic per point -- 64 scattered memory-side requests per wave --
-// was 2x dearer):
+// The tree is counting-sorted by cell -- coarse bin (c0, c1), numbered c0 * 20 + c1 whatever the grid, then fine bin
+// (c2, c3) = c2 * nc3 + c3 inside it (<= 160 000 cells) -- in two levels, both on LDS histograms (a global atomic per
+// point -- 64 scattered memory-side requests per wave -- was 2x dearer):
 //   level 1 (cell_place_kernel, ONE pass over the input rows): the sets are cut into slices of CELL_SLICE points; a
 //     workgroup reads its slice once, orders its records by the <= 400 coarse bins (c0, c1) in LDS and writes them back
 //     as one contiguous run, together with a directory row (count, offset) per bin.  (Round 2 histogrammed the rows in a
 //     first pass only to learn where every workgroup's records go, then read them again to place them: 0.19 ms of the
 //     1.6 ms chain per 200 x 50k frames, bound by touching every 40-B row a second time.)
 //   offsets (cell_offsets_kernel): column sums of the directory and their scan -> first slot of every coarse bin.
-//   level 2 (cell_fine_kernel): one workgroup per coarse bin GATHERS its points from the slices' runs (directory column),
-//     orders them by the <= 400 fine bins (c2, c3) in LDS and writes that bin's slice of the sorted tree and of the start
-//     table; the same workgroup copies the bin's query indices from their runs into one contiguous list.
+//   level 2 (cell_fine_kernel): one workgroup per group of FG consecutive coarse bins GATHERS their points from the slices'
+//     runs (directory columns), orders them by (bin, fine bin) in LDS and writes the group's slice of the sorted tree and of
+//     the start tables; the same workgroup copies the group's query records from their runs into one list per bin.
 // A sorted tree point is 8 bytes: its original index and the FILTER WORD -- components 0..3 quantised to 8 bits each
 // (see quant8 / the filter's proof below).  The search never reads a float of the tree before it has a survivor.
 //
