@@ -1009,10 +1009,13 @@ __global__ __launch_bounds__(HCPAD) void cell_offsets_kernel(CellArgs a) {
 // cannot express its slots): written for such bins only.  Bit 15 of a 16-bit entry says "a run of <= 3 cells starting
 // here holds more than 4 points": the search's first pass looks at four candidates per run and leaves such runs to its
 // second pass.
-constexpr int FG = 5;                    // coarse bins per level-2 workgroup (HNC is a multiple)
-constexpr int FINE_PPT = 4;              // tree records per thread kept in registers between counting and placing
-constexpr int FINE_QPT = 4;              // query records per thread
-constexpr int FCNT = 2048;               // counters: FG * n_fine <= 2000
+#ifndef VO_FG
+#define VO_FG 5
+#endif
+constexpr int FG = VO_FG;                // coarse bins per level-2 workgroup (HNC is a multiple)
+constexpr int FINE_PPT = FG <= 5 ? 4 : 8;   // tree records per thread kept in registers between counting and placing
+constexpr int FINE_QPT = FG <= 5 ? 4 : 8;   // query records per thread
+constexpr int FCNT = FG <= 5 ? 2048 : 4096; // counters: FG * n_fine <= FG * 400
 static_assert(HNC % FG == 0 && FG * HCOARSE <= FCNT, "");
 __global__ __launch_bounds__(256) void cell_fine_kernel(CellArgs a) {
   int f, grp;
