@@ -139,3 +139,34 @@ def test_large_ragged_frames_pick_the_cell_hash_search_by_themselves(vo, ctx):
         assert np.array_equal(got[k], f["gt_matches"]), k
         if k in (0, 9):
             assert np.array_equal(got[k], vo.compute_correspondences_images(f["ref_app"], f["cur_app"], ctx=ctx)), k
+
+
+def test_ragged_argument_checks_and_clamping(vo, ctx):
+    """the ragged entry points refuse inconsistent arguments before touching the stream, and per-frame sizes beyond the
+    capacity / below zero are clamped instead of read past the arrays"""
+    lib, h = ctx.lib, ctx.h
+    rng = np.random.default_rng(9)
+    a = rng.uniform(-1, 1, (3, 40, 10)).astype(np.float32)
+    b = a[:, ::-1].copy()
+    d_a, d_b = ctx.to_device(a), ctx.to_device(b)
+    d_out, d_cnt = ctx.alloc(3 * 40 * 8), ctx.alloc(3 * 4)
+    d_n = ctx.to_device(np.array([40, 10, 0], np.int32))
+    NUL = C.c_void_p(0)
+    call = lambda F, pa, c1, n1, pb, c2, n2, po, pc: lib.vo_match_appearances_batch_dev(
+        h, C.c_int(F), pa, C.c_int(c1), n1, pb, C.c_int(c2), n2, C.c_float(0.1), po, pc)
+    A, B, O, CN, N = (C.c_void_p(x) for x in (d_a, d_b, d_out, d_cnt, d_n))
+    assert call(3, A, 40, N, B, 40, NUL, O, CN) < 0            # one size array without the other
+    assert call(-1, A, 40, N, B, 40, N, O, CN) < 0
+    assert call(70000, A, 40, N, B, 40, N, O, CN) < 0
+    assert call(3, NUL, 40, N, B, 40, N, O, CN) < 0 and call(3, A, 40, N, B, 40, N, NUL, CN) < 0 and call(3, A, 40, N, B, 40, N, O, NUL) < 0
+    assert call(0, NUL, 0, NUL, NUL, 0, NUL, NUL, CN) == 0      # nothing to do
+    assert lib.vo_frames_batch_ragged_dev(h, NUL, NUL) < 0
+    # sizes beyond the capacity and below zero: clamped to [0, cap]
+    d_big = ctx.to_device(np.array([1000, -5, 40], np.int32))
+    assert call(3, A, 40, C.c_void_p(d_big), B, 40, C.c_void_p(d_big), O, CN) == 0
+    cnt = np.zeros(3, np.int32); ctx.d2h(cnt, d_cnt)
+    assert cnt.tolist() == [40, 0, 40]
+    out = np.zeros((3, 40, 2), np.int32); ctx.d2h(out, d_out)
+    assert sorted(out[0].tolist()) == [[i, 39 - i] for i in range(40)]
+    for d in (d_a, d_b, d_out, d_cnt, d_n, d_big):
+        ctx.free(d)
