@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("tool,seed,seconds", [("fuzz_operators", 101, 20), ("fuzz_chains", 102, 20),
-                                                ("fuzz_fast_solver", 103, 20), ("fuzz_search", 104, 15)])
+                                                ("fuzz_fast_solver", 103, 20), ("fuzz_search", 104, 15), ("fuzz_ragged", 105, 15)])
 def test_fuzz_slice(tool, seed, seconds):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool + ".py"), str(seed), str(seconds)],
                        capture_output=True, text=True, timeout=600)
@@ -26,5 +26,5 @@ def test_fuzz_slice(tool, seed, seconds):
     assert "FAIL" not in r.stdout, r.stdout[-3000:]
     m = re.search(r"failures\s+(\d+)", r.stdout)
     assert m and int(m.group(1)) == 0, r.stdout[-2000:]
-    n = [int(x) for x in re.findall(r"(?:iterations|sequences|batches|single problems|cases) (\d+)", r.stdout)]
+    n = [int(x) for x in re.findall(r"(?:iterations|sequences|batches|single problems|cases|matcher calls|frame calls) (\d+)", r.stdout)]
     assert n and max(n) >= 5, r.stdout[-500:]                      # the slice really ran cases
