@@ -21,7 +21,9 @@
  *    are copied to the GPU, outputs copied back, and the call returns when the
  *    outputs are valid.  *_dev variants take DEVICE pointers (memory from
  *    vo_dev_alloc or any hipMalloc), enqueue on the context's stream and do not
- *    synchronise; counts are then produced in device memory.
+ *    synchronise; counts are then produced in device memory.  Device arrays
+ *    must start on an 8-byte boundary (hipMalloc gives 256; a sub-array at an
+ *    even element offset keeps it): rows and index pairs move as 8-byte pieces.
  *  - a vo_ctx and the handles created from it must be used by one host thread
  *    at a time (the reference objects are not thread-safe either).
  *  - there is NO CPU fallback: every entry point fails with VO_ERR_NO_DEVICE if

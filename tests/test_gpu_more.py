@@ -456,3 +456,26 @@ def test_batched_frames_are_bitwise_reproducible_run_to_run(vo):
         seen.add(h.hexdigest())
     bp.close(); c.close()
     assert len(seen) == 1
+
+
+def test_device_arrays_off_an_8_byte_boundary_are_refused(vo, ctx):
+    """vo_hip.h, Conventions: rows and index pairs move as 8-byte pieces, so a device array that starts 4 bytes into one is
+    an argument error (reported before any launch), not a slow path."""
+    lib = ctx.lib
+    n = 64
+    d_a = ctx.alloc(40 * n + 16)
+    d_out = ctx.alloc(8 * n + 16)
+    d_cnt = ctx.alloc(16)
+    try:
+        ok = lib.vo_match_appearances_dev(ctx.h, C.c_void_p(d_a), C.c_int(n), C.c_void_p(d_a), C.c_int(n), C.c_float(0.1),
+                                          C.c_void_p(d_out), C.c_void_p(d_cnt))
+        assert ok == 0
+        ctx.synchronize()
+        for a1, out in ((d_a + 4, d_out), (d_a, d_out + 4)):
+            rc = lib.vo_match_appearances_dev(ctx.h, C.c_void_p(a1), C.c_int(n), C.c_void_p(d_a), C.c_int(n), C.c_float(0.1),
+                                              C.c_void_p(out), C.c_void_p(d_cnt))
+            assert rc == -1                                            # VO_ERR_INVALID_ARG
+            assert b"8-byte" in lib.vo_last_error()
+    finally:
+        for p in (d_a, d_out, d_cnt):
+            ctx.free(p)

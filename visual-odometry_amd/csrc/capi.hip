@@ -44,6 +44,10 @@ void set_error_v(const char* fmt, va_list ap) { vsnprintf(g_err, sizeof(g_err), 
 #define VO_REQUIRE(cond, msg) \
   do { if (!(cond)) return fail(VO_ERR_INVALID_ARG, "%s: %s", __func__, msg); } while (0)
 
+// device arrays move as 8-byte pieces (vo_hip.h, Conventions): true when every pointer given is null or on such a boundary
+template <typename... P>
+static bool aligned8(const P*... p) { return ((... | reinterpret_cast<uintptr_t>(p)) & 7u) == 0; }
+
 // entry points that copy host memory or wait for the stream cannot be part of a graph capture (vo_ctx_begin_capture): refused
 // BEFORE any HIP call, because a refused HIP call would invalidate the capture in progress
 #define VO_NOT_CAPTURING(ctx) \
@@ -973,6 +977,7 @@ int vo_match_appearances_dev(vo_ctx* c, const float* d_a1, int n1, const float* 
   VO_REQUIRE(c && d_n_out, "null argument");
   VO_REQUIRE(n1 >= 0 && n2 >= 0, "negative count");
   VO_REQUIRE((n1 == 0 || d_a1) && (n2 == 0 || d_a2), "null appearance array");
+  VO_REQUIRE(aligned8(d_a1, d_a2, d_out_pairs), "device array not on an 8-byte boundary");
   const int nq = n1 < n2 ? n1 : n2;
   VO_REQUIRE(nq == 0 || d_out_pairs, "null output");
   if (int r = set_device(c)) return r;
@@ -1023,6 +1028,7 @@ int vo_match_appearances_batch_dev(vo_ctx* c, int n_frames, const float* d_a1, i
   VO_REQUIRE((d_n1 == nullptr) == (d_n2 == nullptr), "per-frame sizes: give both arrays or neither");
   const int q = cap1 < cap2 ? cap1 : cap2;
   VO_REQUIRE((cap1 == 0 || d_a1) && (cap2 == 0 || d_a2) && (q == 0 || d_out_pairs), "null device array");
+  VO_REQUIRE(aligned8(d_a1, d_a2, d_out_pairs), "device array not on an 8-byte boundary");
   if (int r = set_device(c)) return r;
   VO_HIP_CHECK(c->scratch.ensure(sizeof(int) * compaction_scratch_ints(q) * (size_t)n_frames, c->stream));
   VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)(q ? q : 1) * (size_t)n_frames, c->stream));
@@ -1060,6 +1066,8 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
   VO_REQUIRE(q > 0 && b->n_model > 0, "empty frames");
   VO_REQUIRE(b->ref_app && b->cur_app && b->ref_pts && b->cur_pts && b->model && b->model_pairs, "null input array");
   VO_REQUIRE(b->matches && b->joined && b->poses && b->tri_xyz && b->tri_pairs && b->counts, "null output array");
+  VO_REQUIRE(aligned8(b->ref_app, b->cur_app, b->ref_pts, b->cur_pts, b->model_pairs, b->matches, b->joined, b->tri_pairs, b->tri_app),
+             "device array not on an 8-byte boundary");
   if (int r = set_device(c)) return r;
   const int nt = b->n_ref > b->n_cur ? b->n_ref : b->n_cur;
   const size_t cs = compaction_scratch_ints(q);
@@ -1118,6 +1126,7 @@ int vo_join_correspondences_dev(vo_ctx* c, const int32_t* d_img, int n_img, cons
   VO_REQUIRE(c && d_n_out, "null argument");
   VO_REQUIRE(n_img >= 0 && n_world >= 0 && n_ref >= 0, "negative count");
   VO_REQUIRE((n_img == 0 || (d_img && d_out)) && (n_world == 0 || d_world), "null pair array");
+  VO_REQUIRE(aligned8(d_img, d_world, d_out), "device array not on an 8-byte boundary");
   if (int r = set_device(c)) return r;
   if (int r = ensure_scratch(c, n_img)) return r;
   VO_HIP_CHECK(c->table.ensure(sizeof(unsigned long long) * (size_t)(n_ref ? n_ref : 1), c->stream));
@@ -1226,6 +1235,7 @@ int vo_triangulate_dev(vo_ctx* c, const float K[9], const float X[16], const flo
   VO_REQUIRE(X || d_X16, "no pose given");
   VO_REQUIRE(n >= 0 && n1 >= 0 && n2 >= 0, "negative count");
   VO_REQUIRE(n == 0 || (d_pairs && d_p1 && d_p2 && d_out_xyz), "null device array");
+  VO_REQUIRE(aligned8(d_pairs, d_p1, d_p2, d_app2, d_out_app) && aligned8(d_out_pairs), "device array not on an 8-byte boundary");
   if (int r = set_device(c)) return r;
   if (int r = ensure_scratch(c, n)) return r;
   Pose Xp;

@@ -340,17 +340,17 @@ __global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a0) {
   if (k < n) ok = tri_eval(a, s_c, k, i2, p);
   int total;
   const int r = block_rank(ok, s_wave, total);
+  __shared__ int s_src[CB];
   if (ok) {
     const size_t dst = (size_t)a.counts[fb.b] + r;
     a.out_xyz[3 * dst] = p[0]; a.out_xyz[3 * dst + 1] = p[1]; a.out_xyz[3 * dst + 2] = p[2];
-    if (a.out_pairs) { a.out_pairs[2 * dst] = i2; a.out_pairs[2 * dst + 1] = (int)dst; }   // utils.cpp:97
+    if (a.out_pairs) reinterpret_cast<int2*>(a.out_pairs)[dst] = make_int2(i2, (int)dst);     // utils.cpp:97
+    s_src[r] = i2;
   }
+  __syncthreads();
   if (a.out_app && a.app2) {                                                                 // utils.cpp:127
-    // appearance copy-through, cooperatively: the survivors' source indices go through LDS in output order, then
-    // consecutive threads move consecutive 8-byte pieces (coalesced stores, 40-byte gathers)
-    __shared__ int s_src[CB];
-    if (ok) s_src[r] = i2;
-    __syncthreads();
+    // appearance copy-through, cooperatively: consecutive threads move consecutive 8-byte pieces of the survivors' rows
+    // (coalesced stores, 40-byte gathers)
     const float2* app = reinterpret_cast<const float2*>(a.app2);
     float2* o = reinterpret_cast<float2*>(a.out_app) + 5 * (size_t)a.counts[fb.b];
     for (int j = threadIdx.x; j < 5 * total; j += CB) {
