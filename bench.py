@@ -571,8 +571,8 @@ def sequence_leg(vo, ctx, args):
     t0 = time.perf_counter()
     seq = vo.synth.sequence(seed=3000, n_frames=args.seq_frames, n_visible=args.seq_points)
     t_gen = time.perf_counter() - t0
-    def timed(overlap):
-        sp = vo.SequencePipeline(ctx, seq, n_iters=args.seq_iters, overlap_match=overlap)
+    def timed(overlap, prematch=False):
+        sp = vo.SequencePipeline(ctx, seq, n_iters=args.seq_iters, overlap_match=overlap, prematch=prematch)
         sp.run(); ctx.synchronize()                  # warm-up pass: sizes every workspace, builds the solver graph
         t0 = time.perf_counter()
         sp.start(); ctx.synchronize()
@@ -581,13 +581,19 @@ def sequence_leg(vo, ctx, args):
             sp.step(t)
         ctx.synchronize()
         t2 = time.perf_counter()
-        res = (sp.trajectory(), sp.counts(), t1 - t0, t2 - t1, sp.F)
+        res = [sp.trajectory(), sp.counts(), t1 - t0, t2 - t1, sp.F]
+        if prematch:                                  # the one batched matcher call on its own
+            ctx.synchronize(); t3 = time.perf_counter()
+            sp.match_all(); ctx.synchronize()
+            res.append(time.perf_counter() - t3)
         sp.close()
         return res
 
     traj, counts, init_s, chain_s, F = timed(False)
     traj2, counts2, _, chain2, _ = timed(True)
     assert np.array_equal(traj, traj2) and np.array_equal(counts, counts2), "overlapped matcher changed the result"
+    traj3, counts3, init3, chain3, _, match_all_s = timed(False, prematch=True)
+    assert np.array_equal(traj, traj3) and np.array_equal(counts, counts3), "matching up front changed the result"
     m = _sequence_metrics(vo, seq, traj)
     n = [len(f["pts"]) for f in seq["frames"]]
     return {"frames": F, "points_per_frame": {"min": int(min(n)), "max": int(max(n))}, "landmarks": len(seq["world_xyz"]),
@@ -596,6 +602,11 @@ def sequence_leg(vo, ctx, args):
             "ms_per_frame": chain_s * 1e3 / (F - 2),
             "picp_iters_per_sec": (F - 2) * args.seq_iters / chain_s,
             "frames_per_sec_matcher_on_second_stream": (F - 2) / chain2,
+            "matched_up_front": {"frames_per_sec": (F - 2) / (chain3 + match_all_s), "chain_ms": chain3 * 1e3,
+                                 "match_all_ms": match_all_s * 1e3, "init_ms": init3 * 1e3,
+                                 "note": "all F-1 pairs matched by one vo_match_appearances_batch_dev call at the start (the "
+                                         "matcher needs the appearances alone; vo_complete has every measurement file on "
+                                         "hand); the whole call is charged to the F-2 chained frames; identical results"},
             "joined_per_frame": {"min": int(counts[2:, 1].min()), "max": int(counts[2:, 1].max())},
             "accuracy_vs_ground_truth": m, "generate_s": t_gen,
             "note": "init = match + vo_estimate_transform (host 8-point, once) + triangulate of the first pair; "

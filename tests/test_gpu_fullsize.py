@@ -108,6 +108,11 @@ def test_sequence_200x50k_is_bit_identical_to_ref32(vo, ctx, o32, n_frames):
     # joined pairs follow the previous frame's triangulation, whose cheirality test sees a pose that differs in the
     # last bits: a borderline point may flip
     assert np.abs(c_fast[:, 1:] - counts[:, 1:]).max() <= 8
+    # all 199 pairs matched up front by one batched call (cell-hash search at this size): the same chain, bit for bit
+    sp = vo.SequencePipeline(ctx, seq, n_iters=100, prematch=True)
+    sp.run()
+    assert np.array_equal(sp.counts(), c_fast) and np.array_equal(sp.trajectory(), t_fast)
+    sp.close()
     # rounding-level differences of one frame's pose scale the next frame's model: over 200 chained frames they grow to ~2e-3
     assert np.abs(np.array(t_fast) - np.array(traj)).max() < 5e-3 and np.abs(np.array(t_fast[:40]) - np.array(traj[:40])).max() < 5e-4
 

@@ -169,6 +169,24 @@ def test_overlapped_matcher_gives_identical_chain(vo, ctx, seq_run):
     assert ctx.lib.vo_event_record(None, ctx.h) == -1
 
 
+def test_sequence_matched_up_front_gives_identical_chain(vo, ctx, seq_run):
+    """prematch=True matches every consecutive pair of the sequence in ONE ragged batched call at start()
+    (vo_match_appearances_batch_dev; the frames hold different numbers of points) and the chain reads pairs
+    and counts where that call left them: counts, poses and clouds bit-identical to the frame-by-frame chain, twice."""
+    seq, d, res, P = seq_run
+    a = vo.SequencePipeline(ctx, seq, n_iters=ROUNDS)
+    a.run()
+    ta, ca, cloud_a = a.trajectory(), a.counts(), a.cloud(a.F - 1)
+    a.close()
+    b = vo.SequencePipeline(ctx, seq, n_iters=ROUNDS, prematch=True)
+    for _ in range(2):
+        b.run()
+        assert np.array_equal(b.counts(), ca) and np.array_equal(b.trajectory(), ta)
+        cloud_b = b.cloud(b.F - 1)
+        assert np.array_equal(cloud_b[0], cloud_a[0]) and np.array_equal(cloud_b[1], cloud_a[1])
+    b.close()
+
+
 def test_cpp_resident_sequence_equals_frame_by_frame(vo, seq_run, tmp_path):
     """apps/vo_complete --resident (vo::DeviceSequence: whole chain on the GPU, map built afterwards) writes the
     same trajectory and map files as the frame-by-frame facade loop, and the same trajectory as SequencePipeline."""

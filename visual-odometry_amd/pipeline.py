@@ -368,8 +368,13 @@ class SequencePipeline:
     (PointCloudVector::update) is host code in the C++ application and not part of this chain."""
 
     def __init__(self, ctx: Context, seq: dict, n_iters: int = 100, kernel_threshold: float = 10000.0,
-                 keep_appearance: bool = False, matches: list | None = None, overlap_match: bool = False, exact: bool = False):
-        """exact: the solver in reference-order arithmetic (vo_picp_set_exact): the whole chain is then bit-identical to the
+                 keep_appearance: bool = False, matches: list | None = None, overlap_match: bool = False, exact: bool = False,
+                 prematch: bool = False):
+        """prematch: the matcher depends on the appearances alone, so when the whole sequence is on hand -- as it
+        is for vo_complete, which reads its measurement files from a directory -- all F-1 consecutive pairs are matched by ONE
+        vo_match_appearances_batch_dev call at start() (frames of different sizes, per-frame tree choice as in the single
+        call), and the chain reads frame t's pairs and count where that call left them.  Same pairs in the same order.
+        exact: the solver in reference-order arithmetic (vo_picp_set_exact): the whole chain is then bit-identical to the
         float32 CPU restatement of the loop started from the same first relative pose.
         matches: optional precomputed appearance matches, matches[t-1] = (n,2) int32 pairs
         (idx in frame t-1, idx in frame t) for t = 1..F-1 -- e.g. computed up front, sharded over several
@@ -395,7 +400,17 @@ class SequencePipeline:
         self.d_app = up(np.ascontiguousarray(np.concatenate([f["app"] for f in fr]), np.float32))
         cap, F = self.cap, self.F
         self.d_m, self.d_j, self.d_model_t = a(cap * 8), a(cap * 8), a(cap * 12)
-        self.overlap = bool(overlap_match) and matches is None
+        self.overlap = bool(overlap_match) and matches is None and not prematch
+        self.prematch = bool(prematch) and matches is None
+        if self.prematch:
+            # the batched call strides the frames by the capacity: a padded copy of the appearances ([F][cap][10]; the pairs
+            # (t-1, t) are then two views of it, one frame apart), the sizes, and room for every frame's pairs and count
+            pad = np.zeros((self.F, self.cap, 10), np.float32)
+            for t, f in enumerate(fr):
+                pad[t, : self.n[t]] = f["app"]
+            self.d_app_pad = up(pad)
+            self.d_n_all = up(np.asarray(self.n, np.int32))
+            self.d_pm, self.d_pm_cnt = a((self.F - 1) * self.cap * 8), a((self.F - 1) * 4)
         if self.overlap:
             self.ctx2 = Context(ctx.device)                   # second stream of the same device
             self.d_mb = [self.d_m, a(cap * 8)]               # matches of frame t live in buffer t % 2
@@ -432,7 +447,10 @@ class SequencePipeline:
     # device addresses of frame t's inputs / outputs
     def _pts(self, t): return C.c_void_p(self.d_pts + 8 * int(self.off[t]))
     def _app(self, t): return C.c_void_p(self.d_app + 40 * int(self.off[t]))
-    def _cnt(self, t, i): return C.c_void_p(self.d_counts + 4 * (3 * t + i))
+    def _cnt(self, t, i):
+        if i == 0 and self.prematch:
+            return C.c_void_p(self.d_pm_cnt + 4 * (t - 1))
+        return C.c_void_p(self.d_counts + 4 * (3 * t + i))
     def _xyz(self, t): return C.c_void_p(self.d_tri_xyz + 12 * self.cap * t)
     def _pairs(self, t): return C.c_void_p(self.d_tri_pairs + 8 * self.cap * t)
     def _tapp(self, t): return C.c_void_p(self.d_tri_app + 40 * self.cap * t) if self.d_tri_app else None
@@ -441,6 +459,8 @@ class SequencePipeline:
         """device address of frame t's matches"""
         if self.overlap:
             return C.c_void_p(self.d_mb[t % 2])
+        if self.prematch:
+            return C.c_void_p(self.d_pm + 8 * self.cap * (t - 1))
         return C.c_void_p(self.d_m if self.pre is None else self.pre + 8 * int(self.pre_off[t - 1]))
 
     def _match_ahead(self, t):
@@ -457,8 +477,15 @@ class SequencePipeline:
             self.ev_free[t % 2].record(self.ctx)
             self._free_recorded[t % 2] = True
 
+    def match_all(self):
+        """prematch mode: every consecutive pair of the sequence in one call (asynchronous)"""
+        _chk(self.lib.vo_match_appearances_batch_dev(
+            self.ctx.h, C.c_int(self.F - 1), C.c_void_p(self.d_app_pad), C.c_int(self.cap), C.c_void_p(self.d_n_all),
+            C.c_void_p(self.d_app_pad + 40 * self.cap), C.c_int(self.cap), C.c_void_p(self.d_n_all + 4), C.c_float(0.1),
+            C.c_void_p(self.d_pm), C.c_void_p(self.d_pm_cnt)))
+
     def _match(self, t):
-        if self.pre is not None:
+        if self.pre is not None or self.prematch:
             return                                  # matched up front: pairs and count are already in place
         if self.overlap:
             self.ev_matched[t % 2].wait(self.ctx)    # enqueued earlier by _match_ahead(t)
@@ -478,8 +505,8 @@ class SequencePipeline:
     def initialise(self):
         """first pair: match, epipolar initialisation (host, once per sequence), triangulate (vo_complete.cpp:121-132)"""
         self._match(1)
-        c = np.zeros(3, np.int32)
-        self.ctx.d2h(c, self.d_counts + 12)
+        c = np.zeros(1, np.int32)
+        self.ctx.d2h(c, self._cnt(1, 0).value)
         pairs = np.zeros((max(int(c[0]), 1), 2), np.int32)
         if c[0]:
             self.ctx.d2h(pairs[: c[0]], self._m(1).value)
@@ -523,6 +550,8 @@ class SequencePipeline:
             self._match_ahead(1)
             if self.F > 2:
                 self._match_ahead(2)
+        if self.prematch:
+            self.match_all()
         self.initialise()
 
     def run(self):
@@ -539,6 +568,10 @@ class SequencePipeline:
     def counts(self):
         c = np.zeros((self.F, 3), np.int32)
         self.ctx.d2h(c, self.d_counts)
+        if self.prematch:
+            m = np.zeros(self.F - 1, np.int32)
+            self.ctx.d2h(m, self.d_pm_cnt)
+            c[1:, 0] = m
         return c
 
     def cloud(self, t):
@@ -571,5 +604,6 @@ class SequencePipeline:
             self.overlap = False
         for d in (self.d_pts, self.d_app, self.d_m, self.d_j, self.d_model_t, self.d_tri_xyz, self.d_tri_pairs,
                   self.d_counts, self.d_traj, self.d_ident) + ((self.d_tri_app,) if self.d_tri_app else ()) + \
-                ((self.pre,) if self.pre is not None else ()):
+                ((self.pre,) if self.pre is not None else ()) + \
+                ((self.d_app_pad, self.d_n_all, self.d_pm, self.d_pm_cnt) if self.prematch else ()):
             self.ctx.free(d)
