@@ -3,7 +3,7 @@
 // association.  Same call sequence, same output files (written into the
 // current directory or into argv[2]): world.txt, trajectory_gt.txt, map.txt,
 // map_appearances.txt, trajectory_est_complete.txt, trajectory_est_data.txt.
-//   usage: vo_complete <data dir> [output dir] [rounds=100] [--resident] [--exact]
+//   usage: vo_complete <data dir> [output dir] [rounds=100] [--resident [--match-up-front]] [--exact]
 // --resident: the same sequence through vo::DeviceSequence -- all measurement files are read and uploaded first, the
 // whole frame chain runs on the GPU without a host round trip per frame, the map is built afterwards from the
 // per-frame clouds.  Same outputs.
@@ -28,7 +28,7 @@ static void write_poses_raw(const std::string& file, const IsometryVector& traje
 }
 
 // the device-resident form of the loop below: same call sequence, the frame chain inside vo::DeviceSequence
-static int run_resident(const std::string& path, const std::string& out, int rounds, bool exact, const std::string& first_file,
+static int run_resident(const std::string& path, const std::string& out, int rounds, bool exact, bool up_front, const std::string& first_file,
                         const std::string& second_file, const std::set<std::string>& files) {
   std::vector<PointCloudVector<2>> frames;
   std::vector<std::string> names{first_file, second_file};
@@ -49,6 +49,7 @@ static int run_resident(const std::string& path, const std::string& out, int rou
   Camera cam(int_params[3], int_params[2], int_params[0], int_params[1], k);
   DeviceSequence seq(cam, frames, rounds);
   seq.setExact(exact);
+  seq.setMatchUpFront(up_front);              // all consecutive pairs in one batched matcher call before the chain
   seq.run();
   const IsometryVector trajectory = seq.trajectory();          // waits for the chain
   // map upkeep afterwards, in frame order (vo_complete.cpp:145-147,175-176,181)
@@ -75,12 +76,13 @@ static int run_resident(const std::string& path, const std::string& out, int rou
 
 int main(int argc, char* argv[]) {
   // flags first, wherever they stand; what is left are the positional arguments
-  bool resident = false, exact = false;
+  bool resident = false, exact = false, up_front = false;
   std::vector<std::string> pos;
   for (int i = 1; i < argc; ++i) {
     const std::string a(argv[i]);
     if (a == "--resident") resident = true;
     else if (a == "--exact") exact = true;
+    else if (a == "--match-up-front") up_front = true;
     else if (a.rfind("--", 0) == 0) { std::cout << "unknown option " << a << std::endl; return -1; }
     else pos.push_back(a);
   }
@@ -100,7 +102,7 @@ int main(int argc, char* argv[]) {
     const auto second_file = *(files.erase(files.begin()));
     files.erase(files.begin());
 
-    if (resident) return run_resident(path, out, rounds, exact, first_file, second_file, files);
+    if (resident) return run_resident(path, out, rounds, exact, up_front, first_file, second_file, files);
     PointCloudVector<2> reference_pc, current_pc;
     if (!get_meas_content(path + first_file, reference_pc)) { std::cout << "Unable to open file measurement file 0\n"; return -1; }
     if (!get_meas_content(path + second_file, current_pc)) { std::cout << "Unable to open file measurement file 1\n"; return -1; }

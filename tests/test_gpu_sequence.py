@@ -196,10 +196,17 @@ def test_cpp_resident_sequence_equals_frame_by_frame(vo, seq_run, tmp_path):
     os.makedirs(a); os.makedirs(b)
     subprocess.run([exe, d, a, str(ROUNDS)], check=True, stdout=subprocess.DEVNULL, timeout=600)
     subprocess.run([exe, d, b, str(ROUNDS), "--resident"], check=True, stdout=subprocess.DEVNULL, timeout=600)
-    for name in ("trajectory_est_complete.txt", "trajectory_est_data.txt", "map.txt", "map_appearances.txt"):
-        x, y = np.loadtxt(a + name), np.loadtxt(b + name)
-        assert x.shape == y.shape, name
-        assert np.array_equal(x, y), (name, float(np.abs(x - y).max()))
+    # ... and with every consecutive pair matched by one batched call before the chain (DeviceSequence::setMatchUpFront)
+    c = str(tmp_path / "c") + "/"
+    os.makedirs(c)
+    out_b = subprocess.run([exe, d, c, str(ROUNDS), "--resident", "--match-up-front"], check=True, capture_output=True, text=True,
+                           timeout=600).stdout
+    assert " matches, " in out_b
+    for other in (b, c):
+        for name in ("trajectory_est_complete.txt", "trajectory_est_data.txt", "map.txt", "map_appearances.txt"):
+            x, y = np.loadtxt(a + name), np.loadtxt(other + name)
+            assert x.shape == y.shape, name
+            assert np.array_equal(x, y), (name, float(np.abs(x - y).max()))
 
 
 @pytest.mark.parametrize("case", ["normal", "empty5", "foreign5", "tiny5", "empty_last"])
@@ -232,3 +239,8 @@ def test_degenerate_sequences_follow_the_reference_loop(vo, ctx, o32, case):
     assert np.array_equal(counts[1:, 2], np.array(res["tri_counts"]))                       # triangulated points
     assert np.array_equal(np.isnan(traj), np.isnan(ref)) and np.array_equal(traj, ref, equal_nan=True)
     assert np.isfinite(ref).all() == (case in ("normal", "tiny5", "empty_last"))            # the lost frames do poison the rest
+    # the same sequence with every pair matched up front by one ragged batched call: empty and three-point frames included
+    sp = vo.SequencePipeline(ctx, seq, n_iters=30, exact=True, prematch=True)
+    sp.run()
+    assert np.array_equal(sp.counts(), counts) and np.array_equal(sp.trajectory(), traj, equal_nan=True)
+    sp.close()
