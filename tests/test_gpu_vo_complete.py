@@ -48,7 +48,12 @@ def test_vo_complete_on_example_data(tmp_path, o32):
     # frame's triangulation: equal while the chain is young
     assert np.array_equal(c_fast[:, 0], c_exact[:, 0])
     assert np.array_equal(c_fast[:40, 1], c_exact[:40, 1])
-    assert np.array_equal(c_fast[:25], c_exact[:25])                       # inlier counts too
+    # inlier counts of the last round: the default mode's fused arithmetic leaves every projection within an ulp or two of
+    # the reference-order value, so a correspondence that lies within that rounding of a gate or of the chi^2 threshold may
+    # fall on the other side (measured: one correspondence in frame 12 of the first 45 frames) -- never more than one per
+    # frame, and rarely
+    dn = np.abs(c_fast[:40, 2] - c_exact[:40, 2])
+    assert dn.max() <= 1 and (dn != 0).sum() <= 3, (c_fast[:40, 2], c_exact[:40, 2])
     # per-frame relative pose against the reference-order run, first 40 frames (as tests/test_gpu_fullsize.py does for
     # config 3): rounding-level
     d = np.abs(fast[:41] - exact[:41]).reshape(41, -1).max(1)

@@ -21,6 +21,7 @@
 // Reduction: per-thread registers -> DPP row reduction (16 lanes) -> LDS across
 // rows and waves -> workgroup partial.  No MFMA: the normal equations are a
 // tall-skinny accumulate (21+6+3 sums per correspondence), not a contraction.
+#include <type_traits>
 #include <stdlib.h>
 
 #include "vo_internal.h"
@@ -805,6 +806,15 @@ __global__ void picp_batch_T0_out_kernel(BatchArgs a) {
   if (k < 4 && a.stats_out) a.stats_out[4 * p + k] = 0.f;
 }
 
+// The rotation lives in scalar registers; the translation is kept in three VECTOR registers: pc = fma(R, w, t) may read one
+// scalar operand only (constant bus), so a scalar t would cost a v_mov per component and correspondence in a loop that
+// is bound by VALU issue.
+#ifdef VO_BATCH_T_SCALAR
+#define VO_BATCH_T_VGPR(T)
+#else
+#define VO_BATCH_T_VGPR(T) asm volatile("" : "+v"((T).t[0]), "+v"((T).t[1]), "+v"((T).t[2]))
+#endif
+
 template <bool PINHOLE, bool KEEP>
 __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs a) {
   __shared__ float s_red[(PICP_BATCH_BLOCK / 64) * 4 * 32];
@@ -832,13 +842,18 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
     T.t[0] = T.t[1] = T.t[2] = 0.f;
   }
   T = uniform_pose(T);
+  VO_BATCH_T_VGPR(T);
   const CamK cam = a.cam;
   const int n4 = n & ~3;
   // The workgroup owns its CU (168 VGPRs x 768 threads), so the CU's LDS is otherwise idle: the first
   // PICP_BATCH_LDS_TRIPS trips of every thread (its own float4 groups, written in round 0, read back by
   // the same thread in every later round -- no barrier, conflict-free b128) never touch HBM again.
   __shared__ float4 s_cache[PICP_BATCH_LDS_TRIPS][5][PICP_BATCH_BLOCK];
-  for (int it = 0; it < a.n_iters; ++it) {
+  // One round.  The statistics (chi of inliers / outliers, inlier count: 6 of ~110 vector instructions per correspondence
+  // in a loop bound by VALU issue) are what the LAST round reports (picp_solver.h:44-50 read after oneRound); the rounds
+  // before it run the instantiation without them.
+  auto round = [&](int it, auto stats_tag) {
+    constexpr bool STATS = decltype(stats_tag)::value;
     float acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
@@ -867,10 +882,10 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
           cx = s_cache[c][0][tid]; cy = s_cache[c][1][tid]; cz = s_cache[c][2][tid];
           cu = s_cache[c][3][tid]; cv = s_cache[c][4][tid];
         }
-        picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, cx.x, cy.x, cz.x, cu.x, cv.x, acc);
-        picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, cx.y, cy.y, cz.y, cu.y, cv.y, acc);
-        picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, cx.z, cy.z, cz.z, cu.z, cv.z, acc);
-        picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, cx.w, cy.w, cz.w, cu.w, cv.w, acc);
+        picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, cx.x, cy.x, cz.x, cu.x, cv.x, acc);
+        picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, cx.y, cy.y, cz.y, cu.y, cv.y, acc);
+        picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, cx.z, cy.z, cz.z, cu.z, cv.z, acc);
+        picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, cx.w, cy.w, cz.w, cu.w, cv.w, acc);
       }
     }
     // register double buffering: the next trip's five 16-B loads are in flight while the current four correspondences are
@@ -885,10 +900,10 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
         z2 = *reinterpret_cast<const float4*>(Z + i); u2 = *reinterpret_cast<const float4*>(U + i);
         v2 = *reinterpret_cast<const float4*>(V + i);
       }
-      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, x.x, y.x, z.x, u.x, v.x, acc);
-      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, x.y, y.y, z.y, u.y, v.y, acc);
-      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, x.z, y.z, z.z, u.z, v.z, acc);
-      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, x.w, y.w, z.w, u.w, v.w, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x.x, y.x, z.x, u.x, v.x, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x.y, y.y, z.y, u.y, v.y, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x.z, y.z, z.z, u.z, v.z, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x.w, y.w, z.w, u.w, v.w, acc);
       if (!have2) break;
       i += PICP_BATCH_BLOCK * 4;
       have = i < n4;
@@ -897,13 +912,13 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
         z = *reinterpret_cast<const float4*>(Z + i); u = *reinterpret_cast<const float4*>(U + i);
         v = *reinterpret_cast<const float4*>(V + i);
       }
-      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, x2.x, y2.x, z2.x, u2.x, v2.x, acc);
-      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, x2.y, y2.y, z2.y, u2.y, v2.y, acc);
-      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, x2.z, y2.z, z2.z, u2.z, v2.z, acc);
-      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, x2.w, y2.w, z2.w, u2.w, v2.w, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x2.x, y2.x, z2.x, u2.x, v2.x, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x2.y, y2.y, z2.y, u2.y, v2.y, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x2.z, y2.z, z2.z, u2.z, v2.z, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x2.w, y2.w, z2.w, u2.w, v2.w, acc);
     }
     for (int i = n4 + tid; i < n; i += PICP_BATCH_BLOCK) {
-      picp_accumulate_t<PINHOLE, KEEP>(cam, T, a.thr, X[i], Y[i], Z[i], U[i], V[i], acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, X[i], Y[i], Z[i], U[i], V[i], acc);
     }
     const float tot = block_reduce_acc<PICP_BATCH_BLOCK / 64>(acc, s_red);
     if (tid < 32) s_tot[tid] = tot;
@@ -930,6 +945,11 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
     }
     __syncthreads();
     T = uniform_pose(load_pose12(s_pose));
+    VO_BATCH_T_VGPR(T);
+  };
+  for (int it = 0; it < a.n_iters; ++it) {
+    if (it == a.n_iters - 1) round(it, std::true_type{});
+    else round(it, std::false_type{});
   }
   if (tid == 0) {
     float T16[16];

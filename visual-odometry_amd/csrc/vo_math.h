@@ -24,6 +24,19 @@ namespace vo {
 
 VO_HD float vo_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// 1/z of the default-mode linearisation: hardware reciprocal + one Newton step + the special-case fixup (0, inf, nan
+// as the IEEE quotient gives them) -- 4 instructions for the 10 of the correctly rounded quotient, at most 1 ulp from it
+// (-DVO_IEEE_RCP: the quotient).
+VO_HD float vo_recip_z(float z) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VO_IEEE_RCP)
+  const float r = __builtin_amdgcn_rcpf(z);
+  const float e = __builtin_fmaf(-z, r, 1.f);
+  return __builtin_amdgcn_div_fixupf(__builtin_fmaf(r, e, r), z, 1.f);
+#else
+  return 1.0f / z;
+#endif
+}
+
 // A correspondence whose index lies outside its point array is DROPPED by the gather kernels: its world x carries this
 // bit pattern (a quiet NaN with a payload no arithmetic produces) and the linearisation skips it.  A world point that
 // really is NaN is not such a marker: it goes through the arithmetic like in the reference (and poisons the pose, like
@@ -159,55 +172,63 @@ VO_HD bool is_pinhole(const float K[9]) {
 // inputs of its Jacobian zeroed so that no inf/nan of a rejected projection
 // can reach an accumulator.  A world x of VO_DROPPED_BITS marks a dropped correspondence.
 //
-// Decisions (depth/image gates, chi^2 test) use the reference's operation
-// order without FMA.  The pinhole Jacobian's two-term sums and the accumulators use one FMA per product:
-// H_rc += J0r*J0c ; H_rc += J1r*J1c  (lambda, when it is not 1, is folded into
-// the left factor), instead of the reference's (J0r*J0c + J1r*J1c)*lambda
-// followed by an add -- same sum, fewer roundings.
-template <bool PINHOLE, bool KEEP>
+// This is the DEFAULT mode's arithmetic: the reference's formulas with one FMA per product and the reciprocal of
+// vo_recip_z -- every intermediate within an ulp or two of the reference's unfused value, so a decision (depth / image
+// gate, chi^2 test) can differ from the reference's only for a correspondence that lies within that rounding of the
+// gate itself; sums: H_rc += J0r*J0c ; H_rc += J1r*J1c (lambda, when it is not 1, folded into the left factor)
+// instead of (J0r*J0c + J1r*J1c)*lambda followed by an add.  The batched solver is bound by VALU issue, and this form
+// is ~20 instructions per correspondence shorter than the unfused one.  Reference-order arithmetic, decisions
+// included, is picp_term_exact below (vo_picp_set_exact).
+template <bool PINHOLE, bool KEEP, bool STATS = true>
 VO_HD void picp_accumulate_t(const CamK& cam, const Pose& T, float thr, float wx, float wy, float wz,
                              float zu, float zv, float acc[NACC]) {
   constexpr bool keep_outliers = KEEP;
-  float pc[3], ph[3];
-  pose_apply(T, wx, wy, wz, pc[0], pc[1], pc[2]);                       // camera.h:27
-  const bool z_ok = !(pc[2] > (float)cam.z_far || pc[2] < (float)cam.z_near);   // camera.h:28
+  // pc = t + R p (camera.h:27), one FMA per product
+  const float pc0 = vo_fma(T.R[6], wz, vo_fma(T.R[3], wy, vo_fma(T.R[0], wx, T.t[0])));
+  const float pc1 = vo_fma(T.R[7], wz, vo_fma(T.R[4], wy, vo_fma(T.R[1], wx, T.t[1])));
+  const float pc2 = vo_fma(T.R[8], wz, vo_fma(T.R[5], wy, vo_fma(T.R[2], wx, T.t[2])));
+  const bool z_ok = !(pc2 > (float)cam.z_far || pc2 < (float)cam.z_near);       // camera.h:28
+  float ph0, ph1, ph2;                                                          // camera.h:30
   if (PINHOLE) {
-    ph[0] = cam.K[0] * pc[0] + cam.K[6] * pc[2];
-    ph[1] = cam.K[4] * pc[1] + cam.K[7] * pc[2];
-    ph[2] = pc[2];
+    ph0 = vo_fma(cam.K[0], pc0, cam.K[6] * pc2);
+    ph1 = vo_fma(cam.K[4], pc1, cam.K[7] * pc2);
+    ph2 = pc2;
   } else {
-    mat3_vec(cam.K, 3, pc, ph);                                        // camera.h:30
+    ph0 = vo_fma(cam.K[0], pc0, vo_fma(cam.K[3], pc1, cam.K[6] * pc2));
+    ph1 = vo_fma(cam.K[1], pc0, vo_fma(cam.K[4], pc1, cam.K[7] * pc2));
+    ph2 = vo_fma(cam.K[2], pc0, vo_fma(cam.K[5], pc1, cam.K[8] * pc2));
   }
-  float iz = 1.0f / ph[2];                                              // camera.h:31, picp_solver.cpp:44
-  const float u = ph[0] * iz, v = ph[1] * iz;
+  float iz = vo_recip_z(ph2);                                                   // camera.h:31, picp_solver.cpp:44
+  const float u = ph0 * iz, v = ph1 * iz;
   const bool in_img = !(u < 0.f || u > (float)(cam.cols - 1)) && !(v < 0.f || v > (float)(cam.rows - 1));
-  const bool ok = z_ok && in_img && !is_dropped(wx);                    // :32-34, :72-73
-  float e0 = u - zu, e1 = v - zv;                                       // :35
-  const float chi = e0 * e0 + e1 * e1;                                  // :75
-  const bool inl = ok && !(chi > thr);                                  // :78 (strict >)
+  const bool ok = z_ok && in_img && !is_dropped(wx);                            // :32-34, :72-73
+  float e0 = u - zu, e1 = v - zv;                                               // :35
+  const float chi = vo_fma(e0, e0, e1 * e1);                                    // :75
+  const bool inl = ok && !(chi > thr);                                          // :78 (strict >)
   const bool outl = ok && (chi > thr);
-  acc[27] += inl ? chi : 0.f;                                           // :86
-  acc[28] += outl ? chi : 0.f;                                          // :82
-  acc[29] += inl ? 1.f : 0.f;                                           // :87
+  if (STATS) {                                    // (a caller that reports no statistics for this round leaves them out)
+    acc[27] += inl ? chi : 0.f;                                                 // :86
+    acc[28] += outl ? chi : 0.f;                                                // :82
+    acc[29] += inl ? 1.f : 0.f;                                                 // :87
+  }
   float lambda = inl ? 1.f : 0.f;
-  if (keep_outliers) lambda = outl ? sqrtf(thr / chi) : lambda;         // :80, :90
+  if (keep_outliers) lambda = outl ? sqrtf(thr / chi) : lambda;                 // :80, :90
   const bool use = lambda != 0.f;
+  // Jp*K (:39-51): row 0 = iz * (K row 0 - u * K row 2), row 1 = iz * (K row 1 - v * K row 2) -- the reference's
+  // iz*K_0c + (-ph0*iz^2)*K_2c with u = ph0*iz taken out.  A term that must not contribute has the generators of its
+  // Jacobian zeroed, so that no inf/nan of a rejected projection reaches an accumulator.
   iz = use ? iz : 0.f;
   e0 = use ? e0 : 0.f;
   e1 = use ? e1 : 0.f;
-  const float p0 = use ? pc[0] : 0.f, p1 = use ? pc[1] : 0.f, p2 = use ? pc[2] : 0.f;
-  const float h0 = use ? ph[0] : 0.f, h1 = use ? ph[1] : 0.f;
-  const float iz2 = iz * iz;                                            // :45
-  const float g0 = -h0 * iz2, g1 = -h1 * iz2;                           // :47-49
+  const float p0 = use ? pc0 : 0.f, p1 = use ? pc1 : 0.f, p2 = use ? pc2 : 0.f;
+  const float un = use ? -u : 0.f, vn = use ? -v : 0.f;
   float J0[6], J1[6];
   if (PINHOLE) {
-    // Jp*K = [iz*fx 0 iz*cx+g0 ; 0 iz*fy iz*cy+g1];  J = (Jp K)[I | skew(-pc)]   (:39-51)
-    // The Jacobian's entries reach the accumulators only -- never a gate or the chi^2 test, which are all decided above --
-    // so its two-term sums are fused like the accumulator products (4 of ~125 instructions per correspondence).
     const float a = iz * cam.K[0], b = iz * cam.K[4];
-    const float c0 = vo_fma(iz, cam.K[6], g0), c1 = vo_fma(iz, cam.K[7], g1);
+    const float c0 = iz * (cam.K[6] + un), c1 = iz * (cam.K[7] + vn);
     J0[0] = a;   J0[1] = 0.f; J0[2] = c0;
     J1[0] = 0.f; J1[1] = b;   J1[2] = c1;
+    // J = (Jp K)[I | skew(-pc)]
     J0[3] = c0 * p1;
     J1[3] = vo_fma(b, -p2, c1 * p1);
     J0[4] = vo_fma(a, p2, c0 * (-p0));
@@ -215,11 +236,11 @@ VO_HD void picp_accumulate_t(const CamK& cam, const Pose& T, float thr, float wx
     J0[5] = a * (-p1);
     J1[5] = b * p0;
   } else {
-    // (fused the same way as the pinhole form above, so that the two forms stay bit-identical for a pinhole K)
+    // (the same roundings as the pinhole form for a pinhole K: fma(x, 0, k) = k, fma(x, 1, k) = k + x)
     float A0[3], A1[3];
     for (int c = 0; c < 3; ++c) {
-      A0[c] = vo_fma(iz, cam.K[3 * c], g0 * cam.K[2 + 3 * c]);
-      A1[c] = vo_fma(iz, cam.K[1 + 3 * c], g1 * cam.K[2 + 3 * c]);
+      A0[c] = iz * vo_fma(un, cam.K[2 + 3 * c], cam.K[3 * c]);
+      A1[c] = iz * vo_fma(vn, cam.K[2 + 3 * c], cam.K[1 + 3 * c]);
     }
     // skew(v) = [0 -v2 v1; v2 0 -v0; -v1 v0 0] with v = -pc  (utils.h:96-102)
     const float v0 = -p0, v1 = -p1, v2 = -p2;
