@@ -2,6 +2,7 @@
 """Turns the rocprofv3 outputs of tools/collect_profiles.sh into the summaries kept under profiles/.
 usage: python tools/summarize_pmc.py gpurun_out/prof_<tag> profiles/<prefix>"""
 import collections
+import os
 import csv
 import glob
 import json
@@ -9,10 +10,17 @@ import shutil
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+
+
+def newest(pattern):
+    """gpurun merges a call's files into what earlier calls left under gpurun_out/: take the latest run's file"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 WIDE = ("vo::picp_batch_kernel",)       # kernels whose streaming loads are 16 B per lane (dwordx4)
 out = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"{src}/{C}/*/*counter_collection.csv")[0]
+    f = newest(f"{src}/{C}/*/*counter_collection.csv")
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -30,7 +38,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
 # the tri_scatter_kernel that ends the call, summed (last complete call of the pass)
 call = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"{src}/{C}/*/*counter_collection.csv")[0]
+    f = newest(f"{src}/{C}/*/*counter_collection.csv")
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
     cur, last = None, None
     for r in rows:
@@ -89,7 +97,7 @@ if vf:
                         "instruction were an FMA with all lanes active -- the share of the FP32 vector peak (157.3 TFLOP/s, "
                         "MI355X_MICROARCH.md) its instruction stream occupies",
                "kernels": valu}, open(dst + "_pmc_valu.json", "w"), indent=1, sort_keys=True)
-shutil.copy(glob.glob(f"{src}/stats/*/*kernel_stats.csv")[0], dst + "_bench_kernel_stats.csv")
+shutil.copy(newest(f"{src}/stats/*/*kernel_stats.csv"), dst + "_bench_kernel_stats.csv")
 for k in ("vo::picp_batch_kernel<true, false>", "vo::picp_round_kernel<true, false, true, false>"):
     if k in out:
         print(k, json.dumps(out[k]))
