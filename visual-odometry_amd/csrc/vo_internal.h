@@ -9,9 +9,9 @@
 
 // records the message vo_last_error() returns on this thread and hands `code` back (capi.hip)
 int vo_fail(int code, const char* fmt, ...);
-extern "C" int vo_ctx_capturing(struct vo_ctx* ctx);   // 1 while a graph capture is in progress on the context (capi.hip)
-extern "C" int vo_ctx_alive(struct vo_ctx* ctx);       // 0 once the context has been destroyed (handles may outlive it)
-extern "C" unsigned long long vo_ctx_id(struct vo_ctx* ctx);   // unique id of a live context (0: not alive): addresses get recycled, ids do not
+extern "C" __attribute__((visibility("hidden"))) int vo_ctx_capturing(struct vo_ctx* ctx);   // 1 while a graph capture is in progress on the context (capi.hip)
+extern "C" __attribute__((visibility("hidden"))) int vo_ctx_alive(struct vo_ctx* ctx);       // 0 once the context has been destroyed (handles may outlive it)
+extern "C" __attribute__((visibility("hidden"))) unsigned long long vo_ctx_id(struct vo_ctx* ctx);   // unique id of a live context (0: not alive): addresses get recycled, ids do not
 
 namespace vo {
 
