@@ -273,3 +273,8 @@ def test_example_data_chain_is_bit_identical_to_ref32(tmp_path, o32):
     rdir.mkdir()
     _, poses_r = _run_app(rdir, "--exact", "--resident")
     assert np.array_equal(poses_r, poses)
+    # ... also with all 120 consecutive pairs of the dataset (14..127 points per frame) matched by ONE batched call up front
+    udir = tmp_path / "upfront"
+    udir.mkdir()
+    _, poses_u = _run_app(udir, "--exact", "--resident", "--match-up-front")
+    assert np.array_equal(poses_u, poses)
