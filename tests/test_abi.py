@@ -24,6 +24,19 @@ def test_every_declared_symbol_is_exported(vo):
     assert lib.vo_abi_version() == 1
 
 
+def test_nothing_undeclared_is_exported(vo):
+    """... and the other way round: the dynamic symbol table holds no vo_* function the header does not declare (helpers
+    shared between the library's translation units are hidden)."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm")
+    if nm is None:
+        pytest.skip("no nm")
+    out = subprocess.run([nm, "-D", "--defined-only", vo.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r" T (vo_[a-z0-9_]+)$", out, flags=re.M)))
+    assert exported == declared_symbols()
+
+
 def test_no_python_fallback_in_product(vo):
     """The product package must not import the oracle nor carry a CPU path."""
     pkg = os.path.join(ROOT, "visual-odometry_amd")
