@@ -1070,8 +1070,7 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
              "device array not on an 8-byte boundary");
   if (int r = set_device(c)) return r;
   const int nt = b->n_ref > b->n_cur ? b->n_ref : b->n_cur;
-  const size_t cs = compaction_scratch_ints(q);
-  VO_HIP_CHECK(c->scratch.ensure(sizeof(int) * cs * (size_t)F, c->stream));
+  VO_HIP_CHECK(c->scratch.ensure(triangulate_scratch_bytes(q, F), c->stream));    // (covers the counts of the other compactions)
   VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)q * (size_t)F, c->stream));
   VO_HIP_CHECK(c->table.ensure(sizeof(unsigned long long) * (size_t)(b->n_ref ? b->n_ref : 1) * (size_t)F, c->stream));
   // ragged frames (sz): the counts of the struct are capacities (= strides), frame f holds sz->n_ref[f] / n_cur[f] points and
@@ -1128,7 +1127,7 @@ int vo_join_correspondences_dev(vo_ctx* c, const int32_t* d_img, int n_img, cons
   VO_REQUIRE((n_img == 0 || (d_img && d_out)) && (n_world == 0 || d_world), "null pair array");
   VO_REQUIRE(aligned8(d_img, d_world, d_out), "device array not on an 8-byte boundary");
   if (int r = set_device(c)) return r;
-  if (int r = ensure_scratch(c, n_img)) return r;
+  VO_HIP_CHECK(c->scratch.ensure(join_scratch_bytes(n_img, 1), c->stream));
   VO_HIP_CHECK(c->table.ensure(sizeof(unsigned long long) * (size_t)(n_ref ? n_ref : 1), c->stream));
   VO_HIP_CHECK(launch_join(c->stream, d_img, n_img, d_n_img, d_world, n_world, d_n_world, n_ref, d_out,
                            d_n_out, c->table.as<unsigned long long>(), c->scratch.as<int>()));
@@ -1237,7 +1236,7 @@ int vo_triangulate_dev(vo_ctx* c, const float K[9], const float X[16], const flo
   VO_REQUIRE(n == 0 || (d_pairs && d_p1 && d_p2 && d_out_xyz), "null device array");
   VO_REQUIRE(aligned8(d_pairs, d_p1, d_p2, d_app2, d_out_app) && aligned8(d_out_pairs), "device array not on an 8-byte boundary");
   if (int r = set_device(c)) return r;
-  if (int r = ensure_scratch(c, n)) return r;
+  VO_HIP_CHECK(c->scratch.ensure(triangulate_scratch_bytes(n, 1), c->stream));
   Pose Xp;
   if (X) Xp = pose_from_T16(X);
   VO_HIP_CHECK(launch_triangulate(c->stream, K, X ? &Xp : nullptr, d_X16, d_pairs, n, d_n, d_p1, n1, d_p2,

@@ -260,6 +260,9 @@ struct TriArgs {
   int32_t* out_pairs;
   float* out_app;
   int* counts;
+  // what the counting pass keeps for the writing pass: every pair's point and one bit per pair ("survives")
+  float* tmp_xyz;                   // [n_frames][n_max][3]
+  unsigned long long* tmp_ok;       // [n_frames][(n_max + 63) / 64]
   // batched use: strides in pairs / points per frame (0 for a single frame); nb workgroups for each of n_frames frames
   size_t pairs_stride, p1_stride, p2_stride, out_stride, counts_stride;
   int nb, n_frames;
@@ -278,6 +281,8 @@ __device__ __forceinline__ TriArgs tri_frame(TriArgs a, int frame) {
   if (a.out_pairs) a.out_pairs += 2 * f * a.out_stride;
   if (a.out_app) a.out_app += 10 * f * a.out_stride;
   a.counts += f * a.counts_stride;
+  a.tmp_xyz += 3 * f * (size_t)a.n_max;
+  a.tmp_ok += f * (size_t)((a.n_max + 63) / 64);
   return a;
 }
 
@@ -319,7 +324,12 @@ __global__ __launch_bounds__(CB) void tri_count_kernel(TriArgs a0) {
   const int n = clamp_count(a.d_n, a.n_max);
   const int k = fb.b * CB + threadIdx.x;
   bool ok = false;
-  if (k < n) { int i2; float p[3]; ok = tri_eval(a, s_c, k, i2, p); }
+  float p[3] = {0.f, 0.f, 0.f};
+  if (k < n) { int i2; ok = tri_eval(a, s_c, k, i2, p); }
+  // kept for the writing pass (coalesced), which then neither gathers the image points nor triangulates again
+  if (k < a.n_max) { a.tmp_xyz[3 * (size_t)k] = p[0]; a.tmp_xyz[3 * (size_t)k + 1] = p[1]; a.tmp_xyz[3 * (size_t)k + 2] = p[2]; }
+  const unsigned long long m = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && k < a.n_max) a.tmp_ok[k >> 6] = m;
   int total;
   block_rank(ok, s_wave, total);
   if (threadIdx.x == 0) a.counts[fb.b] = total;
@@ -329,15 +339,19 @@ __global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a0) {
   const FrameBlock fb = frame_block(a0.nb, a0.n_frames);
   if (!fb.live) return;
   const TriArgs a = tri_frame(a0, fb.f);
-  __shared__ TriConst s_c;
   __shared__ int s_wave[CB / 64];
-  tri_setup(a, &s_c);
-  const int n = clamp_count(a.d_n, a.n_max);
   const int k = fb.b * CB + threadIdx.x;
+  // the counting pass left every pair's point and verdict (tri_count_kernel): nothing is gathered or triangulated twice
   bool ok = false;
   int i2 = 0;
   float p[3] = {0.f, 0.f, 0.f};
-  if (k < n) ok = tri_eval(a, s_c, k, i2, p);
+  if (k < a.n_max) {
+    ok = (a.tmp_ok[k >> 6] >> (k & 63)) & 1ull;
+    if (ok) {
+      i2 = a.pairs[2 * (size_t)k + 1];
+      p[0] = a.tmp_xyz[3 * (size_t)k]; p[1] = a.tmp_xyz[3 * (size_t)k + 1]; p[2] = a.tmp_xyz[3 * (size_t)k + 2];
+    }
+  }
   int total;
   const int r = block_rank(ok, s_wave, total);
   __shared__ int s_src[CB];
@@ -360,6 +374,16 @@ __global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a0) {
   }
 }
 
+// bytes of d_scratch the join needs: the compaction's counts, then one looked-up index per image pair
+size_t join_scratch_bytes(int n_img, int n_frames) {
+  return (sizeof(int) * (compaction_scratch_ints(n_img) + (size_t)n_img) + sizeof(unsigned long long) * (size_t)((n_img + 63) / 64)) * (size_t)n_frames + 16;
+}
+
+// bytes of d_scratch the triangulation needs: the compaction's counts, then one bit and one point per pair
+size_t triangulate_scratch_bytes(int n, int n_frames) {
+  return (sizeof(int) * compaction_scratch_ints(n) + sizeof(unsigned long long) * (size_t)((n + 63) / 64) + 12 * (size_t)n) * (size_t)n_frames + 16;
+}
+
 // n_frames > 1: frame f uses d_X16 + 16f, pairs + f*pairs_stride, d_n[f], p1/p2/app2 + f*stride, writes
 // out_* + f*out_stride and d_n_out[f]; d_scratch holds n_frames * compaction_scratch_ints(n) ints.
 hipError_t launch_triangulate_batch(hipStream_t st, const float K[9], const Pose* X_host, const float* d_X16,
@@ -376,6 +400,13 @@ hipError_t launch_triangulate_batch(hipStream_t st, const float K[9], const Pose
   a.p1 = d_p1; a.n1 = n1; a.p2 = d_p2; a.n2 = n2; a.app2 = d_app2;
   a.out_xyz = d_out_xyz; a.out_pairs = d_out_pairs; a.out_app = d_out_app;
   a.counts = d_scratch;
+  {
+    size_t off = sizeof(int) * compaction_scratch_ints(n) * (size_t)n_frames;   // triangulate_scratch_bytes
+    off = (off + 15) & ~(size_t)15;
+    char* t = reinterpret_cast<char*>(d_scratch) + off;
+    a.tmp_ok = reinterpret_cast<unsigned long long*>(t);
+    a.tmp_xyz = reinterpret_cast<float*>(t + sizeof(unsigned long long) * (size_t)((n + 63) / 64) * (size_t)n_frames);
+  }
   const bool batched = n_frames > 1;
   a.pairs_stride = batched ? pairs_stride : 0; a.p1_stride = batched ? p1_stride : 0;
   a.p2_stride = batched ? p2_stride : 0; a.out_stride = batched ? out_stride : 0;
@@ -427,6 +458,8 @@ struct JoinArgs {
   int* counts;
   size_t img_stride, world_stride, out_stride, counts_stride;   // per frame, in pairs / ints
   int nb, n_frames;                                             // workgroups per frame, frames
+  int* tmp_w;                                                   // [n_frames][n_max]: what the counting pass looked up ...
+  unsigned long long* tmp_ok;                                   // [n_frames][(n_max + 63) / 64]: ... and whether there was a partner
 };
 
 __device__ __forceinline__ JoinArgs join_frame(JoinArgs a, int frame) {
@@ -437,6 +470,8 @@ __device__ __forceinline__ JoinArgs join_frame(JoinArgs a, int frame) {
   a.table += f * (size_t)a.n_ref;
   a.out += 2 * f * a.out_stride;
   a.counts += f * a.counts_stride;
+  a.tmp_w += f * (size_t)a.n_max;
+  a.tmp_ok += f * (size_t)((a.n_max + 63) / 64);
   return a;
 }
 
@@ -458,7 +493,14 @@ __global__ __launch_bounds__(CB) void join_count_kernel(JoinArgs a0) {
   const int n = clamp_count(a.d_n, a.n_max);
   const int i = fb.b * CB + threadIdx.x;
   bool ok = false;
-  if (i < n) { int c, w; ok = join_eval(a, i, c, w); }
+  int c, w = 0;
+  if (i < n) ok = join_eval(a, i, c, w);
+  // kept for the writing pass: one coalesced read there instead of the lookup again
+  const unsigned long long m = __ballot(ok);
+  if (i < a.n_max) {
+    a.tmp_w[i] = w;
+    if ((threadIdx.x & 63) == 0) a.tmp_ok[i >> 6] = m;
+  }
   int total;
   block_rank(ok, s_wave, total);
   if (threadIdx.x == 0) a.counts[fb.b] = total;
@@ -469,11 +511,13 @@ __global__ __launch_bounds__(CB) void join_scatter_kernel(JoinArgs a0) {
   if (!fb.live) return;
   const JoinArgs a = join_frame(a0, fb.f);
   __shared__ int s_wave[CB / 64];
-  const int n = clamp_count(a.d_n, a.n_max);
   const int i = fb.b * CB + threadIdx.x;
   bool ok = false;
   int c = 0, w = 0;
-  if (i < n) ok = join_eval(a, i, c, w);
+  if (i < a.n_max) {
+    ok = (a.tmp_ok[i >> 6] >> (i & 63)) & 1ull;        // join_count_kernel's lookup
+    if (ok) { w = a.tmp_w[i]; c = a.img[2 * (size_t)i + 1]; }
+  }
   int total;
   const int r = block_rank(ok, s_wave, total);
   if (ok) {
@@ -505,7 +549,13 @@ hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, co
   const int nb = (n_img + CB - 1) / CB;
   JoinArgs a{d_img, n_img, d_n_img, d_world, n_ref, d_table, d_out, d_scratch,
              batched ? img_stride : 0, batched ? world_stride : 0, batched ? out_stride : 0,
-             batched ? compaction_scratch_ints(n_img) : 0, nb, n_frames};
+             batched ? compaction_scratch_ints(n_img) : 0, nb, n_frames, nullptr, nullptr};
+  {
+    size_t off = (sizeof(int) * compaction_scratch_ints(n_img) * (size_t)n_frames + 15) & ~(size_t)15;      // join_scratch_bytes
+    char* t = reinterpret_cast<char*>(d_scratch) + off;
+    a.tmp_ok = reinterpret_cast<unsigned long long*>(t);
+    a.tmp_w = reinterpret_cast<int*>(t + sizeof(unsigned long long) * (size_t)((n_img + 63) / 64) * (size_t)n_frames);
+  }
   if (nb > 0) hipLaunchKernelGGL(join_count_kernel, frame_grid(nb, n_frames), dim3(CB), 0, st, a);
   e = launch_scan(st, d_scratch, nb, d_n_out, nullptr, n_frames, a.counts_stride);
   if (e != hipSuccess) return e;

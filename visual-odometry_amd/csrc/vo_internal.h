@@ -136,6 +136,8 @@ struct Workspace;  // scratch owned by the context
 
 // d_scratch: compaction_scratch_ints(n) ints (per-workgroup counts / offsets)
 size_t compaction_scratch_ints(int n);
+size_t join_scratch_bytes(int n_img, int n_frames);      // d_scratch of launch_join[_batch]
+size_t triangulate_scratch_bytes(int n, int n_frames);   // d_scratch of launch_triangulate[_batch]
 hipError_t launch_project_points(hipStream_t st, const CamK& cam, const Pose& T, const float* d_world,
                                  int n, int keep_indices, float* d_out_uv, int* d_counts,
                                  int* d_scratch);
