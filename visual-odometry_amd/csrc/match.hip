@@ -658,7 +658,10 @@ constexpr int HCOARSE = HNC * HNC;       // coarse bins (c0, c1) / fine bins (c2
 constexpr int HCPAD = 512;               // HCOARSE rounded up to a power of two (scan width)
 constexpr int HROW = 408;                // u16 entries per row of the relative start table (>= HCOARSE + 1, 16-byte rows)
 constexpr int CELL_SAMPLE = 2048;        // points per set that define the grid's bounds
-constexpr int CELL_SLICE = 1792;         // points per level-1 workgroup: 7 per thread, ordered in 28 KiB of LDS
+#ifndef VO_CELL_SLICE
+#define VO_CELL_SLICE 1792
+#endif
+constexpr int CELL_SLICE = VO_CELL_SLICE;         // points per level-1 workgroup: 7 per thread, ordered in 28 KiB of LDS
 constexpr int CELL_PPT = CELL_SLICE / 256;
 constexpr int CELL_MAX_SLICES = 1024;    // per set: the cell variant serves sets of up to 1 835 008 points (beyond: pruned scan)
 #ifndef VO_CS_NB
