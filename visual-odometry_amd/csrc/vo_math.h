@@ -2,12 +2,15 @@
 // side of libvo_hip.so.  Everything is float32, column-major like the Eigen
 // objects of the reference (defs.h:7-29).
 //
-// The library is compiled with -ffp-contract=off: the decision-making chains
-// (projection, depth/image gates, chi^2 test, cheirality test) are written in
-// the operation order of the reference so that they round like its SSE2 build
-// (CMakeLists.txt:6-7, no FMA).  Fused multiply-adds are used only where they
-// are requested explicitly (vo_fma), i.e. in the accumulators, whose summation
-// order differs from the reference's sequential loop anyway.
+// The library is compiled with -ffp-contract=off: everything that must round
+// like the reference's SSE2 build (CMakeLists.txt:6-7, no FMA) -- the matcher's
+// distances, the projection / transform / triangulation operators and their
+// gates, the reference-order solver mode (picp_term_exact) -- is written in the
+// reference's operation order and stays unfused.  Fused multiply-adds appear
+// only where they are requested explicitly (vo_fma): in the DEFAULT solver
+// mode's linearisation (picp_accumulate_t), whose sums are tree-reduced in
+// another order than the reference's sequential loop anyway, and in its 6x6
+// solve.
 #pragma once
 
 #include <math.h>
