@@ -41,6 +41,14 @@ __device__ __forceinline__ int block_rank(bool flag, int* s_wave, int& total) {
   return off + before;
 }
 
+// Small frames -- every frame of the reference's dataset holds 14..127 points -- are compacted by ONE workgroup per frame: it walks
+// the items 256 at a time with the running count in a register, so count, scan and scatter are one launch instead of three
+// (the join: table fill and build too -- one instead of five; the table lives in LDS).  Same ranks, same order, same output.
+#ifndef VO_SMALL_N
+#define VO_SMALL_N 2048
+#endif
+constexpr int SMALL_N = VO_SMALL_N;   // (-DVO_SMALL_N=-1: the general kernels for every size)
+
 __device__ __forceinline__ int clamp_count(const int* d_n, int n_max) {
   int n = n_max;
   if (d_n) { const int m = *d_n; n = m < n_max ? (m < 0 ? 0 : m) : n_max; }
@@ -374,6 +382,44 @@ __global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a0) {
   }
 }
 
+__global__ __launch_bounds__(CB) void tri_small_kernel(TriArgs a0, int* d_n_out) {
+  const int f = blockIdx.x;
+  const TriArgs a = tri_frame(a0, f);
+  __shared__ TriConst s_c;
+  __shared__ int s_wave[CB / 64];
+  __shared__ int s_src[CB];
+  tri_setup(a, &s_c);
+  const int n = clamp_count(a.d_n, a.n_max);
+  int first = 0;
+  for (int base = 0; base < n; base += CB) {
+    const int k = base + threadIdx.x;
+    bool ok = false;
+    int i2 = 0;
+    float p[3] = {0.f, 0.f, 0.f};
+    if (k < n) ok = tri_eval(a, s_c, k, i2, p);
+    int total;
+    const int r = block_rank(ok, s_wave, total);
+    if (ok) {
+      const size_t dst = (size_t)first + r;
+      a.out_xyz[3 * dst] = p[0]; a.out_xyz[3 * dst + 1] = p[1]; a.out_xyz[3 * dst + 2] = p[2];
+      if (a.out_pairs) reinterpret_cast<int2*>(a.out_pairs)[dst] = make_int2(i2, (int)dst);     // utils.cpp:97
+      s_src[r] = i2;
+    }
+    __syncthreads();
+    if (a.out_app && a.app2) {                                                                 // utils.cpp:127
+      const float2* app = reinterpret_cast<const float2*>(a.app2);
+      float2* o = reinterpret_cast<float2*>(a.out_app) + 5 * (size_t)first;
+      for (int j = threadIdx.x; j < 5 * total; j += CB) {
+        const int pt = j / 5;
+        o[j] = app[5 * (size_t)s_src[pt] + (j - 5 * pt)];
+      }
+    }
+    first += total;
+    __syncthreads();                                   // s_wave and s_src are reused by the next 256 items
+  }
+  if (threadIdx.x == 0) d_n_out[f] = first;
+}
+
 // bytes of d_scratch the join needs: the compaction's counts, then one looked-up index per image pair
 size_t join_scratch_bytes(int n_img, int n_frames) {
   return (sizeof(int) * (compaction_scratch_ints(n_img) + (size_t)n_img) + sizeof(unsigned long long) * (size_t)((n_img + 63) / 64)) * (size_t)n_frames + 16;
@@ -413,6 +459,10 @@ hipError_t launch_triangulate_batch(hipStream_t st, const float K[9], const Pose
   a.counts_stride = batched ? compaction_scratch_ints(n) : 0;
   const int nb = (n + CB - 1) / CB;
   a.nb = nb; a.n_frames = n_frames;
+  if (n <= SMALL_N) {
+    hipLaunchKernelGGL(tri_small_kernel, dim3(n_frames), dim3(CB), 0, st, a, d_n_out);
+    return hipGetLastError();
+  }
   if (nb > 0) hipLaunchKernelGGL(tri_count_kernel, frame_grid(nb, n_frames), dim3(CB), 0, st, a);
   hipError_t e = launch_scan(st, d_scratch, nb, d_n_out, nullptr, n_frames, a.counts_stride);
   if (e != hipSuccess) return e;
@@ -527,6 +577,43 @@ __global__ __launch_bounds__(CB) void join_scatter_kernel(JoinArgs a0) {
   }
 }
 
+__global__ __launch_bounds__(CB) void join_small_kernel(JoinArgs a0, int n_world_max, const int* d_n_world, int* d_n_out) {
+  const int f = blockIdx.x;
+  const JoinArgs a = join_frame(a0, f);
+  __shared__ unsigned long long s_tab[SMALL_N > 0 ? SMALL_N : 1];
+  __shared__ int s_wave[CB / 64];
+  for (int k = threadIdx.x; k < a.n_ref; k += CB) s_tab[k] = JOIN_EMPTY;
+  __syncthreads();
+  const int nw = clamp_count(d_n_world ? d_n_world + f : nullptr, n_world_max);
+  for (int j = threadIdx.x; j < nw; j += CB) {           // as join_build_kernel
+    const int2 pr = reinterpret_cast<const int2*>(a.world)[j];
+    if (pr.x >= 0 && pr.x < a.n_ref) atomicMin(&s_tab[pr.x], ((unsigned long long)(unsigned)j << 32) | (unsigned)pr.y);
+  }
+  __syncthreads();
+  const int n = clamp_count(a.d_n, a.n_max);
+  int first = 0;
+  for (int base = 0; base < n; base += CB) {
+    const int i = base + threadIdx.x;
+    bool ok = false;
+    int c = 0, w = 0;
+    if (i < n) {
+      const int2 pr = reinterpret_cast<const int2*>(a.img)[i];
+      c = pr.y;
+      if (pr.x >= 0 && pr.x < a.n_ref) {
+        const unsigned long long e = s_tab[pr.x];
+        ok = e != JOIN_EMPTY;
+        w = (int)(unsigned)(e & 0xffffffffull);
+      }
+    }
+    int total;
+    const int r = block_rank(ok, s_wave, total);
+    if (ok) reinterpret_cast<int2*>(a.out)[(size_t)first + r] = make_int2(c, w);      // vo_complete.cpp:59
+    first += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) d_n_out[f] = first;
+}
+
 // n_frames > 1: frame f joins d_img + f*img_stride (d_n_img[f] pairs) with d_world + f*world_stride
 // (d_n_world[f] pairs, or n_world when null) into d_out + f*out_stride, count in d_n_out[f];
 // d_table: n_frames*n_ref 64-bit words, d_scratch: n_frames*compaction_scratch_ints(n_img) ints.
@@ -536,6 +623,12 @@ hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, co
                              size_t world_stride, size_t out_stride) {
   const bool batched = n_frames > 1;
   hipError_t e = hipSuccess;
+  if (n_img <= SMALL_N && n_ref <= SMALL_N && n_world <= 8 * SMALL_N) {
+    JoinArgs a{d_img, n_img, d_n_img, d_world, n_ref, d_table, d_out, d_scratch,
+               batched ? img_stride : 0, batched ? world_stride : 0, batched ? out_stride : 0, 0, 0, n_frames, nullptr, nullptr};
+    hipLaunchKernelGGL(join_small_kernel, dim3(n_frames), dim3(CB), 0, st, a, n_world, d_n_world, d_n_out);
+    return hipGetLastError();
+  }
   if (n_ref > 0) {
     e = hipMemsetAsync(d_table, 0x7f, sizeof(unsigned long long) * (size_t)n_ref * (size_t)n_frames, st);
     if (e != hipSuccess) return e;
@@ -625,12 +718,41 @@ __global__ __launch_bounds__(CB) void match_scatter_kernel(MatchOutArgs a) {
   }
 }
 
+__global__ __launch_bounds__(CB) void match_compact_small_kernel(MatchOutArgs a, int* d_n_out) {
+  __shared__ int s_wave[CB / 64];
+  const unsigned long long* best = a.best + blockIdx.y * a.best_stride;
+  int32_t* out = a.out + 2 * blockIdx.y * a.out_stride;
+  int nq, tree_is_1;
+  match_out_frame(a, nq, tree_is_1);
+  int first = 0;
+  for (int base = 0; base < nq; base += CB) {
+    const int q = base + threadIdx.x;
+    unsigned idx = 0xffffffffu;
+    if (q < nq) idx = (unsigned)(best[q] & 0xffffffffull);
+    const bool ok = idx != 0xffffffffu;
+    int total;
+    const int r = block_rank(ok, s_wave, total);
+    if (ok) {
+      const size_t dst = (size_t)first + r;
+      out[2 * dst] = tree_is_1 ? (int)idx : q;
+      out[2 * dst + 1] = tree_is_1 ? q : (int)idx;
+    }
+    first += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) d_n_out[blockIdx.y] = first;
+}
+
 hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best, int nq, int tree_is_1,
                                 int32_t* d_out, int* d_n_out, int* d_scratch, int n_frames, size_t best_stride,
                                 size_t out_stride, const int* d_n1, const int* d_n2) {
   const int nb = (nq + CB - 1) / CB;
   const size_t cs = n_frames > 1 ? compaction_scratch_ints(nq) : 0;
   MatchOutArgs a{d_best, nq, tree_is_1, d_out, d_scratch, best_stride, n_frames > 1 ? out_stride : 0, cs, d_n1, d_n2};
+  if (nq <= SMALL_N) {
+    hipLaunchKernelGGL(match_compact_small_kernel, dim3(1, n_frames), dim3(CB), 0, st, a, d_n_out);
+    return hipGetLastError();
+  }
   if (nb > 0) hipLaunchKernelGGL(match_count_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);
   hipError_t e = launch_scan(st, d_scratch, nb, d_n_out, nullptr, n_frames, cs);
   if (e != hipSuccess) return e;
