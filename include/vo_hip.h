@@ -214,7 +214,10 @@ int vo_picp_solve_batch_dev(vo_ctx *ctx, int n_problems, int rows, int cols, int
  * (query, tree point) pair; 2: counting-sort both sets into 1024 buckets along the two appearance
  * components of largest spread and scan only the buckets within the radius (LDS-tiled); 3: counting-sort
  * both sets into a 4-D grid of cells no narrower than the radius and visit, per query, the <= 81 cells
- * around it (about 25 candidates per query on uniform appearances). */
+ * around it (about 25 candidates per query on uniform appearances); 4 / 5: first answer every query that has a
+ * bitwise copy in the tree (appearances are copied from frame to frame; a copy is at distance 0, the minimum) through
+ * per-slice hash tables, then run 2 / 3 for the remaining queries only -- what mode 0 does from the sizes on where
+ * it sorts (sets of up to 102 400 points; beyond, 2 / 3 alone). */
 int vo_match_set_mode(vo_ctx *ctx, int mode);
 int vo_match_appearances(vo_ctx *ctx, const float *a1, int n1, const float *a2, int n2,
                          float radius, int32_t *out_pairs, int *n_out);

@@ -1,0 +1,98 @@
+"""The exact-duplicate pass of the matcher (match.hip "hash-first", modes 4 / 5 and the automatic mode from the sizes on
+where it sorts): appearances are copied from frame to frame, so a query usually has a bitwise copy in the tree -- its nearest
+neighbour at distance 0 -- which per-slice hash tables find without any search.  The pass must never change a result
+(compute_correspondences_images, vo_complete.cpp:12-49; ties to the lowest index): every case here is held to the oracle
+and to the plain searches (modes 1 / 3)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctxs(vo, modes):
+    out = []
+    for m in modes:
+        c = vo.Context(0)
+        assert c.lib.vo_match_set_mode(c.h, m) == 0
+        out.append(c)
+    return out
+
+
+def _check(vo, o32, ctxs, a, b, radius=0.1):
+    exp = o32.match(a, b, radius)
+    for c in ctxs:
+        got = vo.compute_correspondences_images(a, b, radius=radius, ctx=c)
+        assert np.array_equal(got, exp), (len(a), len(b))
+    return exp
+
+
+def test_hash_first_adversarial_rows(vo, o32):
+    rng = np.random.default_rng(41)
+    ctxs = _ctxs(vo, (1, 4, 5))
+    base = rng.uniform(-1, 1, (3000, 10)).astype(np.float32)
+    perm = rng.permutation(3000)
+    # (1) plain copies, a permutation apart; with drops and strangers on both sides
+    m = _check(vo, o32, ctxs, base, base[perm])
+    assert len(m) == 3000
+    strangers = rng.uniform(-1, 1, (400, 10)).astype(np.float32)
+    _check(vo, o32, ctxs, np.concatenate([base[:2500], strangers]), np.concatenate([strangers[::-1][:100] * np.float32(0.5), base[perm][:2800]]))
+    # (2) every tree row repeated five times, scattered: the LOWEST index of the copies must win
+    tree = np.concatenate([base[:600]] * 5)[rng.permutation(3000)]
+    m = _check(vo, o32, ctxs, tree, base[:600][::-1].copy())
+    assert len(m) == 600
+    # (3) one row, 3000 times (a chain of one entry, not of 3000), and a near copy of it in front
+    same = np.repeat(base[:1], 3000, 0)
+    same[0, 3] = np.nextafter(same[0, 3], np.float32(2))
+    m = _check(vo, o32, ctxs, same, base[:1].repeat(40, 0))
+    assert (m[:, 0] == 1).all()
+    # (4) rows the pass must leave to the search: zeros, negative zeros, tiny values whose squared differences underflow to
+    # zero (distance-0 ties between rows that are NOT copies), NaN, inf
+    t = base[:2000].copy(); q = base[:2000][rng.permutation(2000)][:1500].copy()
+    t[10:20, 2] = 0.0; t[20:30, 2] = -0.0
+    q[:5] = t[10:15]; q[5:10] = t[20:25]; q[5:10, 2] = 0.0              # +0 against -0: equal, though not bitwise
+    tiny = np.full((6, 10), 1e-30, np.float32)
+    tiny[2, 0] = 1.5e-30; tiny[4, 5] = 0.5e-30                          # rows 0,1,3,5 identical; 2 and 4 differ by less than sqrt(min float)
+    t[100:106] = tiny; q[20:23] = tiny[[5, 2, 4]]
+    t[200, 4] = np.nan; q[30] = t[200]; t[201, 7] = np.inf; q[31] = t[201]; q[32, 0] = -np.inf
+    for a, b in ((t, q), (q, t)):
+        _check(vo, o32, ctxs, a, b)
+    # (5) radius edge: nothing can match at radius 0 (0 < 0 is false), everything safe at a tiny positive radius
+    assert len(_check(vo, o32, ctxs, base[:2100], base[:2100][::-1].copy(), radius=0.0)) == 0
+    assert len(_check(vo, o32, ctxs, base[:2100], base[:2100][::-1].copy(), radius=1e-6)) == 2100
+    # (6) values around the bound that separates the rows the pass takes from those it leaves (2^-40)
+    edge = base[:2400].copy()
+    edge[::3, 1] = np.float32(2.0 ** -40); edge[1::3, 1] = np.nextafter(np.float32(2.0 ** -40), np.float32(0))
+    _check(vo, o32, ctxs, edge, edge[rng.permutation(2400)][:2200].copy())
+    for c in ctxs: c.close()
+
+
+def test_hash_first_many_slices_and_batches(vo, ctx, o32):
+    """several tables per frame (70k points: five / forty-four slices), frames of different sizes in one call with either
+    image the larger one, and a batch whose frames differ in how many queries the pass leaves open (none ... all)"""
+    rng = np.random.default_rng(43)
+    big = rng.uniform(-1, 1, (70000, 10)).astype(np.float32)
+    q = big[rng.permutation(70000)][:60000].copy()
+    q[:3000] += np.float32(0.01)                                        # near copies: the search must find them
+    q[3000:4000] = rng.uniform(-1, 1, (1000, 10)).astype(np.float32)    # strangers
+    c1, c5 = _ctxs(vo, (3, 5))
+    exp = vo.compute_correspondences_images(big, q, ctx=c1)
+    assert 58000 < len(exp) <= 60000
+    assert np.array_equal(vo.compute_correspondences_images(big, q, ctx=c5), exp)
+    assert np.array_equal(vo.compute_correspondences_images(big, q, ctx=ctx), exp)          # automatic mode
+    assert np.array_equal(vo.compute_correspondences_images(q, big, ctx=ctx), exp[:, ::-1])
+    # ragged batch, 12 frames, open queries from 0 % to 100 %
+    a1, a2 = [], []
+    for k in range(12):
+        n = int(rng.integers(2500, 9000))
+        t = rng.uniform(-1, 1, (n, 10)).astype(np.float32)
+        m = int(n * rng.uniform(0.5, 1.0))
+        qq = t[rng.permutation(n)][:m].copy()
+        n_open = int(m * k / 11)
+        qq[:n_open] += rng.normal(0, 0.02, (n_open, 10)).astype(np.float32)
+        if k % 2: a1.append(t); a2.append(qq)
+        else: a1.append(qq); a2.append(t)
+    for c in (c5, ctx):
+        got = vo.match_batch_ragged(c, a1, a2)
+        for k in range(12):
+            assert np.array_equal(got[k], o32.match(a1[k], a2[k])), k
+    c1.close(); c5.close()

@@ -171,12 +171,13 @@ def test_gates_match_oracle_bitwise(vo, ctx, o32):
 
 
 def test_matcher_variants_agree(vo, o32):
-    """Full scan (mode 1), bucket-pruned scan (mode 2) and cell-hash search (mode 3) must return the
-    oracle's pairs on every input, including duplicates (ties -> lowest index), degenerate spreads and tiny sets."""
+    """Full scan (mode 1), bucket-pruned scan (mode 2), cell-hash search (mode 3) and both of the latter behind the
+    exact-duplicate pass (modes 4, 5) must return the oracle's pairs on every input, including duplicates (ties -> lowest
+    index), degenerate spreads and tiny sets."""
     import ctypes as C
-    c1, c2, c3 = vo.Context(0), vo.Context(0), vo.Context(0)
-    assert c1.lib.vo_match_set_mode(c1.h, 1) == 0 and c2.lib.vo_match_set_mode(c2.h, 2) == 0
-    assert c3.lib.vo_match_set_mode(c3.h, 3) == 0
+    c1, c2, c3, c4, c5 = (vo.Context(0) for _ in range(5))
+    for k, c in enumerate((c1, c2, c3, c4, c5)):
+        assert c.lib.vo_match_set_mode(c.h, k + 1) == 0
     assert c1.lib.vo_match_set_mode(c1.h, 7) != 0
     rng = np.random.default_rng(17)
     cases = []
@@ -208,7 +209,9 @@ def test_matcher_variants_agree(vo, o32):
             assert np.array_equal(vo.compute_correspondences_images(x, y, ctx=c1), exp)
             assert np.array_equal(vo.compute_correspondences_images(x, y, ctx=c2), exp)
             assert np.array_equal(vo.compute_correspondences_images(x, y, ctx=c3), exp)
-    c1.close(); c2.close(); c3.close()
+            assert np.array_equal(vo.compute_correspondences_images(x, y, ctx=c4), exp)
+            assert np.array_equal(vo.compute_correspondences_images(x, y, ctx=c5), exp)
+    for c in (c1, c2, c3, c4, c5): c.close()
 
 
 def test_matcher_sizes_and_branches(vo, ctx, o32):

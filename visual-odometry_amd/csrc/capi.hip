@@ -107,7 +107,7 @@ struct vo_ctx {
   PicpParams batch_params_host{};        //   its parameter block as last uploaded, and where
   const PicpParams* batch_params_dev = nullptr;
   DevBuf prune_ws;    // sorted copies / tables of the matcher's sorted variants
-  int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan, 3 cell-hash search
+  int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan, 3 cell-hash search, 4 / 5 exact-duplicate pass first, then 2 / 3
   int batch_form = 0; // batched solver: 0 auto, 1 one launch per round, 2 one workgroup per problem
   bool capturing = false;
   unsigned long long id = 0;   // unique per context ever created: an address can be reused, an id cannot
@@ -948,26 +948,42 @@ static int match_workspace(vo_ctx* c, int variant, int nt, int nq, int n_frames,
 // Auto: full scan for small sets; for one frame the bucket-pruned scan (its LDS-tiled scan is the shorter
 // dependency chain when the GPU is not full: 82 vs 130 us at 50k x 50k); for many frames per call the cell-hash
 // search (25 instead of ~1400 candidates per query: 4.0 vs 4.4 ms per 200 frames, its random accesses hidden
-// by occupancy).  VO_MATCH_AUTO=2|3 forces one of the sorted variants in auto mode.
+// by occupancy).  In front of either sorted search auto mode runs the exact-duplicate pass (variants 4 / 5, match.hip
+// "hash-first": appearances are copied from frame to frame, so almost every query has a bitwise copy in the tree, which
+// is its nearest neighbour at distance 0; the search then only sees the queries without one).
+// VO_MATCH_AUTO=2|3 forces one of the sorted variants in auto mode, VO_MATCH_HASH=0 leaves the exact-duplicate pass out.
+static int with_hash(int v, int nt, int n_frames) {
+  static const bool on = [] { const char* e = getenv("VO_MATCH_HASH"); return !(e && e[0] == '0'); }();
+  return (on && (v == 2 || v == 3) && match_hash_supported(nt, n_frames)) ? v + 2 : v;
+}
 static int match_variant(const vo_ctx* c, int nt, int nq, int n_frames) {
   const bool cells_ok = match_cells_supported(nt, nq);      // the cell-hash search serves sets of up to 1.8 M points
-  if (c->match_mode != 0) return (c->match_mode == 3 && !cells_ok) ? 2 : c->match_mode;
+  if (c->match_mode != 0) {
+    int m = c->match_mode;
+    const bool hash = m >= 4;                               // 4 / 5: exact-duplicate pass first, at any size it takes
+    if (hash) m -= 2;
+    if (m == 3 && !cells_ok) m = 2;
+    return (hash && match_hash_supported(nt, n_frames)) ? m + 2 : m;
+  }
   if ((double)nt * (double)nq < 4.0e6) return 1;
   static const int forced = [] { const char* e = getenv("VO_MATCH_AUTO"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 3) ? v : 0; }();
-  if (forced) return (forced == 3 && !cells_ok) ? 2 : forced;
-  return (n_frames >= 8 && cells_ok) ? 3 : 2;
+  if (forced) return with_hash((forced == 3 && !cells_ok) ? 2 : forced, nt, n_frames);
+  return with_hash((n_frames >= 8 && cells_ok) ? 3 : 2, nt, n_frames);
 }
 
 // frames of different sizes: the full scan, or -- from the sizes on where a sorted search pays -- the cell-hash search (its
-// workspace is then laid out for the larger capacity in both roles); the bucket-pruned scan takes one size only
+// workspace is then laid out for the larger capacity in both roles), with the exact-duplicate pass in front of it like
+// match_variant decides; the bucket-pruned scan takes one size only
 static int ragged_variant(const vo_ctx* c, int nt_cap, int q_cap, int n_frames) {
   const int v = match_variant(c, nt_cap, q_cap, n_frames);
-  return (v == 1 || !match_cells_supported(nt_cap, nt_cap)) ? 1 : 3;
+  if (v == 1 || !match_cells_supported(nt_cap, nt_cap)) return 1;
+  return v >= 4 ? 5 : 3;
 }
 
 int vo_match_set_mode(vo_ctx* c, int mode) {
   VO_REQUIRE(c, "ctx is null");
-  VO_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (auto), 1 (full scan), 2 (bucket-pruned scan) or 3 (cell-hash search)");
+  VO_REQUIRE(mode >= 0 && mode <= 5, "mode must be 0 (auto), 1 (full scan), 2 (bucket-pruned scan), 3 (cell-hash search), "
+                                     "4 / 5 (exact-duplicate pass, then 2 / 3)");
   c->match_mode = mode;
   return VO_OK;
 }

@@ -168,7 +168,14 @@ struct MatchStrides {
   size_t ws;            // bytes between consecutive frames' workspaces (identical internal layout)
   size_t best;          // keys between consecutive frames
   size_t mm;            // bytes between consecutive frames' min/max words (kept contiguous: one memset)
+  const int* unres;     // hash-first (or null): per-frame count of queries the exact-duplicate pass left open; a frame with
+                        //   none is skipped by every kernel, a query it has answered is not sorted in (best0 tells)
+  const unsigned long long* best0;
 };
+
+// a key the exact-duplicate pass has written for an answered query: distance 0 and a tree index (an open query holds the
+// "no hit" key: radius^2 and index 0xffffffff, like match_init_kernel writes)
+__device__ __forceinline__ bool key_answered(unsigned long long k) { return (k >> 32) == 0ull && (unsigned)k != 0xffffffffu; }
 template <class T>
 __device__ __forceinline__ T* frame_ptr(T* p, size_t bytes) {
   return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + bytes);
@@ -211,6 +218,7 @@ __device__ __forceinline__ float ord2f(unsigned o) {
 __global__ __launch_bounds__(256) void match_minmax_kernel(const float* __restrict__ a, int na, int sa,
                                                            const float* __restrict__ b, int nb, int sb, unsigned* mm,
                                                            MatchStrides ms) {
+  if (ms.unres && ms.unres[blockIdx.z] == 0) return;
   a += blockIdx.z * ms.tree; b += blockIdx.z * ms.qry; mm = frame_ptr(mm, blockIdx.z * ms.mm);
   __shared__ float s_lo[4][10], s_hi[4][10];
   float lo[10], hi[10];
@@ -296,7 +304,9 @@ __global__ __launch_bounds__(256) void match_bucket_hist_kernel(const float* __r
                                                                 const float* __restrict__ qry, int nq,
                                                                 const unsigned* __restrict__ mm, float radius,
                                                                 BucketParams* bp_out, int* block_hist, MatchStrides ms) {
+  if (ms.unres && ms.unres[blockIdx.z] == 0) return;
   tree += blockIdx.z * ms.tree; qry += blockIdx.z * ms.qry;
+  const unsigned long long* best_in = ms.unres ? ms.best0 + blockIdx.z * ms.best : nullptr;
   mm = frame_ptr(mm, blockIdx.z * ms.mm); bp_out = frame_ptr(bp_out, blockIdx.z * ms.ws);
   block_hist = frame_ptr(block_hist, blockIdx.z * ms.ws);
   __shared__ int s_h[2 * NBUCKET];
@@ -312,6 +322,7 @@ __global__ __launch_bounds__(256) void match_bucket_hist_kernel(const float* __r
   sort_slice(nt, nq, lo, hi);
   for (int i = lo + threadIdx.x; i < hi; i += 256) {
     const bool is_t = i < nt;
+    if (!is_t && best_in && key_answered(best_in[i - nt])) continue;
     const float* pt = is_t ? tree + 10 * (size_t)i : qry + 10 * (size_t)(i - nt);
     atomicAdd(&s_h[(is_t ? 0 : NBUCKET) + bucket_of(pt[bp.dimA], pt[bp.dimB], bp)], 1);
   }
@@ -321,6 +332,7 @@ __global__ __launch_bounds__(256) void match_bucket_hist_kernel(const float* __r
 
 // grid 2 (tree half, query half) x NBUCKET threads (one bin each)
 __global__ __launch_bounds__(NBUCKET) void match_bucket_offsets_kernel(int* block_hist, int* starts, MatchStrides ms) {
+  if (ms.unres && ms.unres[blockIdx.z] == 0) return;
   block_hist = frame_ptr(block_hist, blockIdx.z * ms.ws); starts = frame_ptr(starts, blockIdx.z * ms.ws);
   __shared__ int s_w[NBUCKET / 64];
   const int half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -354,6 +366,7 @@ __global__ __launch_bounds__(256) void match_bucket_place_kernel(const float* __
                                                                  const int* __restrict__ block_off, float* tree_rec,
                                                                  float* qry_rec, unsigned long long* best, float r2,
                                                                  MatchStrides ms) {
+  if (ms.unres && ms.unres[blockIdx.z] == 0) return;
   tree += blockIdx.z * ms.tree; qry += blockIdx.z * ms.qry; best += blockIdx.z * ms.best;
   bpp = frame_ptr(bpp, blockIdx.z * ms.ws); block_off = frame_ptr(block_off, blockIdx.z * ms.ws);
   tree_rec = frame_ptr(tree_rec, blockIdx.z * ms.ws); qry_rec = frame_ptr(qry_rec, blockIdx.z * ms.ws);
@@ -366,6 +379,7 @@ __global__ __launch_bounds__(256) void match_bucket_place_kernel(const float* __
   for (int i = lo + threadIdx.x; i < hi; i += 256) {
     const bool is_t = i < nt;
     const int idx = is_t ? i : i - nt;
+    if (!is_t && ms.unres && key_answered(best[idx])) continue;       // answered by the exact-duplicate pass: not a query any more
     const float2* src = reinterpret_cast<const float2*>((is_t ? tree : qry) + 10 * (size_t)idx);
     float2 v[5];
 #pragma unroll
@@ -393,6 +407,7 @@ __global__ __launch_bounds__(MBP) void match_pruned_kernel(const float* __restri
                                                           const int* __restrict__ starts,
                                                           const BucketParams* __restrict__ bpp, int nchunks, float r2,
                                                           unsigned long long* __restrict__ best, MatchStrides ms) {
+  if (ms.unres && ms.unres[blockIdx.z] == 0) return;
   tree_rec = frame_ptr(tree_rec, blockIdx.z * ms.ws); qry_rec = frame_ptr(qry_rec, blockIdx.z * ms.ws);
   starts = frame_ptr(starts, blockIdx.z * ms.ws); bpp = frame_ptr(bpp, blockIdx.z * ms.ws);
   best += blockIdx.z * ms.best;
@@ -571,7 +586,8 @@ size_t match_pruned_workspace_bytes(int nt, int nq, int n_frames) {
 
 static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt, const float* qry, int nq,
                                       float radius, float r2, unsigned long long* d_best, void* ws, int n_cu,
-                                      int n_frames, size_t tree_stride, size_t qry_stride, size_t best_stride) {
+                                      int n_frames, size_t tree_stride, size_t qry_stride, size_t best_stride,
+                                      const int* d_unres = nullptr) {
   // workspace carve of frame 0 (all offsets multiples of 16 bytes); frame f lives ws_stride bytes further
   unsigned* mm = static_cast<unsigned*>(ws);
   char* p = static_cast<char*>(ws) + align256(128 * (size_t)n_frames);
@@ -584,6 +600,7 @@ static hipError_t launch_match_pruned(hipStream_t st, const float* tree, int nt,
   ms.tree = tree_stride; ms.qry = qry_stride; ms.best = best_stride;
   ms.ws = n_frames > 1 ? match_frame_ws_bytes(nt, nq) : 0;
   ms.mm = 128;
+  ms.unres = d_unres; ms.best0 = d_best;
   const unsigned Z = (unsigned)n_frames;
   hipError_t e = hipMemsetAsync(mm, 0xff, 128 * (size_t)n_frames, st);
   if (e != hipSuccess) return e;
@@ -799,10 +816,15 @@ struct CellArgs {
   int rs_capacity;
   const int* d_n1; const int* d_n2;   // ragged frames (or null): per-frame sizes of set 1 / set 2; tree / qry / nt / nq above are
                                       //   then set 1 / set 2 and their capacities, and every frame picks its roles (cell_sets)
+  const int* unres;         // hash-first (or null): per-frame count of queries the exact-duplicate pass left open.  A frame with
+                            //   none is skipped by every kernel; a query that pass has answered (key_answered(best[q])) is not
+                            //   sorted in, so the search neither visits nor overwrites it
 };
 
-// the two sets of frame f with their roles: the larger one is the tree, set 1 on ties (vo_complete.cpp:15-20)
-__device__ __forceinline__ void cell_sets(const CellArgs& a, int f, const float*& tree, const float*& qry, int& nt, int& nq) {
+// the two sets of frame f with their roles: the larger one is the tree, set 1 on ties (vo_complete.cpp:15-20).  A: CellArgs
+// or HashArgs -- (tree, qry, nt, nq) are (set 1, set 2, capacity 1, capacity 2) when the per-frame sizes are given.
+template <class A>
+__device__ __forceinline__ void cell_sets(const A& a, int f, const float*& tree, const float*& qry, int& nt, int& nq) {
   tree = a.tree + f * a.tree_stride; qry = a.qry + f * a.qry_stride; nt = a.nt; nq = a.nq;
   if (a.d_n1) {
     int n1 = a.d_n1[f], n2 = a.d_n2[f];
@@ -870,6 +892,7 @@ __device__ __forceinline__ int scan512(int c0, int c1, int* s_w, int& total) {
 // grid bounds: one workgroup per frame, min/max per component over a strided sample of both sets -> CellParams
 __global__ __launch_bounds__(1024) void cell_bounds_kernel(CellArgs a) {
   const int f = blockIdx.x;
+  if (a.unres && a.unres[f] == 0) return;
   const float* tree; const float* qry; int nt, nq;
   cell_sets(a, f, tree, qry, nt, nq);
   __shared__ float s_lo[16][10], s_hi[16][10];
@@ -919,6 +942,7 @@ __global__ __launch_bounds__(1024) void cell_bounds_kernel(CellArgs a) {
 __global__ __launch_bounds__(256) void cell_place_kernel(CellArgs a) {
   int f, blk;
   if (!xcd_frame_block(a.tb + a.qb, a.n_frames, f, blk)) return;
+  if (a.unres && a.unres[f] == 0) return;
   char* ws = a.ws + f * a.ws_stride;
   const bool is_t = blk < a.tb;
   const float* tree; const float* qry; int nt, nq;
@@ -928,6 +952,7 @@ __global__ __launch_bounds__(256) void cell_place_kernel(CellArgs a) {
   const int lo = lo0 < n_set ? lo0 : n_set;                // (ragged frames: a slice beyond the frame's set is empty)
   const int hi = lo + CELL_SLICE < n_set ? lo + CELL_SLICE : n_set;
   const float* src = is_t ? tree : qry;
+  const unsigned long long* answered = (!is_t && a.unres) ? a.best + f * a.best_stride : nullptr;
   __shared__ int s_h[HCPAD];
   __shared__ int s_w[4];
   __shared__ uint4 s_rec[CELL_SLICE];
@@ -941,7 +966,7 @@ __global__ __launch_bounds__(256) void cell_place_kernel(CellArgs a) {
   for (int k = 0; k < CELL_PPT; ++k) {
     const int i = lo + k * 256 + tid;
     bins[k] = -1; word[k] = 0; rank[k] = 0; box[k] = 0;
-    if (i < hi) {
+    if (i < hi && !(answered && key_answered(answered[i]))) {
       float v10[10];
       load10(src + 10 * (size_t)i, v10);
       int coarse, fine;
@@ -973,13 +998,14 @@ __global__ __launch_bounds__(256) void cell_place_kernel(CellArgs a) {
   }
   __syncthreads();
   uint4* dst = reinterpret_cast<uint4*>(ws + (is_t ? a.w.t1 : a.w.ql1)) + lo;
-  for (int j = tid; j < hi - lo; j += 256) dst[j] = s_rec[j];
+  for (int j = tid; j < total; j += 256) dst[j] = s_rec[j];      // (total < hi - lo when answered queries were left out)
 }
 
 // offsets: grid (2 halves: tree, queries) x frames, HCPAD threads (one coarse bin each): column sums of the directory,
 // exclusive scan over the bins -> coarse_start[2][HCPAD + 1]
 __global__ __launch_bounds__(HCPAD) void cell_offsets_kernel(CellArgs a) {
   const int f = blockIdx.z;
+  if (a.unres && a.unres[f] == 0) return;
   char* ws = a.ws + f * a.ws_stride;
   const unsigned* dir = reinterpret_cast<const unsigned*>(ws + a.w.dir);
   int* starts = reinterpret_cast<int*>(ws + a.w.coarse_start);
@@ -1023,6 +1049,7 @@ static_assert(HNC % FG == 0 && FG * HCOARSE <= FCNT, "");
 __global__ __launch_bounds__(256) void cell_fine_kernel(CellArgs a) {
   int f, grp;
   if (!xcd_frame_block(HCOARSE / FG, a.n_frames, f, grp)) return;
+  if (a.unres && a.unres[f] == 0) return;
   char* ws = a.ws + f * a.ws_stride;
   const int coarse = grp * FG;                             // first bin of the group (same c0 for all: HNC % FG == 0)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1227,6 +1254,7 @@ template <int MODE>
 __global__ __launch_bounds__(CS_THREADS, CS_THREADS * CS_WG_PER_CU / 256) void cell_search_kernel(CellArgs a) {
   int f, blk;
   if (!xcd_frame_block(HNC * CS_STRIPS, a.n_frames, f, blk)) return;
+  if (a.unres && a.unres[f] == 0) return;
   char* ws = a.ws + f * a.ws_stride;
   const int c0 = blk / CS_STRIPS, c1f = (blk - c0 * CS_STRIPS) * CS_NB;
   const int nb_here = HNC - c1f < CS_NB ? HNC - c1f : CS_NB;
@@ -1452,12 +1480,229 @@ __global__ __launch_bounds__(CS_THREADS, CS_THREADS * CS_WG_PER_CU / 256) void c
   }
 }
 
+
+// ---- exact duplicates first ("hash-first") ------------------------------------------------------------------------
+// The appearance of a landmark is COPIED from frame to frame (the reference's dataset: max |difference| 0 over all frames,
+// SURVEY appendix C; the synthetic generators likewise), so for almost every query the nearest tree point is a bitwise copy
+// of it, at distance exactly 0 -- the smallest value the reference's sum of squares (brute_force_search.h:34) can take.  This
+// pass finds those copies by hashing, exactly:
+//   * a row is SAFE when its ten components are finite and |x| >= 2^-40.  For a safe query q and ANY tree row t,
+//     d2(t, q) == 0 in the reference's float arithmetic iff t == q component by component: a difference t_k - q_k != 0
+//     has magnitude >= ulp(2^-40)/2 = 2^-64, its square 2^-128 is a normal float, and a sum of non-negative terms with one
+//     positive term is positive.  (Without the bound tiny differences square to 0 by underflow: such rows go to the
+//     general search, like NaN / inf rows, which no distance test can pass.)
+//   * every slice of <= 0.39 * S tree points gets its own open-addressing table of S 32-bit words in LDS (word = tag : 17 |
+//     index in the slice : 14; linear probing; a row equal to one already present takes the SMALLER index into that entry by
+//     atomicMin after comparing the two rows, so a table holds one entry per distinct row -- the lowest index, which is the
+//     reference-order tie rule of this library's matcher) and stores the finished table as one contiguous image: no global
+//     atomics (match.hip's level-1 comment: a global atomic per point is 64 scattered memory-side requests per wave).
+//   * a safe query looks its hash up in every slice's table (independent loads, issued together), fetches the row of an
+//     entry whose tag agrees and compares all ten floats: equal -> key (distance 0, lowest index over the slices).  With
+//     radius^2 > 0 that key is FINAL: no tree point is closer than 0, and every tree point at distance 0 is a bitwise copy,
+//     all of which the tables hold.
+// Queries without a copy (new landmarks, noise, unsafe rows) keep the "no hit" key and are counted per frame; the general
+// search that follows (bucket-pruned scan or cell-hash search) then sorts in only those queries and is skipped altogether
+// by a frame that has none.  Results are identical to the general search alone for every input
+// (tests/test_gpu_parity.py::test_matcher_variants_agree, tests/test_gpu_hashfirst.py).
+constexpr unsigned HJ_EMPTY = 0xffffffffu;
+constexpr int HJ_IB = 14;                          // bits of a point's index inside its slice
+constexpr unsigned HJ_IMASK = (1u << HJ_IB) - 1u;
+constexpr unsigned HJ_TMASK = (1u << (31 - HJ_IB)) - 1u;   // 17 tag bits: a word never equals HJ_EMPTY
+
+struct HashArgs {
+  const float* tree; const float* qry; int nt, nq;          // as CellArgs (set 1 / set 2 and capacities when ragged)
+  size_t tree_stride, qry_stride, best_stride;
+  const int* d_n1; const int* d_n2;
+  unsigned* tables;           // frame 0's tables: slices << log2s words; frame f = tables + f * tables_stride
+  size_t tables_stride;
+  int* unres;                 // [n_frames] queries left open
+  unsigned long long* best;
+  float r2;
+  int n_frames, slices, slice, qblocks;
+};
+
+__device__ __forceinline__ bool row_safe(const Row10& r) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { const float m = fabsf(r.v[k]); ok = ok && (m >= 0x1p-40f) && (m < INFINITY); }   // NaN fails the first test
+  return ok;
+}
+__device__ __forceinline__ bool rows_equal(const Row10& a, const Row10& b) {
+  unsigned d = 0;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) d |= __float_as_uint(a.v[k]) ^ __float_as_uint(b.v[k]);
+  return d == 0u;                                  // bitwise: for safe rows (no zeros, no NaN) the same as float equality
+}
+__device__ __forceinline__ unsigned rotl32(unsigned x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ unsigned row_hash(const Row10& r) {                 // MurmurHash3 x86_32 over the ten words
+  unsigned h = 0x9747b28cu;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    unsigned w = __float_as_uint(r.v[k]) * 0xcc9e2d51u;
+    w = rotl32(w, 15) * 0x1b873593u;
+    h = rotl32(h ^ w, 13) * 5u + 0xe6546b64u;
+  }
+  h ^= 40u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+
+template <int LOG2S, int THREADS>
+__global__ __launch_bounds__(THREADS) void hash_build_kernel(HashArgs a) {
+  constexpr unsigned S = 1u << LOG2S;
+  int f, b;
+  if (!xcd_frame_block(a.slices, a.n_frames, f, b)) return;
+  const float* tree; const float* qry; int nt, nq;
+  cell_sets(a, f, tree, qry, nt, nq);
+  const int tid = threadIdx.x;
+  if (b == 0 && tid == 0) a.unres[f] = 0;                 // (the lookup kernel is a later launch)
+  const int lo = b * a.slice;
+  if (lo >= nt) return;                                   // ragged frames: no such slice (the lookup knows from nt)
+  const int hi = lo + a.slice < nt ? lo + a.slice : nt;
+  __shared__ __attribute__((aligned(16))) unsigned s_tab[S];
+  for (unsigned k = tid; k < S / 4; k += THREADS) reinterpret_cast<uint4*>(s_tab)[k] = make_uint4(HJ_EMPTY, HJ_EMPTY, HJ_EMPTY, HJ_EMPTY);
+  __syncthreads();
+  for (int i = lo + tid; i < hi; i += THREADS) {
+    const Row10 r = load_row(tree + 10 * (size_t)i);
+    if (!row_safe(r)) continue;                           // can never be at distance 0 from a safe query
+    const unsigned h = row_hash(r);
+    const unsigned word = (((h >> LOG2S) & HJ_TMASK) << HJ_IB) | (unsigned)(i - lo);
+    unsigned s = h & (S - 1u);
+    for (unsigned n = 0; n < S; ++n) {                     // (slice < S: an empty slot always exists)
+      const unsigned old = atomicCAS(&s_tab[s], HJ_EMPTY, word);
+      if (old == HJ_EMPTY) break;
+      if ((old >> HJ_IB) == (word >> HJ_IB)) {
+        // same tag: the same row?  (the entry's index may be lowered meanwhile -- by a copy of the same row)
+        const Row10 o = load_row(tree + 10 * (size_t)(lo + (int)(old & HJ_IMASK)));
+        if (rows_equal(o, r)) { atomicMin(&s_tab[s], word); break; }
+      }
+      s = (s + 1u) & (S - 1u);
+    }
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(a.tables + f * a.tables_stride + ((size_t)b << LOG2S));
+  for (unsigned k = tid; k < S / 4; k += THREADS) dst[k] = reinterpret_cast<const uint4*>(s_tab)[k];
+}
+
+template <int LOG2S>
+__global__ __launch_bounds__(256) void hash_probe_kernel(HashArgs a) {
+  constexpr unsigned S = 1u << LOG2S, MASK = S - 1u;
+  int f, blk;
+  if (!xcd_frame_block(a.qblocks, a.n_frames, f, blk)) return;
+  const float* tree; const float* qry; int nt, nq;
+  cell_sets(a, f, tree, qry, nt, nq);
+  if (blk * 256 >= nq) return;                            // (uniform)
+  __shared__ int s_open;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_open = 0;
+  const int j = blk * 256 + tid;
+  const bool live = j < nq;
+  const unsigned* tab = a.tables + f * a.tables_stride;
+  const int live_slices = (nt + a.slice - 1) / a.slice;
+  unsigned found = 0xffffffffu;
+  Row10 q;
+  if (live) q = load_row(qry + 10 * (size_t)j);
+  if (live && a.r2 > 0.f && row_safe(q)) {
+    const unsigned h = row_hash(q), tag = (h >> LOG2S) & HJ_TMASK, home = h & MASK, next = (home + 1u) & MASK;
+    for (int s0 = 0; s0 < live_slices; s0 += 4) {
+      unsigned w0[4], w1[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {                       // eight independent loads
+        const bool have = s0 + k < live_slices;
+        const unsigned* t = tab + ((size_t)(have ? s0 + k : s0) << LOG2S);
+        w0[k] = t[home]; w1[k] = t[next];
+        if (!have) w0[k] = HJ_EMPTY;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (w0[k] == HJ_EMPTY) continue;
+        const unsigned* t = tab + ((size_t)(s0 + k) << LOG2S);
+        const int base = (s0 + k) * a.slice;
+        unsigned w = w0[k], s = home;
+        for (unsigned n = 0; n < S; ++n) {                 // the chain from the home slot to the first empty one
+          if (w == HJ_EMPTY) break;
+          if ((w >> HJ_IB) == tag) {
+            const int cand = base + (int)(w & HJ_IMASK);
+            if (rows_equal(load_row(tree + 10 * (size_t)cand), q)) { found = (unsigned)cand < found ? (unsigned)cand : found; break; }   // one entry per distinct row
+          }
+          s = (s + 1u) & MASK;
+          w = n == 0 ? w1[k] : t[s];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const bool open = live && found == 0xffffffffu;
+  const unsigned long long m = __ballot(open);
+  if ((tid & 63) == 0 && m != 0ull) atomicAdd(&s_open, __popcll(m));
+  if (live) {
+    unsigned long long* best = a.best + f * a.best_stride;
+    best[j] = open ? (((unsigned long long)__float_as_uint(a.r2) << 32) | 0xffffffffull) : (unsigned long long)found;
+  }
+  __syncthreads();
+  if (tid == 0 && s_open > 0) atomicAdd(&a.unres[f], s_open);
+}
+
+// table size per slice (2^log2s words), workgroup size and points per slice (<= 0.39 * 2^log2s: load factor of the tables)
+struct HashPlan { int log2s, threads, slice, slices; };
+static bool hash_plan(int nt, int n_frames, HashPlan& p) {
+  if (nt <= 0) return false;
+  static const int slice_of[4] = {1600, 3200, 6400, 12800};            // log2s 12 .. 15
+  int l = 0;
+  if (n_frames >= 8) {                 // many frames fill the GPU by themselves: few, large tables (few lookups per query)
+    while (l < 3 && (nt + slice_of[l] - 1) / slice_of[l] > 4) ++l;
+  }                                    // few frames: many small slices, so that the build itself is spread over the CUs
+  p.log2s = 12 + l; p.threads = l == 0 ? 256 : (l == 1 ? 512 : 1024); p.slice = slice_of[l];
+  p.slices = (nt + p.slice - 1) / p.slice;
+  return p.slices <= (n_frames >= 8 ? 8 : 64);
+}
+// workspace of the pass: the open-query counters, then the tables
+static size_t hash_ws_bytes(int nt, int n_frames) {
+  HashPlan p;
+  if (!hash_plan(nt, n_frames, p)) return 0;
+  return align256(sizeof(int) * (size_t)n_frames) + align256(sizeof(unsigned) * ((size_t)p.slices << p.log2s)) * (size_t)n_frames;
+}
+bool match_hash_supported(int nt, int n_frames) { HashPlan p; return hash_plan(nt, n_frames, p); }
+size_t match_hash_workspace_bytes(int nt, int n_frames) { return hash_ws_bytes(nt, n_frames); }
+
+// (tree, qry, nt, nq): the two sets in their roles, or (set 1, set 2, capacities) with the per-frame sizes d_n1 / d_n2
+static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, const float* qry, int nq, float r2,
+                                    unsigned long long* d_best, void* ws, int n_frames, size_t tree_stride, size_t qry_stride,
+                                    size_t best_stride, const int* d_n1, const int* d_n2, int** d_unres_out) {
+  HashPlan p;
+  const int nt_plan = d_n1 ? (nt > nq ? nt : nq) : nt;
+  if (!hash_plan(nt_plan, n_frames, p)) return hipErrorInvalidValue;
+  HashArgs a;
+  a.tree = tree; a.qry = qry; a.nt = nt; a.nq = nq;
+  a.tree_stride = tree_stride; a.qry_stride = qry_stride; a.best_stride = best_stride;
+  a.d_n1 = d_n1; a.d_n2 = d_n2;
+  a.unres = static_cast<int*>(ws);
+  a.tables = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + align256(sizeof(int) * (size_t)n_frames));
+  a.tables_stride = align256(sizeof(unsigned) * ((size_t)p.slices << p.log2s)) / sizeof(unsigned);
+  a.best = d_best; a.r2 = r2;
+  a.n_frames = n_frames; a.slices = p.slices; a.slice = p.slice;
+  const int q_cap = d_n1 ? (nt < nq ? nt : nq) : nq;       // ragged: either set may be the queries, never more than the smaller capacity
+  a.qblocks = (q_cap + 255) / 256;
+  const dim3 gb(xcd_grid(p.slices, n_frames)), gp(xcd_grid(a.qblocks, n_frames));
+  switch (p.log2s) {
+    case 12: hipLaunchKernelGGL((hash_build_kernel<12, 256>), gb, dim3(256), 0, st, a);
+             hipLaunchKernelGGL(hash_probe_kernel<12>, gp, dim3(256), 0, st, a); break;
+    case 13: hipLaunchKernelGGL((hash_build_kernel<13, 512>), gb, dim3(512), 0, st, a);
+             hipLaunchKernelGGL(hash_probe_kernel<13>, gp, dim3(256), 0, st, a); break;
+    case 14: hipLaunchKernelGGL((hash_build_kernel<14, 1024>), gb, dim3(1024), 0, st, a);
+             hipLaunchKernelGGL(hash_probe_kernel<14>, gp, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((hash_build_kernel<15, 1024>), gb, dim3(1024), 0, st, a);
+             hipLaunchKernelGGL(hash_probe_kernel<15>, gp, dim3(256), 0, st, a); break;
+  }
+  *d_unres_out = a.unres;
+  return hipGetLastError();
+}
+
 static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tree, int nt, const float* qry, int nq,
                                     float radius, float r2, unsigned long long* d_best, void* ws, int n_frames,
                                     size_t tree_stride, size_t qry_stride, size_t best_stride, const int* d_n1 = nullptr,
-                                    const int* d_n2 = nullptr) {
+                                    const int* d_n2 = nullptr, const int* d_unres = nullptr) {
   a.tree = tree; a.qry = qry; a.nt = nt; a.nq = nq;
-  a.d_n1 = d_n1; a.d_n2 = d_n2;
+  a.d_n1 = d_n1; a.d_n2 = d_n2; a.unres = d_unres;
   a.ws = static_cast<char*>(ws);
   if (d_n1) { const int cap = nt > nq ? nt : nq; a.w = cell_ws_layout(cap, cap); }   // ragged: either set may play either role
   else a.w = cell_ws_layout(nt, nq);
@@ -1477,10 +1722,10 @@ static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tr
 static hipError_t launch_match_cells(hipStream_t st, const float* tree, int nt, const float* qry, int nq,
                                      float radius, float r2, unsigned long long* d_best, void* ws, int n_frames,
                                      size_t tree_stride, size_t qry_stride, size_t best_stride, const int* d_n1 = nullptr,
-                                     const int* d_n2 = nullptr) {
+                                     const int* d_n2 = nullptr, const int* d_unres = nullptr) {
   CellArgs a;
   hipError_t e = launch_cells_sort(st, a, tree, nt, qry, nq, radius, r2, d_best, ws, n_frames, tree_stride, qry_stride,
-                                   best_stride, d_n1, d_n2);
+                                   best_stride, d_n1, d_n2, d_unres);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(cell_search_kernel<0>, dim3(xcd_grid(HNC * CS_STRIPS, n_frames)), dim3(CS_THREADS), 0, st, a);
   return hipGetLastError();
@@ -1507,16 +1752,28 @@ hipError_t launch_radius_search(hipStream_t st, const float* d_tree, int nt, con
 hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t a1_stride, const float* d_a2, int n2,
                               size_t a2_stride, float radius, int32_t* d_out_pairs, size_t out_stride, int* d_n_out,
                               unsigned long long* d_best, int* d_scratch, int n_cu, void* d_prune_ws, int n_frames,
-                              int variant, const int* d_n1, const int* d_n2) {
+                              int variant_in, const int* d_n1, const int* d_n2) {
+  // variants 4 / 5: the exact-duplicate pass first, then variant 2 / 3 for the queries it left open (its workspace comes
+  // first in d_prune_ws)
+  const bool hash_first = variant_in >= 4 && d_prune_ws != nullptr;
+  const int variant = variant_in >= 4 ? variant_in - 2 : variant_in;
+  int* d_unres = nullptr;
   if (d_n1 && d_n2) {
     // ragged frames: every frame its own sizes and roles; full scan or (variant 3) the cell-hash search.
     // q = min(n1, n2) is the room per frame in d_best / d_out_pairs.
     const int q = n1 < n2 ? n1 : n2;
     const float r2 = radius * radius;
     if (q > 0 && variant == 3 && d_prune_ws) {
+      void* ws = d_prune_ws;
+      if (hash_first) {
+        hipError_t eh = launch_hash_first(st, d_a1, n1, d_a2, n2, r2, d_best, d_prune_ws, n_frames, a1_stride, a2_stride, (size_t)q,
+                                          d_n1, d_n2, &d_unres);
+        if (eh != hipSuccess) return eh;
+        ws = static_cast<char*>(d_prune_ws) + hash_ws_bytes(n1 > n2 ? n1 : n2, n_frames);
+      }
       // the cell-hash search with per-frame sizes and roles (workspace laid out for max(n1, n2) in both roles)
-      hipError_t ec = launch_match_cells(st, d_a1, n1, d_a2, n2, radius, r2, d_best, d_prune_ws, n_frames, a1_stride, a2_stride,
-                                         (size_t)q, d_n1, d_n2);
+      hipError_t ec = launch_match_cells(st, d_a1, n1, d_a2, n2, radius, r2, d_best, ws, n_frames, a1_stride, a2_stride,
+                                         (size_t)q, d_n1, d_n2, d_unres);
       if (ec != hipSuccess) return ec;
     } else if (q > 0) {
       hipLaunchKernelGGL(match_init_kernel, dim3((q + 255) / 256, 1, (unsigned)n_frames), dim3(256), 0, st, d_best, q, r2, (size_t)q);
@@ -1543,13 +1800,20 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
   const float r2 = radius * radius;
   const size_t best_stride = n_frames > 1 ? (size_t)nq : 0;
   const unsigned Z = (unsigned)n_frames;
+  void* ws = d_prune_ws;
+  if (hash_first && nq > 0 && nt > 0 && (variant == 2 || variant == 3)) {
+    hipError_t eh = launch_hash_first(st, tree, nt, qry, nq, r2, d_best, d_prune_ws, n_frames, n_frames > 1 ? ts : 0,
+                                      n_frames > 1 ? qs : 0, best_stride, nullptr, nullptr, &d_unres);
+    if (eh != hipSuccess) return eh;
+    ws = static_cast<char*>(d_prune_ws) + hash_ws_bytes(nt, n_frames);
+  }
   if (nq > 0 && nt > 0 && d_prune_ws && variant == 3) {
-    hipError_t ep = launch_match_cells(st, tree, nt, qry, nq, radius, r2, d_best, d_prune_ws, n_frames, ts, qs,
-                                       best_stride);
+    hipError_t ep = launch_match_cells(st, tree, nt, qry, nq, radius, r2, d_best, ws, n_frames, ts, qs,
+                                       best_stride, nullptr, nullptr, d_unres);
     if (ep != hipSuccess) return ep;
   } else if (nq > 0 && nt > 0 && d_prune_ws) {
-    hipError_t ep = launch_match_pruned(st, tree, nt, qry, nq, radius, r2, d_best, d_prune_ws, n_cu, n_frames, ts, qs,
-                                        best_stride);
+    hipError_t ep = launch_match_pruned(st, tree, nt, qry, nq, radius, r2, d_best, ws, n_cu, n_frames, ts, qs,
+                                        best_stride, d_unres);
     if (ep != hipSuccess) return ep;
   } else if (nq > 0) {
     hipLaunchKernelGGL(match_init_kernel, dim3((nq + 255) / 256, 1, Z), dim3(256), 0, st, d_best, nq, r2, best_stride);

@@ -158,14 +158,19 @@ hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const in
                        int32_t* d_out, int* d_n_out, unsigned long long* d_table /* n_ref words */,
                        int* d_scratch);
 
-// matcher variants: 1 = full scan (no workspace), 2 = bucket-pruned scan, 3 = cell-hash search; the
+// matcher variants: 1 = full scan (no workspace), 2 = bucket-pruned scan, 3 = cell-hash search, 4 / 5 = the
+// exact-duplicate pass first ("hash-first", match.hip), then variant 2 / 3 for the queries it left open; the
 // workspace of variant v holds match_workspace_bytes(v, nt, nq, n_frames) bytes
 size_t match_pruned_workspace_bytes(int nt, int nq, int n_frames);
 size_t match_cells_workspace_bytes(int nt, int nq, int n_frames);
+size_t match_hash_workspace_bytes(int nt, int n_frames);
 bool match_cells_supported(int nt, int nq);   // set sizes the cell-hash search takes (beyond: the bucket-pruned scan)
+bool match_hash_supported(int nt, int n_frames);   // tree sizes the exact-duplicate pass takes (beyond: the general search alone)
 inline size_t match_workspace_bytes(int variant, int nt, int nq, int n_frames) {
-  return variant == 3 ? match_cells_workspace_bytes(nt, nq, n_frames)
-       : variant == 2 ? match_pruned_workspace_bytes(nt, nq, n_frames) : 0;
+  const size_t hash = variant >= 4 ? match_hash_workspace_bytes(nt, n_frames) : 0;
+  const int v = variant >= 4 ? variant - 2 : variant;
+  return hash + (v == 3 ? match_cells_workspace_bytes(nt, nq, n_frames)
+               : v == 2 ? match_pruned_workspace_bytes(nt, nq, n_frames) : 0);
 }
 // n_frames frames of identical set sizes, frame f at base + f*stride (strides in floats / pairs);
 // d_best: n_frames*min(n1,n2) keys; d_scratch: n_frames * compaction_scratch_ints(min(n1,n2)) ints; d_n_out[n_frames]
