@@ -67,7 +67,7 @@ def test_hash_first_adversarial_rows(vo, o32):
 
 
 def test_hash_first_many_slices_and_batches(vo, ctx, o32):
-    """several tables per frame (70k points: five / forty-four slices), frames of different sizes in one call with either
+    """several parts per table (70k points: eight parts), frames of different sizes in one call with either
     image the larger one, and a batch whose frames differ in how many queries the pass leaves open (none ... all)"""
     rng = np.random.default_rng(43)
     big = rng.uniform(-1, 1, (70000, 10)).astype(np.float32)

@@ -1491,41 +1491,49 @@ __global__ __launch_bounds__(CS_THREADS, CS_THREADS * CS_WG_PER_CU / 256) void c
 //     has magnitude >= ulp(2^-40)/2 = 2^-64, its square 2^-128 is a normal float, and a sum of non-negative terms with one
 //     positive term is positive.  (Without the bound tiny differences square to 0 by underflow: such rows go to the
 //     general search, like NaN / inf rows, which no distance test can pass.)
-//   * every slice of <= 0.39 * S tree points gets its own open-addressing table of S 32-bit words in LDS (word = tag : 17 |
-//     index in the slice : 14; linear probing; a row equal to one already present takes the SMALLER index into that entry by
-//     atomicMin after comparing the two rows, so a table holds one entry per distinct row -- the lowest index, which is the
-//     reference-order tie rule of this library's matcher) and stores the finished table as one contiguous image: no global
-//     atomics (match.hip's level-1 comment: a global atomic per point is 64 scattered memory-side requests per wave).
-//   * a safe query looks its hash up in every slice's table (independent loads, issued together), fetches the row of an
-//     entry whose tag agrees and compares all ten floats: equal -> key (distance 0, lowest index over the slices).  With
-//     radius^2 > 0 that key is FINAL: no tree point is closer than 0, and every tree point at distance 0 is a bitwise copy,
-//     all of which the tables hold.
-// Queries without a copy (new landmarks, noise, unsafe rows) keep the "no hit" key and are counted per frame; the general
-// search that follows (bucket-pruned scan or cell-hash search) then sorts in only those queries and is skipped altogether
-// by a frame that has none.  Results are identical to the general search alone for every input
+//   * the frame's table is cut into P parts BY HASH (top bits), S 32-bit words each, one workgroup per part: it streams ALL
+//     the frame's tree rows (the P workgroups of a frame share an XCD, hence its L2), keeps the safe rows of its part and
+//     inserts them into an open-addressing table in LDS (word = tag | index, index in the low `ib` bits; linear probing from
+//     an even home slot; a row equal to one already present takes the SMALLER index into that entry by atomicMin after
+//     comparing the two rows, so the table holds one entry per distinct row -- the lowest index, which is the tie rule of this
+//     library's matcher), then stores the finished part as one contiguous image.  No global atomics (level 1's comment above:
+//     a global atomic per point is 64 scattered memory-side requests per wave).
+//   * a safe query reads ONE 8-byte word -- home slot and its neighbour -- of the part its hash selects (a first version
+//     cut the tree by position and looked into every slice's table: 8 scattered loads per query at ~200 G scattered
+//     lane-loads/s chip-wide made the lookup 0.64 ms per 200 x 50k frames), fetches the row of an entry whose tag agrees
+//     and compares all ten floats: equal -> key (distance 0, that entry's index).  With radius^2 > 0 the key is FINAL: no tree
+//     point is closer than 0, and every tree point at distance 0 is a bitwise copy, merged into that entry.
+// Queries without a copy (new landmarks, noise, unsafe rows; rows a full part could not take) keep the "no hit" key and are
+// counted per frame; the general search that follows (bucket-pruned scan or cell-hash search) then sorts in only those queries
+// and is skipped altogether by a frame that has none.  Results are identical to the general search alone for every input
 // (tests/test_gpu_parity.py::test_matcher_variants_agree, tests/test_gpu_hashfirst.py).
 constexpr unsigned HJ_EMPTY = 0xffffffffu;
-constexpr int HJ_IB = 14;                          // bits of a point's index inside its slice
-constexpr unsigned HJ_IMASK = (1u << HJ_IB) - 1u;
-constexpr unsigned HJ_TMASK = (1u << (31 - HJ_IB)) - 1u;   // 17 tag bits: a word never equals HJ_EMPTY
+constexpr int HJ_THREADS = 768;                     // 12 waves: the table (<= 128 KiB) and a 2560-byte strip per wave fill the CU's LDS
+constexpr int HJ_NW = HJ_THREADS / 64;
+constexpr int HJ_STRIP = 320;                       // float2 per strip: 64 rows of 40 bytes
 
 struct HashArgs {
   const float* tree; const float* qry; int nt, nq;          // as CellArgs (set 1 / set 2 and capacities when ragged)
   size_t tree_stride, qry_stride, best_stride;
   const int* d_n1; const int* d_n2;
-  unsigned* tables;           // frame 0's tables: slices << log2s words; frame f = tables + f * tables_stride
+  unsigned* tables;           // frame 0's table: parts << log2s words; frame f = tables + f * tables_stride
   size_t tables_stride;
+  unsigned* hashes;           // frame 0's row hashes (tree order); frame f = hashes + f * hashes_stride
+  size_t hashes_stride;
   int* unres;                 // [n_frames] queries left open
   unsigned long long* best;
   float r2;
-  int n_frames, slices, slice, qblocks;
+  int n_frames, log2p, ib, qblocks, hblocks;   // parts = 1 << log2p; ib: index bits of a word (the tag takes the other 31 - ib)
 };
 
-__device__ __forceinline__ bool row_safe(const Row10& r) {
-  bool ok = true;
+__device__ __forceinline__ bool row_safe(const Row10& r) {       // every |x| in [2^-40, inf): an unsigned range test on the bits
+  unsigned worst = 0;
 #pragma unroll
-  for (int k = 0; k < 10; ++k) { const float m = fabsf(r.v[k]); ok = ok && (m >= 0x1p-40f) && (m < INFINITY); }   // NaN fails the first test
-  return ok;
+  for (int k = 0; k < 10; ++k) {
+    const unsigned t = (__float_as_uint(r.v[k]) & 0x7fffffffu) - 0x2b800000u;       // 2^-40 = 0x2b800000; smaller magnitudes wrap around
+    worst = t > worst ? t : worst;
+  }
+  return worst < 0x7f800000u - 0x2b800000u;                     // below +inf (NaN payloads lie above)
 }
 __device__ __forceinline__ bool rows_equal(const Row10& a, const Row10& b) {
   unsigned d = 0;
@@ -1534,55 +1542,177 @@ __device__ __forceinline__ bool rows_equal(const Row10& a, const Row10& b) {
   return d == 0u;                                  // bitwise: for safe rows (no zeros, no NaN) the same as float equality
 }
 __device__ __forceinline__ unsigned rotl32(unsigned x, int r) { return (x << r) | (x >> (32 - r)); }
-__device__ __forceinline__ unsigned row_hash(const Row10& r) {                 // MurmurHash3 x86_32 over the ten words
-  unsigned h = 0x9747b28cu;
+// One 32-bit hash per row; its top bits pick the part, its low bits the home slot, the bits in between are the tag.
+// Every workgroup of a frame hashes EVERY row of the tree (it keeps those of its part), in waves whose lanes all run the
+// same code, so the hash is on the critical path of the build: rotate-and-combine over the ten words (alternating add and
+// xor, two full-rate instructions per word) and two multiply-xorshift rounds at the end -- 32-bit multiplies are
+// quarter-rate, MurmurHash3's thirty of them made the build VALU-bound at 65 us per workgroup and 50k rows.  Nothing
+// but speed depends on the hash's quality: a part that fills up leaves rows without an entry, their queries to the search.
+__device__ __forceinline__ unsigned row_hash(const Row10& r) {
+  unsigned x = __float_as_uint(r.v[0]);
 #pragma unroll
-  for (int k = 0; k < 10; ++k) {
-    unsigned w = __float_as_uint(r.v[k]) * 0xcc9e2d51u;
-    w = rotl32(w, 15) * 0x1b873593u;
-    h = rotl32(h ^ w, 13) * 5u + 0xe6546b64u;
+  for (int k = 1; k < 10; ++k) {
+    const unsigned w = __float_as_uint(r.v[k]);
+    x = (k & 1) ? rotl32(x, 7) + w : rotl32(x, 11) ^ w;
   }
-  h ^= 40u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-  return h;
+  x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
+  return x;
+}
+__device__ __forceinline__ unsigned hj_part(unsigned h, int log2p) { return log2p ? h >> (32 - log2p) : 0u; }
+// home slot (even: the lookup reads it and its neighbour as one 8-byte word) and tag of a hash
+template <int LOG2S> __device__ __forceinline__ unsigned hj_home(unsigned h) { return h & ((1u << LOG2S) - 2u); }
+template <int LOG2S> __device__ __forceinline__ unsigned hj_tag(unsigned h, int ib) { return (h >> LOG2S) & ((1u << (31 - ib)) - 1u); }
+
+// Streaming 40-byte rows: a lane that loads "its" row issues three requests (16 + 16 + 8 bytes) which the texture path
+// takes one lane at a time (~1 lane-request per clock and CU: 150 k requests = 62 us for one workgroup's pass over 50k rows,
+// measured).  So a wave loads 64 consecutive rows as ONE contiguous 2560-byte run -- five 8-byte loads per lane, lane l
+// taking bytes 512 k + 8 l -- and transposes through a 2560-byte LDS strip of its own: row r of the run is float2 elements
+// 5 r .. 5 r + 4 (a 40-byte stride over 8-byte reads: conflict-free per half-wave).
+// A row fetched inside the build's insertion loop (a tag that agrees: rare).  Written as one block with its own wait, so
+// that the compiler's wait-count bookkeeping never sees a load of unknown standing inside the streaming loop -- with a plain
+// load there it waits for vmcnt(0), i.e. for all the runs requested ahead, at the top of every pass.
+__device__ __forceinline__ Row10 load_row_now(const float* p) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  f4v a, b; f2v c;
+  asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\t"
+               "global_load_dwordx2 %2, %3, off offset:32\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p) : "memory");
+  Row10 r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  r.v[8] = c.x; r.v[9] = c.y;
+  return r;
+}
+struct RowRun { float2 v[5]; };
+__device__ __forceinline__ RowRun run_load(const float* set, int n_rows, int chunk) {       // rows 64 chunk .. 64 chunk + 63 of the set (n_rows > 0)
+  RowRun r;
+  const int lane = threadIdx.x & 63;
+  const float2* base = reinterpret_cast<const float2*>(set);
+  const long long limit = 5ll * n_rows;                        // float2 elements of the set
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    // UNCONDITIONAL loads (an element beyond the set reads element 0 instead; the caller ignores rows >= n_rows): with
+    // predicated loads the compiler cannot count what is in flight and waits for everything at every use
+    const long long e = (long long)chunk * HJ_STRIP + 64 * k + lane;
+    r.v[k] = base[e < limit ? e : 0];
+  }
+  return r;
+}
+__device__ __forceinline__ Row10 run_row(const RowRun& r, float2* strip) {                   // this lane's row of the run
+  // One wave, one strip: the LDS executes a wave's instructions in order, so the reads below see the writes above them and
+  // the next run's writes cannot overtake these reads; the compiler keeps the order because the addresses may alias.  (No
+  // fence: a release fence here waits for vmcnt(0), i.e. for the runs that were requested ahead -- 96 instead of 68 us.)
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < 5; ++k) strip[64 * k + lane] = r.v[k];
+  __builtin_amdgcn_wave_barrier();
+  Row10 o;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { const float2 t = strip[5 * lane + k]; o.v[2 * k] = t.x; o.v[2 * k + 1] = t.y; }
+  return o;
 }
 
-template <int LOG2S, int THREADS>
-__global__ __launch_bounds__(THREADS) void hash_build_kernel(HashArgs a) {
-  constexpr unsigned S = 1u << LOG2S;
-  int f, b;
-  if (!xcd_frame_block(a.slices, a.n_frames, f, b)) return;
+// step 1: the hash of every tree row, in row order (a plain map over the rows: the whole chip streams them once)
+__global__ __launch_bounds__(256) void hash_rows_kernel(HashArgs a) {
+  int f, blk;
+  if (!xcd_frame_block(a.hblocks, a.n_frames, f, blk)) return;
   const float* tree; const float* qry; int nt, nq;
   cell_sets(a, f, tree, qry, nt, nq);
-  const int tid = threadIdx.x;
-  if (b == 0 && tid == 0) a.unres[f] = 0;                 // (the lookup kernel is a later launch)
-  const int lo = b * a.slice;
-  if (lo >= nt) return;                                   // ragged frames: no such slice (the lookup knows from nt)
-  const int hi = lo + a.slice < nt ? lo + a.slice : nt;
+  if (blk == 0 && threadIdx.x == 0) a.unres[f] = 0;         // (the lookup kernel is a later launch)
+  if (blk * 256 >= nt) return;
+  __shared__ float2 s_strip[4][HJ_STRIP];
+  const int i = blk * 256 + threadIdx.x;
+  const Row10 r = run_row(run_load(tree, nt, i >> 6), s_strip[threadIdx.x >> 6]);
+  if (i < nt) a.hashes[f * a.hashes_stride + i] = row_hash(r);
+}
+
+// step 2: one workgroup per (frame, part) reads ALL the frame's hashes (200 KB at 50k points, from the XCD's L2), queues
+// the entries of its own part per wave -- (word, home slot), compacted by ballot, so that insertion runs with every lane
+// busy: its compare-and-swap chain is a serial LDS round trip per step, which a wave with a quarter of its lanes active pays
+// four times as often -- and inserts them 64 at a time.  (A first version had every part's workgroup stream all ROWS and hash
+// them itself: 61 us per workgroup and 50k points, the chip 4 x 200 workgroups of it -- bound by those quarter-full chains.)
+template <int LOG2S>
+__global__ __launch_bounds__(HJ_THREADS) void hash_table_kernel(HashArgs a) {
+  constexpr unsigned S = 1u << LOG2S;
+  int f, part;
+  if (!xcd_frame_block(1 << a.log2p, a.n_frames, f, part)) return;
+  const float* tree; const float* qry; int nt, nq;
+  cell_sets(a, f, tree, qry, nt, nq);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   __shared__ __attribute__((aligned(16))) unsigned s_tab[S];
-  for (unsigned k = tid; k < S / 4; k += THREADS) reinterpret_cast<uint4*>(s_tab)[k] = make_uint4(HJ_EMPTY, HJ_EMPTY, HJ_EMPTY, HJ_EMPTY);
+  __shared__ uint2 s_q[HJ_NW][128];
+  for (unsigned k = tid; k < S / 4; k += HJ_THREADS) reinterpret_cast<uint4*>(s_tab)[k] = make_uint4(HJ_EMPTY, HJ_EMPTY, HJ_EMPTY, HJ_EMPTY);
   __syncthreads();
-  for (int i = lo + tid; i < hi; i += THREADS) {
-    const Row10 r = load_row(tree + 10 * (size_t)i);
-    if (!row_safe(r)) continue;                           // can never be at distance 0 from a safe query
-    const unsigned h = row_hash(r);
-    const unsigned word = (((h >> LOG2S) & HJ_TMASK) << HJ_IB) | (unsigned)(i - lo);
-    unsigned s = h & (S - 1u);
-    for (unsigned n = 0; n < S; ++n) {                     // (slice < S: an empty slot always exists)
+  const unsigned imask = (1u << a.ib) - 1u;
+  const unsigned* hashes = a.hashes + f * a.hashes_stride;
+  uint2* q = s_q[wave];
+  int qhead = 0, qcount = 0;                                // wave-uniform
+  auto insert = [&](bool have, uint2 e) {                   // e = (word, home slot)
+    if (!have) return;
+    const unsigned word = e.x;
+    unsigned s = e.y;
+    for (unsigned n = 0; n < S; ++n) {                      // (a full part: the row gets no entry, its queries stay open)
       const unsigned old = atomicCAS(&s_tab[s], HJ_EMPTY, word);
       if (old == HJ_EMPTY) break;
-      if ((old >> HJ_IB) == (word >> HJ_IB)) {
+      if ((old >> a.ib) == (word >> a.ib)) {
         // same tag: the same row?  (the entry's index may be lowered meanwhile -- by a copy of the same row)
-        const Row10 o = load_row(tree + 10 * (size_t)(lo + (int)(old & HJ_IMASK)));
+        const Row10 o = load_row_now(tree + 10 * (size_t)(old & imask)), r = load_row_now(tree + 10 * (size_t)(word & imask));
         if (rows_equal(o, r)) { atomicMin(&s_tab[s], word); break; }
       }
       s = (s + 1u) & (S - 1u);
     }
+  };
+  const int n_groups = (nt + 255) >> 8;                     // 256 hashes per wave and pass: one 16-byte load per lane
+  auto group_load = [&](int g) {
+    const long long at = 256ll * g + 4 * lane;
+    uint4 h = make_uint4(0u, 0u, 0u, 0u);
+    if (at + 3 < nt) h = *reinterpret_cast<const uint4*>(hashes + at);
+    else if (at < nt) { h.x = hashes[at]; if (at + 1 < nt) h.y = hashes[at + 1]; if (at + 2 < nt) h.z = hashes[at + 2]; }
+    return h;
+  };
+  uint4 h4 = make_uint4(0u, 0u, 0u, 0u);
+  if (wave < n_groups) h4 = group_load(wave);
+  for (int g = wave; g < n_groups; g += HJ_NW) {
+    const uint4 cur = h4;
+    if (g + HJ_NW < n_groups) h4 = group_load(g + HJ_NW);
+    const unsigned hv[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = 256 * g + 4 * lane + u;
+      const unsigned h = hv[u];
+      const bool own = i < nt && hj_part(h, a.log2p) == (unsigned)part;
+      const unsigned long long m = __ballot(own);
+      if (own) {
+        const int pos = qcount + __popcll(m & ((1ull << lane) - 1ull));
+        q[(qhead + pos) & 127] = make_uint2((hj_tag<LOG2S>(h, a.ib) << a.ib) | (unsigned)i, hj_home<LOG2S>(h));
+      }
+      qcount += __popcll(m);
+      if (qcount >= 64) {                                   // (wave-uniform)
+        __builtin_amdgcn_wave_barrier();
+        insert(true, q[(qhead + lane) & 127]);
+        qhead = (qhead + 64) & 127; qcount -= 64;
+      }
+    }
   }
+  __builtin_amdgcn_wave_barrier();
+  insert(lane < qcount, q[(qhead + lane) & 127]);
   __syncthreads();
-  uint4* dst = reinterpret_cast<uint4*>(a.tables + f * a.tables_stride + ((size_t)b << LOG2S));
-  for (unsigned k = tid; k < S / 4; k += THREADS) dst[k] = reinterpret_cast<const uint4*>(s_tab)[k];
+  uint4* dst = reinterpret_cast<uint4*>(a.tables + f * a.tables_stride + ((size_t)part << LOG2S));
+  for (unsigned k = tid; k < S / 4; k += HJ_THREADS) dst[k] = reinterpret_cast<const uint4*>(s_tab)[k];
 }
 
+// step 3: the lookup, in query order.  A query's chain is three dependent round trips -- its row, its table word, the
+// candidate's row.  A lane can carry HJ_Q queries whose round trips fly together; measured at 200 x 50k frames: 277 us
+// with one query per lane, 297 with two, 360 with four (fewer waves) -- the kernel is not short of requests in flight, it
+// runs at the rate the XCD's L2 answers scattered line requests (2.8 per query: 0.3 for its row, 1 table word, 1.5 for the
+// candidate's 40-byte row; 1.0 GB of HBM traffic per call, 3.6 TB/s).  So one query per lane.
+// Fast path: the home slot and its neighbour (one 8-byte word) either end the chain (an empty slot) or name a candidate
+// whose row settles it; everything else -- a longer chain, a tag that agrees on a different row -- walks the chain in full.
+#ifndef VO_HJ_Q
+#define VO_HJ_Q 1
+#endif
+constexpr int HJ_Q = VO_HJ_Q;
 template <int LOG2S>
 __global__ __launch_bounds__(256) void hash_probe_kernel(HashArgs a) {
   constexpr unsigned S = 1u << LOG2S, MASK = S - 1u;
@@ -1590,78 +1720,116 @@ __global__ __launch_bounds__(256) void hash_probe_kernel(HashArgs a) {
   if (!xcd_frame_block(a.qblocks, a.n_frames, f, blk)) return;
   const float* tree; const float* qry; int nt, nq;
   cell_sets(a, f, tree, qry, nt, nq);
-  if (blk * 256 >= nq) return;                            // (uniform)
+  if (blk * (256 * HJ_Q) >= nq) return;                   // (uniform)
   __shared__ int s_open;
-  const int tid = threadIdx.x;
+  __shared__ float2 s_strip[4][HJ_STRIP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid == 0) s_open = 0;
-  const int j = blk * 256 + tid;
-  const bool live = j < nq;
+  const unsigned imask = (1u << a.ib) - 1u;
   const unsigned* tab = a.tables + f * a.tables_stride;
-  const int live_slices = (nt + a.slice - 1) / a.slice;
-  unsigned found = 0xffffffffu;
-  Row10 q;
-  if (live) q = load_row(qry + 10 * (size_t)j);
-  if (live && a.r2 > 0.f && row_safe(q)) {
-    const unsigned h = row_hash(q), tag = (h >> LOG2S) & HJ_TMASK, home = h & MASK, next = (home + 1u) & MASK;
-    for (int s0 = 0; s0 < live_slices; s0 += 4) {
-      unsigned w0[4], w1[4];
+  // query u of this lane: chunk (4 blk + wave) HJ_Q + u, i.e. the wave's HJ_Q consecutive runs of 64 queries
+  int j[HJ_Q];
+  RowRun run[HJ_Q];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {                       // eight independent loads
-        const bool have = s0 + k < live_slices;
-        const unsigned* t = tab + ((size_t)(have ? s0 + k : s0) << LOG2S);
-        w0[k] = t[home]; w1[k] = t[next];
-        if (!have) w0[k] = HJ_EMPTY;
-      }
+  for (int u = 0; u < HJ_Q; ++u) {
+    const int chunk = (4 * blk + wave) * HJ_Q + u;
+    j[u] = 64 * chunk + lane;
+    run[u] = run_load(qry, nq, chunk);
+  }
+  Row10 q[HJ_Q];
+  unsigned h[HJ_Q], found[HJ_Q];
+  bool look[HJ_Q];
+  uint2 w01[HJ_Q];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (w0[k] == HJ_EMPTY) continue;
-        const unsigned* t = tab + ((size_t)(s0 + k) << LOG2S);
-        const int base = (s0 + k) * a.slice;
-        unsigned w = w0[k], s = home;
-        for (unsigned n = 0; n < S; ++n) {                 // the chain from the home slot to the first empty one
-          if (w == HJ_EMPTY) break;
-          if ((w >> HJ_IB) == tag) {
-            const int cand = base + (int)(w & HJ_IMASK);
-            if (rows_equal(load_row(tree + 10 * (size_t)cand), q)) { found = (unsigned)cand < found ? (unsigned)cand : found; break; }   // one entry per distinct row
-          }
-          s = (s + 1u) & MASK;
-          w = n == 0 ? w1[k] : t[s];
+  for (int u = 0; u < HJ_Q; ++u) {
+    q[u] = run_row(run[u], s_strip[wave]);
+    found[u] = 0xffffffffu;
+    look[u] = j[u] < nq && nt > 0 && a.r2 > 0.f && row_safe(q[u]);
+    h[u] = row_hash(q[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < HJ_Q; ++u) {                         // the table words: unconditional loads (a lane that does not look reads slot 0)
+    const unsigned* t = tab + ((size_t)hj_part(h[u], a.log2p) << LOG2S);
+    w01[u] = *reinterpret_cast<const uint2*>(t + (look[u] ? hj_home<LOG2S>(h[u]) : 0u));
+  }
+  unsigned cand[HJ_Q];
+  bool slow[HJ_Q];
+#pragma unroll
+  for (int u = 0; u < HJ_Q; ++u) {
+    const unsigned tag = hj_tag<LOG2S>(h[u], a.ib);
+    const bool e0 = w01[u].x == HJ_EMPTY, e1 = w01[u].y == HJ_EMPTY;
+    const bool m0 = !e0 && (w01[u].x >> a.ib) == tag, m1 = !e0 && !e1 && (w01[u].y >> a.ib) == tag;
+    cand[u] = m0 ? (w01[u].x & imask) : (m1 ? (w01[u].y & imask) : 0xffffffffu);
+    // settled without a candidate: the chain ends inside the word.  Not settled: no candidate and no end -> walk.
+    slow[u] = look[u] && cand[u] == 0xffffffffu && !(e0 || e1);
+    if (!look[u]) cand[u] = 0xffffffffu;
+  }
+  Row10 t[HJ_Q];
+#pragma unroll
+  for (int u = 0; u < HJ_Q; ++u) t[u] = load_row(tree + 10 * (size_t)(cand[u] != 0xffffffffu ? cand[u] : 0u));   // unconditional
+#pragma unroll
+  for (int u = 0; u < HJ_Q; ++u) {
+    if (cand[u] != 0xffffffffu) {
+      if (rows_equal(t[u], q[u])) found[u] = cand[u];      // one entry per distinct row: the chain holds no other copy
+      else slow[u] = true;                                 // the tag of another row: walk
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < HJ_Q; ++u) {
+    if (slow[u]) {                                         // rare: the chain from the home slot to the first empty one
+      const unsigned tag = hj_tag<LOG2S>(h[u], a.ib);
+      const unsigned* tp = tab + ((size_t)hj_part(h[u], a.log2p) << LOG2S);
+      unsigned s = hj_home<LOG2S>(h[u]);
+      for (unsigned n = 0; n < S; ++n) {
+        const unsigned w = tp[s];
+        if (w == HJ_EMPTY) break;
+        if ((w >> a.ib) == tag) {
+          const unsigned c = w & imask;
+          if (rows_equal(load_row(tree + 10 * (size_t)c), q[u])) { found[u] = c; break; }
         }
+        s = (s + 1u) & MASK;
       }
     }
   }
   __syncthreads();
-  const bool open = live && found == 0xffffffffu;
-  const unsigned long long m = __ballot(open);
-  if ((tid & 63) == 0 && m != 0ull) atomicAdd(&s_open, __popcll(m));
-  if (live) {
-    unsigned long long* best = a.best + f * a.best_stride;
-    best[j] = open ? (((unsigned long long)__float_as_uint(a.r2) << 32) | 0xffffffffull) : (unsigned long long)found;
+  int n_open = 0;
+  unsigned long long* best = a.best + f * a.best_stride;
+#pragma unroll
+  for (int u = 0; u < HJ_Q; ++u) {
+    const bool live = j[u] < nq;
+    const bool open = live && found[u] == 0xffffffffu;
+    n_open += __popcll(__ballot(open));
+    if (live) best[j[u]] = open ? (((unsigned long long)__float_as_uint(a.r2) << 32) | 0xffffffffull) : (unsigned long long)found[u];
   }
+  if (lane == 0 && n_open > 0) atomicAdd(&s_open, n_open);
   __syncthreads();
   if (tid == 0 && s_open > 0) atomicAdd(&a.unres[f], s_open);
 }
 
-// table size per slice (2^log2s words), workgroup size and points per slice (<= 0.39 * 2^log2s: load factor of the tables)
-struct HashPlan { int log2s, threads, slice, slices; };
-static bool hash_plan(int nt, int n_frames, HashPlan& p) {
+// 2^log2p parts of 2^log2s words for a tree of nt points: at most ~0.39 * 2^log2s points per part on average (load factor)
+struct HashPlan { int log2s, log2p, ib; };
+static bool hash_plan(int nt, HashPlan& p) {
   if (nt <= 0) return false;
-  static const int slice_of[4] = {1600, 3200, 6400, 12800};            // log2s 12 .. 15
+  static const int fill[4] = {1600, 3200, 6400, 12800};               // log2s 12 .. 15
   int l = 0;
-  if (n_frames >= 8) {                 // many frames fill the GPU by themselves: few, large tables (few lookups per query)
-    while (l < 3 && (nt + slice_of[l] - 1) / slice_of[l] > 4) ++l;
-  }                                    // few frames: many small slices, so that the build itself is spread over the CUs
-  p.log2s = 12 + l; p.threads = l == 0 ? 256 : (l == 1 ? 512 : 1024); p.slice = slice_of[l];
-  p.slices = (nt + p.slice - 1) / p.slice;
-  return p.slices <= (n_frames >= 8 ? 8 : 64);
+  while (l < 3 && nt > fill[l]) ++l;
+  p.log2s = 12 + l;
+  p.log2p = 0;
+  while (p.log2p < 4 && (long long)nt > ((long long)fill[l] << p.log2p)) ++p.log2p;
+  if ((long long)nt > ((long long)fill[l] << p.log2p)) return false;   // more than 204 800 points: the general search alone
+  p.ib = 1;
+  while ((1 << p.ib) < nt) ++p.ib;
+  return true;
 }
-// workspace of the pass: the open-query counters, then the tables
+static size_t hash_table_bytes(const HashPlan& p) { return align256(sizeof(unsigned) * ((size_t)1 << (p.log2s + p.log2p))); }
+static size_t hash_rows_bytes(int nt) { return align256(sizeof(unsigned) * (size_t)nt); }
+// workspace of the pass: the open-query counters, then the tables, then the row hashes
 static size_t hash_ws_bytes(int nt, int n_frames) {
   HashPlan p;
-  if (!hash_plan(nt, n_frames, p)) return 0;
-  return align256(sizeof(int) * (size_t)n_frames) + align256(sizeof(unsigned) * ((size_t)p.slices << p.log2s)) * (size_t)n_frames;
+  if (!hash_plan(nt, p)) return 0;
+  return align256(sizeof(int) * (size_t)n_frames) + (hash_table_bytes(p) + hash_rows_bytes(nt)) * (size_t)n_frames;
 }
-bool match_hash_supported(int nt, int n_frames) { HashPlan p; return hash_plan(nt, n_frames, p); }
+bool match_hash_supported(int nt, int n_frames) { (void)n_frames; HashPlan p; return hash_plan(nt, p); }
 size_t match_hash_workspace_bytes(int nt, int n_frames) { return hash_ws_bytes(nt, n_frames); }
 
 // (tree, qry, nt, nq): the two sets in their roles, or (set 1, set 2, capacities) with the per-frame sizes d_n1 / d_n2
@@ -1670,27 +1838,31 @@ static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, c
                                     size_t best_stride, const int* d_n1, const int* d_n2, int** d_unres_out) {
   HashPlan p;
   const int nt_plan = d_n1 ? (nt > nq ? nt : nq) : nt;
-  if (!hash_plan(nt_plan, n_frames, p)) return hipErrorInvalidValue;
+  if (!hash_plan(nt_plan, p)) return hipErrorInvalidValue;
   HashArgs a;
   a.tree = tree; a.qry = qry; a.nt = nt; a.nq = nq;
   a.tree_stride = tree_stride; a.qry_stride = qry_stride; a.best_stride = best_stride;
   a.d_n1 = d_n1; a.d_n2 = d_n2;
   a.unres = static_cast<int*>(ws);
   a.tables = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + align256(sizeof(int) * (size_t)n_frames));
-  a.tables_stride = align256(sizeof(unsigned) * ((size_t)p.slices << p.log2s)) / sizeof(unsigned);
+  a.tables_stride = hash_table_bytes(p) / sizeof(unsigned);
+  a.hashes = a.tables + a.tables_stride * (size_t)n_frames;
+  a.hashes_stride = hash_rows_bytes(nt_plan) / sizeof(unsigned);
+  a.hblocks = (nt_plan + 255) / 256;
   a.best = d_best; a.r2 = r2;
-  a.n_frames = n_frames; a.slices = p.slices; a.slice = p.slice;
+  a.n_frames = n_frames; a.log2p = p.log2p; a.ib = p.ib;
   const int q_cap = d_n1 ? (nt < nq ? nt : nq) : nq;       // ragged: either set may be the queries, never more than the smaller capacity
-  a.qblocks = (q_cap + 255) / 256;
-  const dim3 gb(xcd_grid(p.slices, n_frames)), gp(xcd_grid(a.qblocks, n_frames));
+  a.qblocks = (q_cap + 256 * HJ_Q - 1) / (256 * HJ_Q);
+  const dim3 gb(xcd_grid(1 << p.log2p, n_frames)), gp(xcd_grid(a.qblocks, n_frames)), tb(HJ_THREADS);
+  hipLaunchKernelGGL(hash_rows_kernel, dim3(xcd_grid(a.hblocks, n_frames)), dim3(256), 0, st, a);
   switch (p.log2s) {
-    case 12: hipLaunchKernelGGL((hash_build_kernel<12, 256>), gb, dim3(256), 0, st, a);
+    case 12: hipLaunchKernelGGL(hash_table_kernel<12>, gb, tb, 0, st, a);
              hipLaunchKernelGGL(hash_probe_kernel<12>, gp, dim3(256), 0, st, a); break;
-    case 13: hipLaunchKernelGGL((hash_build_kernel<13, 512>), gb, dim3(512), 0, st, a);
+    case 13: hipLaunchKernelGGL(hash_table_kernel<13>, gb, tb, 0, st, a);
              hipLaunchKernelGGL(hash_probe_kernel<13>, gp, dim3(256), 0, st, a); break;
-    case 14: hipLaunchKernelGGL((hash_build_kernel<14, 1024>), gb, dim3(1024), 0, st, a);
+    case 14: hipLaunchKernelGGL(hash_table_kernel<14>, gb, tb, 0, st, a);
              hipLaunchKernelGGL(hash_probe_kernel<14>, gp, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((hash_build_kernel<15, 1024>), gb, dim3(1024), 0, st, a);
+    default: hipLaunchKernelGGL(hash_table_kernel<15>, gb, tb, 0, st, a);
              hipLaunchKernelGGL(hash_probe_kernel<15>, gp, dim3(256), 0, st, a); break;
   }
   *d_unres_out = a.unres;
