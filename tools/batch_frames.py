@@ -19,7 +19,7 @@ for F in [int(a) for a in sys.argv[1:]] or [8, 32, 64, 200]:
     bp = vo.BatchPipeline(ctx, fps, n_iters=50)
     bp.run(); ctx.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 3
+    reps = int(os.environ.get("REPS", "10"))
     e0.record(stream)
     for _ in range(reps): bp.run()
     e1.record(stream); ctx.synchronize()

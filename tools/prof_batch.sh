@@ -17,7 +17,7 @@ f = glob.glob("$OUT/stats/*/*kernel_stats.csv")[0]
 rows = list(csv.DictReader(open(f)))
 tot = 0.0
 for r in rows[:24]:
-    per_batch = float(r["TotalDurationNs"]) / 4 / 1e6      # 4 runs of the batch (1 warm-up + 3 timed)
+    per_batch = float(r["TotalDurationNs"]) / 11 / 1e6      # 11 runs of the batch (1 warm-up + 10 timed)
     tot += per_batch
     print("%-52s calls %5s avg %9.1f us  per batch %7.3f ms" % (r["Name"].replace("void ","").replace("vo::","")[:52], r["Calls"], float(r["AverageNs"])/1e3, per_batch))
 print("sum per batch %.3f ms" % tot)

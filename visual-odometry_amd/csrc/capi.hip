@@ -857,6 +857,14 @@ static int picp_solve_batch(vo_ctx* c, int n_problems, int rows, int cols, int z
                             size_t world_stride, const float* d_meas, size_t meas_stride,
                             const int32_t* d_pairs, size_t pairs_stride, const int* d_n_pairs,
                             const float* d_T0, int n_iters, float* d_T_out, float* d_stats_out, const float* d_X_world);
+// the same in two steps: everything up to (not including) the launches -- workspaces sized, BatchArgs filled, the dropped-
+// correspondence counters zeroed on the stream -- so that a caller can hand the arguments to the join as its gather sink
+static int picp_batch_prepare(vo_ctx* c, int n_problems, int rows, int cols, int z_near, int z_far,
+                              const float K[9], float thr, int keep_outliers, const float* d_world,
+                              size_t world_stride, const float* d_meas, size_t meas_stride,
+                              const int32_t* d_pairs, size_t pairs_stride, const int* d_n_pairs,
+                              const float* d_T0, int n_iters, float* d_T_out, float* d_stats_out, const float* d_X_world,
+                              BatchArgs& a);
 
 int vo_picp_solve_batch_dev(vo_ctx* c, int n_problems, int rows, int cols, int z_near, int z_far,
                             const float K[9], float thr, int keep_outliers, const float* d_world,
@@ -873,6 +881,21 @@ static int picp_solve_batch(vo_ctx* c, int n_problems, int rows, int cols, int z
                             size_t world_stride, const float* d_meas, size_t meas_stride,
                             const int32_t* d_pairs, size_t pairs_stride, const int* d_n_pairs,
                             const float* d_T0, int n_iters, float* d_T_out, float* d_stats_out, const float* d_X_world) {
+  BatchArgs a;
+  if (int r = picp_batch_prepare(c, n_problems, rows, cols, z_near, z_far, K, thr, keep_outliers, d_world, world_stride, d_meas,
+                                 meas_stride, d_pairs, pairs_stride, d_n_pairs, d_T0, n_iters, d_T_out, d_stats_out, d_X_world, a))
+    return r;
+  if (n_problems == 0) return VO_OK;
+  VO_HIP_CHECK(launch_picp_batch(c->stream, a));
+  return VO_OK;
+}
+
+static int picp_batch_prepare(vo_ctx* c, int n_problems, int rows, int cols, int z_near, int z_far,
+                              const float K[9], float thr, int keep_outliers, const float* d_world,
+                              size_t world_stride, const float* d_meas, size_t meas_stride,
+                              const int32_t* d_pairs, size_t pairs_stride, const int* d_n_pairs,
+                              const float* d_T0, int n_iters, float* d_T_out, float* d_stats_out, const float* d_X_world,
+                              BatchArgs& a) {
   VO_REQUIRE(c && K, "null argument");
   VO_REQUIRE(n_problems >= 0 && n_iters >= 0, "negative count");
   VO_REQUIRE(n_problems <= 65535, "more than 65535 problems per call (the problem is a grid dimension)");
@@ -881,7 +904,7 @@ static int picp_solve_batch(vo_ctx* c, int n_problems, int rows, int cols, int z
   VO_REQUIRE(world_stride > 0 && meas_stride > 0 && pairs_stride > 0, "zero stride");
   VO_REQUIRE(world_stride < 0x7fffffff && meas_stride < 0x7fffffff && pairs_stride < 0x7fffffff, "stride too large");
   if (int r = set_device(c)) return r;
-  BatchArgs a;
+  a.prepacked = 0;
   a.cam = make_cam(rows, cols, z_near, z_far, K);
   a.thr = thr; a.damping = 1.f; a.keep_outliers = keep_outliers ? 1 : 0;
   a.n_iters = n_iters; a.n_problems = n_problems;
@@ -931,7 +954,6 @@ static int picp_solve_batch(vo_ctx* c, int n_problems, int rows, int cols, int z
     a.partials = c->batch_partials.as<float>();
     a.params = d_params;
   }
-  VO_HIP_CHECK(launch_picp_batch(c->stream, a));
   return VO_OK;
 }
 
@@ -950,10 +972,16 @@ static int match_workspace(vo_ctx* c, int variant, int nt, int nq, int n_frames,
 // search (25 instead of ~1400 candidates per query: 4.0 vs 4.4 ms per 200 frames, its random accesses hidden
 // by occupancy).  In front of either sorted search auto mode runs the exact-duplicate pass (variants 4 / 5, match.hip
 // "hash-first": appearances are copied from frame to frame, so almost every query has a bitwise copy in the tree, which
-// is its nearest neighbour at distance 0; the search then only sees the queries without one).
-// VO_MATCH_AUTO=2|3 forces one of the sorted variants in auto mode, VO_MATCH_HASH=0 leaves the exact-duplicate pass out.
+// is its nearest neighbour at distance 0; the search then only sees the queries without one) -- from 8 frames per call on.
+// For one frame the pass (three launches, ~45 us at 50k) pays only when NO query is left over: 55 against 78 us; a tracking
+// sequence brings new landmarks with every frame, and the sorted search it then still needs costs what it costs without
+// the pass (the tree must be sorted for a single open query): 123 against 75 us per frame of the synthetic 200 x 50k
+// sequence.  Modes 4 / 5 ask for the pass at any size.
+// VO_MATCH_AUTO=2|3 forces one of the sorted variants in auto mode, VO_MATCH_HASH=0 leaves the exact-duplicate pass out,
+// VO_MATCH_HASH=1 puts it in front of every sorted search.
 static int with_hash(int v, int nt, int n_frames) {
-  static const bool on = [] { const char* e = getenv("VO_MATCH_HASH"); return !(e && e[0] == '0'); }();
+  static const int env = [] { const char* e = getenv("VO_MATCH_HASH"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  const bool on = env < 0 ? n_frames >= 8 : env == 1;
   return (on && (v == 2 || v == 3) && match_hash_supported(nt, n_frames)) ? v + 2 : v;
 }
 static int match_variant(const vo_ctx* c, int nt, int nq, int n_frames) {
@@ -1102,11 +1130,6 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
                                   10 * (size_t)b->n_cur, b->radius, b->matches, (size_t)q, n_match,
                                   c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, F, variant,
                                   sz ? sz->n_ref : nullptr, sz ? sz->n_cur : nullptr));
-  // extract_correspondences_world                                               vo_complete.cpp:157
-  VO_HIP_CHECK(launch_join_batch(c->stream, b->matches, q, n_match, b->model_pairs, b->n_model_pairs,
-                                 sz ? sz->n_model_pairs : nullptr, b->n_ref,
-                                 b->joined, n_join, c->table.as<unsigned long long>(), c->scratch.as<int>(), F, (size_t)q,
-                                 (size_t)b->n_model_pairs, (size_t)q));
   // X_curr * triangulated_pc                                                    vo_complete.cpp:159
   // The moved cloud as an output is optional: without it the solver's gather applies X_prev to the points it fetches (the
   // same arithmetic, PointCloud.h:80) and the pass that writes n_model points per frame only to re-read the joined ones
@@ -1119,11 +1142,25 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
   } else {
     X_world = b->X_prev;                              // (null: identity -- the points are used as they are)
   }
-  // solver.init(identity) + n rounds                                            vo_complete.cpp:161-164
-  if (int r = picp_solve_batch(c, F, b->rows, b->cols, b->z_near, b->z_far, b->K, b->kernel_threshold,
-                               b->keep_outliers, world, (size_t)b->n_model, b->cur_pts, (size_t)b->n_cur,
-                               b->joined, (size_t)q, n_join, nullptr, b->n_iters, b->poses, b->stats, X_world))
+  // solver.init(identity) + n rounds: arguments first ...                       vo_complete.cpp:161-164
+  BatchArgs pa;
+  if (int r = picp_batch_prepare(c, F, b->rows, b->cols, b->z_near, b->z_far, b->K, b->kernel_threshold,
+                                 b->keep_outliers, world, (size_t)b->n_model, b->cur_pts, (size_t)b->n_cur,
+                                 b->joined, (size_t)q, n_join, nullptr, b->n_iters, b->poses, b->stats, X_world, pa))
     return r;
+  // extract_correspondences_world                                               vo_complete.cpp:157
+  // ... because the join's writing pass gathers every pair it emits straight into the solver's packed arrays (the one-
+  // workgroup-per-problem and reference-order forms; the launch-per-round form of a few frames keeps its own gather pass,
+  // which also sets the problems' states up): one launch and one read of the joined pairs less (0.145 + 0.038 -> ~0.15 ms
+  // per 200 x 50k frames)
+  static const bool fuse_on = [] { const char* e = getenv("VO_JOIN_GATHER"); return !(e && e[0] == '0'); }();
+  const bool fuse = fuse_on && pa.states == nullptr && join_fuses_gather(q, b->n_model_pairs, b->n_ref);
+  if (fuse) pa.prepacked = 1;
+  VO_HIP_CHECK(launch_join_batch(c->stream, b->matches, q, n_match, b->model_pairs, b->n_model_pairs,
+                                 sz ? sz->n_model_pairs : nullptr, b->n_ref,
+                                 b->joined, n_join, c->table.as<unsigned long long>(), c->scratch.as<int>(), F, (size_t)q,
+                                 (size_t)b->n_model_pairs, (size_t)q, fuse ? &pa : nullptr));
+  VO_HIP_CHECK(launch_picp_batch(c->stream, pa));
   // triangulate_points with the new pose                                        vo_complete.cpp:172-173
   VO_HIP_CHECK(launch_triangulate_batch(c->stream, b->K, nullptr, b->poses, b->matches, q, n_match, b->ref_pts, b->n_ref,
                                         b->cur_pts, b->n_cur, b->tri_app ? b->cur_app : nullptr, b->tri_xyz, b->tri_pairs,

@@ -511,6 +511,8 @@ struct JoinArgs {
   int* tmp_w;                                                   // [n_frames][n_max]: what the counting pass looked up ...
   unsigned long long* tmp_ok;                                   // [n_frames][(n_max + 63) / 64]: ... and whether there was a partner
 };
+// the writing pass with the solver's gather folded in: BatchArgs by value beside the join's own arguments
+struct JoinSink { BatchArgs b; };
 
 __device__ __forceinline__ JoinArgs join_frame(JoinArgs a, int frame) {
   const size_t f = (size_t)frame;
@@ -556,7 +558,8 @@ __global__ __launch_bounds__(CB) void join_count_kernel(JoinArgs a0) {
   if (threadIdx.x == 0) a.counts[fb.b] = total;
 }
 
-__global__ __launch_bounds__(CB) void join_scatter_kernel(JoinArgs a0) {
+template <bool SINK>
+__device__ __forceinline__ void join_scatter_body(const JoinArgs& a0, const BatchArgs* sink) {
   const FrameBlock fb = frame_block(a0.nb, a0.n_frames);
   if (!fb.live) return;
   const JoinArgs a = join_frame(a0, fb.f);
@@ -568,14 +571,23 @@ __global__ __launch_bounds__(CB) void join_scatter_kernel(JoinArgs a0) {
     ok = (a.tmp_ok[i >> 6] >> (i & 63)) & 1ull;        // join_count_kernel's lookup
     if (ok) { w = a.tmp_w[i]; c = a.img[2 * (size_t)i + 1]; }
   }
+  Pose Xw;
+  if (SINK) Xw = batch_pack_pose(*sink, fb.f);
   int total;
   const int r = block_rank(ok, s_wave, total);
   if (ok) {
     const size_t dst = (size_t)a.counts[fb.b] + r;
     a.out[2 * dst] = c;        // vo_complete.cpp:59
     a.out[2 * dst + 1] = w;
+    // the solver's gather for this pair, here where it is in registers (picp_batch_pack_kernel would read it back);
+    // a pair beyond the solver's capacity is not packed, as there
+    if (SINK && dst < sink->cap) batch_pack_item(*sink, fb.f, Xw, dst, c, w);
   }
 }
+__global__ __launch_bounds__(CB) void join_scatter_kernel(JoinArgs a0) { join_scatter_body<false>(a0, nullptr); }
+__global__ __launch_bounds__(CB) void join_scatter_pack_kernel(JoinArgs a0, JoinSink s) { join_scatter_body<true>(a0, &s.b); }
+
+bool join_fuses_gather(int n_img, int n_world, int n_ref) { return !(n_img <= SMALL_N && n_ref <= SMALL_N && n_world <= 8 * SMALL_N) && n_img > 0; }
 
 __global__ __launch_bounds__(CB) void join_small_kernel(JoinArgs a0, int n_world_max, const int* d_n_world, int* d_n_out) {
   const int f = blockIdx.x;
@@ -620,7 +632,7 @@ __global__ __launch_bounds__(CB) void join_small_kernel(JoinArgs a0, int n_world
 hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, const int* d_n_img,
                              const int32_t* d_world, int n_world, const int* d_n_world, int n_ref, int32_t* d_out,
                              int* d_n_out, unsigned long long* d_table, int* d_scratch, int n_frames, size_t img_stride,
-                             size_t world_stride, size_t out_stride) {
+                             size_t world_stride, size_t out_stride, const BatchArgs* sink) {
   const bool batched = n_frames > 1;
   hipError_t e = hipSuccess;
   if (n_img <= SMALL_N && n_ref <= SMALL_N && n_world <= 8 * SMALL_N) {
@@ -652,7 +664,12 @@ hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, co
   if (nb > 0) hipLaunchKernelGGL(join_count_kernel, frame_grid(nb, n_frames), dim3(CB), 0, st, a);
   e = launch_scan(st, d_scratch, nb, d_n_out, nullptr, n_frames, a.counts_stride);
   if (e != hipSuccess) return e;
-  if (nb > 0) hipLaunchKernelGGL(join_scatter_kernel, frame_grid(nb, n_frames), dim3(CB), 0, st, a);
+  if (nb > 0 && sink) {
+    JoinSink js; js.b = *sink;
+    hipLaunchKernelGGL(join_scatter_pack_kernel, frame_grid(nb, n_frames), dim3(CB), 0, st, a, js);
+  } else if (nb > 0) {
+    hipLaunchKernelGGL(join_scatter_kernel, frame_grid(nb, n_frames), dim3(CB), 0, st, a);
+  }
   return hipGetLastError();
 }
 

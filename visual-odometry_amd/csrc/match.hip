@@ -1808,14 +1808,20 @@ __global__ __launch_bounds__(256) void hash_probe_kernel(HashArgs a) {
 
 // 2^log2p parts of 2^log2s words for a tree of nt points: at most ~0.39 * 2^log2s points per part on average (load factor)
 struct HashPlan { int log2s, log2p, ib; };
+#ifndef VO_HJ_MAXL
+#define VO_HJ_MAXL 2
+#endif
 static bool hash_plan(int nt, HashPlan& p) {
   if (nt <= 0) return false;
   static const int fill[4] = {1600, 3200, 6400, 12800};               // log2s 12 .. 15
+  // parts of at most 2^14 words: 64 KiB of table + 12 KiB of queues, so that TWO workgroups share a CU (with 2^15 words --
+  // one workgroup per CU, half as many parts -- the step took 108 instead of ~60 us per 200 x 50k frames: its time is the
+  // compare-and-swap chains' latency, which a second resident workgroup hides)
   int l = 0;
-  while (l < 3 && nt > fill[l]) ++l;
+  while (l < VO_HJ_MAXL && nt > fill[l]) ++l;
   p.log2s = 12 + l;
   p.log2p = 0;
-  while (p.log2p < 4 && (long long)nt > ((long long)fill[l] << p.log2p)) ++p.log2p;
+  while (p.log2p < 5 && (long long)nt > ((long long)fill[l] << p.log2p)) ++p.log2p;
   if ((long long)nt > ((long long)fill[l] << p.log2p)) return false;   // more than 204 800 points: the general search alone
   p.ib = 1;
   while ((1 << p.ib) < nt) ++p.ib;

@@ -760,9 +760,6 @@ __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
   if (n < 0) n = 0;
   if ((size_t)n > a.cap) n = (int)a.cap;
   const int32_t* pairs = a.pairs + 2 * (size_t)p * a.pairs_stride;
-  const float* world = a.world + 3 * (size_t)p * a.world_stride;
-  const float* meas = a.meas + 2 * (size_t)p * a.meas_stride;
-  float* dst = a.packed + (size_t)p * 5 * a.cap;
   if (a.states && fb.b == 0 && threadIdx.x < 12) {       // launch-per-round form: the problem's starting pose
     const int k = threadIdx.x;
     float v;
@@ -770,26 +767,8 @@ __global__ __launch_bounds__(256) void picp_batch_pack_kernel(BatchArgs a) {
     else v = (k < 9 && (k % 4) == 0) ? 1.f : 0.f;
     a.states[p].pose[0][k] = v;
   }
-  const float qnan = __int_as_float((int)VO_DROPPED_BITS);
-  Pose Xw;
-  if (a.X_world) {
-    float t[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t[k] = a.X_world[16 * (size_t)p + k];
-    Xw = pose_from_T16(t);
-  }
-  for (int i = fb.b * 256 + threadIdx.x; i < n; i += fb.nb * 256) {
-    const int m = pairs[2 * i], w = pairs[2 * i + 1];
-    float x = qnan, y = 0.f, z = 0.f, u = 0.f, v = 0.f;
-    if (m >= 0 && m < a.n_meas && w >= 0 && w < a.n_world) {
-      x = world[3 * (size_t)w]; y = world[3 * (size_t)w + 1]; z = world[3 * (size_t)w + 2];
-      if (a.X_world) { const float px = x, py = y, pz = z; pose_apply(Xw, px, py, pz, x, y, z); }   // PointCloud.h:80, as transform_batch_kernel
-      u = meas[2 * (size_t)m]; v = meas[2 * (size_t)m + 1];
-    } else if (a.n_bad) {
-      atomicAdd(&a.n_bad[p], 1);        // dropped (marker) and counted: reported in stats_out[4p + 3]
-    }
-    dst[i] = x; dst[a.cap + i] = y; dst[2 * a.cap + i] = z; dst[3 * a.cap + i] = u; dst[4 * a.cap + i] = v;
-  }
+  const Pose Xw = batch_pack_pose(a, p);
+  for (int i = fb.b * 256 + threadIdx.x; i < n; i += fb.nb * 256) batch_pack_item(a, p, Xw, (size_t)i, pairs[2 * i], pairs[2 * i + 1]);
 }
 
 // after the solver: the number of correspondences dropped for an index outside the point arrays, per problem
@@ -1200,7 +1179,7 @@ hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a) {
   if (gx < 1) gx = 1;
   BatchArgs ap = a;
   ap.pack_gx = gx;
-  hipLaunchKernelGGL(picp_batch_pack_kernel, frame_grid(gx, a.n_problems), dim3(256), 0, st, ap);
+  if (!a.prepacked) hipLaunchKernelGGL(picp_batch_pack_kernel, frame_grid(gx, a.n_problems), dim3(256), 0, st, ap);
   hipError_t e = launch_picp_batch_solve(st, a);
   if (e == hipSuccess && a.stats_out && a.n_bad) {
     hipLaunchKernelGGL(picp_batch_bad_kernel, dim3((a.n_problems + 255) / 256), dim3(256), 0, st, a);

@@ -103,8 +103,41 @@ struct BatchArgs {
   int exact;           // reference-order form (picp_exact_kernel): one workgroup per problem, sequential sums
   const float* X_world;  // n_problems x 16 (column-major) or null: the gather applies X * p to every world point it fetches
                          //   (X_curr * triangulated_pc of vo_complete.cpp:159 without the pass that writes the moved cloud)
+  int prepacked;         // the packed arrays are already filled (the join's writing pass gathered through its own pairs:
+                         //   launch_join_batch with a sink): no gather pass
 };
 hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a);
+#if defined(__HIPCC__)
+// What the gather does for correspondence i of problem p: (measurement m, world point w) -> packed x, y, z, u, v; an index
+// outside its array leaves the marker and is counted (picp_batch_pack_kernel and the join's writing pass share this).
+__device__ __forceinline__ void batch_pack_item(const BatchArgs& a, int p, const Pose& Xw, size_t i, int m, int w) {
+  const float* world = a.world + 3 * (size_t)p * a.world_stride;
+  const float* meas = a.meas + 2 * (size_t)p * a.meas_stride;
+  float* dst = a.packed + (size_t)p * 5 * a.cap;
+  float x = __int_as_float((int)VO_DROPPED_BITS), y = 0.f, z = 0.f, u = 0.f, v = 0.f;
+  if (m >= 0 && m < a.n_meas && w >= 0 && w < a.n_world) {
+    x = world[3 * (size_t)w]; y = world[3 * (size_t)w + 1]; z = world[3 * (size_t)w + 2];
+    if (a.X_world) { const float px = x, py = y, pz = z; pose_apply(Xw, px, py, pz, x, y, z); }   // PointCloud.h:80, as transform_batch_kernel
+    u = meas[2 * (size_t)m]; v = meas[2 * (size_t)m + 1];
+  } else if (a.n_bad) {
+    atomicAdd(&a.n_bad[p], 1);        // dropped (marker) and counted: reported in stats_out[4p + 3]
+  }
+  dst[i] = x; dst[a.cap + i] = y; dst[2 * a.cap + i] = z; dst[3 * a.cap + i] = u; dst[4 * a.cap + i] = v;
+}
+__device__ __forceinline__ Pose batch_pack_pose(const BatchArgs& a, int p) {
+  Pose Xw;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Xw.R[k] = (k % 4 == 0) ? 1.f : 0.f;
+  Xw.t[0] = Xw.t[1] = Xw.t[2] = 0.f;
+  if (a.X_world) {
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = a.X_world[16 * (size_t)p + k];
+    Xw = pose_from_T16(t);
+  }
+  return Xw;
+}
+#endif
 // when is the launch-per-round form the faster one?  (measured: DESIGN.md section 4.1)
 bool picp_batch_prefers_rounds(int n_problems, size_t cap, int n_iters, int n_cu);
 
@@ -187,10 +220,14 @@ hipError_t launch_triangulate_batch(hipStream_t st, const float K[9], const Pose
                                     const float* d_p2, int n2, const float* d_app2, float* d_out_xyz,
                                     int32_t* d_out_pairs, float* d_out_app, int* d_n_out, int* d_scratch, int n_frames,
                                     size_t pairs_stride, size_t p1_stride, size_t p2_stride, size_t out_stride);
+// sink (or null): the batched solver's arguments -- the writing pass then also gathers every pair it emits into the solver's
+// packed arrays (what picp_batch_pack_kernel would do from the pairs it has just written); the caller sets sink->prepacked.
+// join_fuses_gather(): whether launch_join_batch will honour a sink at these sizes (the one-launch form of small frames does not).
+bool join_fuses_gather(int n_img, int n_world, int n_ref);
 hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, const int* d_n_img,
                              const int32_t* d_world, int n_world, const int* d_n_world, int n_ref, int32_t* d_out,
                              int* d_n_out, unsigned long long* d_table, int* d_scratch, int n_frames, size_t img_stride,
-                             size_t world_stride, size_t out_stride);
+                             size_t world_stride, size_t out_stride, const BatchArgs* sink = nullptr);
 
 // in-place exclusive scan of nb ints per frame (one workgroup per frame), total to total[frame] (and total2[frame])
 hipError_t launch_scan(hipStream_t st, int* counts, int nb, int* total, int* total2 = nullptr, int n_frames = 1,
