@@ -194,9 +194,12 @@ def main():
                      "traffic": _pmc_traffic("vo::picp_round_kernel<true, false, true, false>", 256 * ((args.points + 255) // 256))[0],
                      "traffic_note": _pmc_traffic("vo::picp_round_kernel<true, false, true, false>", 256 * ((args.points + 255) // 256))[1],
                      "algorithmic_bytes_per_launch": alg_bytes, "launch_us": per_round_us,
+                     "in_kernel": _headline_stamps(per_round_us),
                      "note": "one launch = one Gauss-Newton round over one 50k pair (1.0 MB, L2-resident): "
                              "latency-bound by the serial solve->linearize dependency, not by HBM; launch_us is "
-                             "event time over the timed region / launches, i.e. it includes the kernel boundary"},
+                             "event time over the timed region / launches, i.e. it includes the kernel boundary "
+                             "(and 1/50 of the step's gather and finishing launches); in_kernel: the phase stamps of the "
+                             "same geometry from the diagnostic build (tools/stamps_headline.sh), kept under profiles/"},
     }
 
     # the rank-0-only legs (batched solver sweep, serial sequence, CPU baseline) would keep the other ranks
@@ -249,6 +252,21 @@ def _pmc_file():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_fetch_write*.json")))
     return files[-1] if files else None
+
+
+def _headline_stamps(launch_us):
+    """In-kernel phase split of the headline round (profiles/r04_headline_stamps.json: s_memtime stamps of workgroup 0 over
+    1470 rounds of the timed geometry, VO_STAMPS build) beside this run's launch_us."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_headline_stamps.json")
+    try:
+        st = json.load(open(path))
+    except Exception:
+        return None
+    return {"source": "profiles/r04_headline_stamps.json", "rounds": st["rounds"],
+            "in_kernel_us": st["in_kernel_us_mean"], "kernel_boundary_us": st["kernel_boundary_us_mean"],
+            "round_to_round_us": st["round_to_round_us_mean"],
+            "round_to_round_over_this_runs_launch_us": st["round_to_round_us_mean"] / launch_us,
+            "phases_us": st["phases_us_mean"]}
 
 
 def _pmc_traffic(kernel, grid_threads):

@@ -354,8 +354,18 @@ __global__ __launch_bounds__(256) void picp_pack_kernel(const int32_t* __restric
       S->stamps[it][k] = _t;                                                              \
     }                                                                                     \
   } while (0)
+// the constant 100 MHz reference clock beside the shader-clock stamp: calibrates s_memtime's tick per step
+#define VO_STAMP_REAL(k)                                                                  \
+  do {                                                                                    \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && it < 128) {                                \
+      unsigned long long _t;                                                              \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");     \
+      S->stamps[it][k] = _t;                                                              \
+    }                                                                                     \
+  } while (0)
 #else
 #define VO_STAMP(k) do {} while (0)
+#define VO_STAMP_REAL(k) do {} while (0)
 #endif
 
 // ---- one Gauss-Newton round ---------------------------------------------------
@@ -388,6 +398,7 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
   __shared__ float s_stat[4];
   const int tid = threadIdx.x;
   VO_STAMP(0);
+  VO_STAMP_REAL(7);
 
   // (1) The previous launch's workgroup partials (nb rows of 32 floats, zero-padded to
   // a multiple of 256 rows) depend on kernel arguments only: their loads go out first,
