@@ -164,8 +164,10 @@ int vo_picp_graph_info(vo_picp *s, int *use_graph, int *n_graphs, int *n_failure
  * (as restated by oracle/: tests/test_gpu_exact.py).  One workgroup, all rounds in one launch:
  * a few microseconds per round at the <= 127 points per frame of the reference's dataset, 0.18 ms
  * per round at 50k (the serial chain of 50 000 dependent float adds).  The default (fast) mode differs from it by rounding only (tree reduction,
- * one FMA per product, Newton-refined hardware reciprocals, unpivoted LDLT, float sincos): every projection is within an ulp or
- * two of the reference-order value, so a gate or chi^2 decision can differ only for a correspondence that close to the gate. */
+ * one FMA per product, Newton-refined hardware reciprocals, unpivoted LDLT, float sincos): a gate or chi^2 decision can differ
+ * from the reference's only for a correspondence whose reference-order value lies within a few ulp of the gate -- measured on
+ * correspondences planted at every gate (tests/test_gpu_gates.py, same pose in): <= 2 ulp for the depth gates, <= 3.7 for the
+ * image gates, <= 276 ulp of the threshold for chi^2 (3e-5 relative); the test holds 4 / 8 / 1024. */
 int vo_picp_set_exact(vo_picp *s, int on);
 /* device pairs; d_n_pairs (may be NULL) points at a device int that overrides
  * n_pairs (<= n_pairs), so the output of the join kernel can be consumed

@@ -176,9 +176,14 @@ VO_HD bool is_pinhole(const float K[9]) {
 // can reach an accumulator.  A world x of VO_DROPPED_BITS marks a dropped correspondence.
 //
 // This is the DEFAULT mode's arithmetic: the reference's formulas with one FMA per product and the reciprocal of
-// vo_recip_z -- every intermediate within an ulp or two of the reference's unfused value, so a decision (depth / image
+// vo_recip_z -- every intermediate within a few ulp of the reference's unfused value, so a decision (depth / image
 // gate, chi^2 test) can differ from the reference's only for a correspondence that lies within that rounding of the
-// gate itself; sums: H_rc += J0r*J0c ; H_rc += J1r*J1c (lambda, when it is not 1, folded into the left factor)
+// gate itself: measured on 49 000 correspondences planted at every gate (tests/test_gpu_gates.py) <= 2 ulp of the gate for
+// the depth gates, <= 3.7 for the image gates, <= 276 ulp of thr for chi^2 (= e0^2 + e1^2: the pixel error of (u, v) times
+// 2 |e|, 3e-5 relative at thr = 100); the test holds the bands 4 / 8 / 1024.  Taking the decisions on reference-order
+// values costs the batched solver 20 % (126 against 99 instructions per correspondence); a guard that
+// re-evaluates only near-gate correspondences was measured too -- its detection arithmetic alone (VO_GUARD_PROBE below)
+// costs 9 % -- and not kept; sums: H_rc += J0r*J0c ; H_rc += J1r*J1c (lambda, when it is not 1, folded into the left factor)
 // instead of (J0r*J0c + J1r*J1c)*lambda followed by an add.  The batched solver is bound by VALU issue, and this form
 // is ~20 instructions per correspondence shorter than the unfused one.  Reference-order arithmetic, decisions
 // included, is picp_term_exact below (vo_picp_set_exact).
@@ -216,7 +221,22 @@ VO_HD void picp_accumulate_t(const CamK& cam, const Pose& T, float thr, float wx
   }
   float lambda = inl ? 1.f : 0.f;
   if (keep_outliers) lambda = outl ? sqrtf(thr / chi) : lambda;                 // :80, :90
+#ifdef VO_GUARD_PROBE
+  // TIMING PROBE ONLY (never shipped): the detection half of a rigorous decision guard -- margins of the depth and image gates
+  // folded with min / min3, a per-lane slack for (u, v) from |1/z|, the chi^2 margin against a slack from |e0| + |e1| -- with
+  // placeholder per-problem constants; a lane found near a gate is dropped so that the arithmetic stays live.
+  bool use;
+  {
+    const float dz = fminf(pc2 - (float)cam.z_near, (float)cam.z_far - pc2);
+    const float duv = fminf(fminf(u, (float)(cam.cols - 1) - u), fminf(v, (float)(cam.rows - 1) - v));
+    const float s_lane = vo_fma(fabsf(iz), 0.02f, 2e-4f);
+    const float s_chi = vo_fma(fabsf(e0) + fabsf(e1), s_lane + s_lane, 4e-6f * chi);
+    const bool near = (fabsf(dz) <= 1e-5f) | (pc2 < (float)cam.z_far * 0.0078125f) | (fabsf(duv) <= s_lane) | (fabsf(chi - thr) <= s_chi);
+    use = lambda != 0.f && !near;
+  }
+#else
   const bool use = lambda != 0.f;
+#endif
   // Jp*K (:39-51): row 0 = iz * (K row 0 - u * K row 2), row 1 = iz * (K row 1 - v * K row 2) -- the reference's
   // iz*K_0c + (-ph0*iz^2)*K_2c with u = ph0*iz taken out.  A term that must not contribute has the generators of its
   // Jacobian zeroed, so that no inf/nan of a rejected projection reaches an accumulator.
