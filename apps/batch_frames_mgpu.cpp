@@ -25,29 +25,14 @@
 #include <rccl/rccl.h>
 
 #include "synth.hpp"
+#include "vo/shard.hpp"
 #include "vo_hip.h"
 
 namespace {
 
-// dist.shard_range: contiguous blocks that differ by at most one item
-void shard_range(int n_items, int rank, int world, int& lo, int& hi) {
-  const int base = n_items / world, rem = n_items % world;
-  lo = rank * base + std::min(rank, rem);
-  hi = lo + base + (rank < rem ? 1 : 0);
-}
-
-struct Barrier {
-  std::mutex m;
-  std::condition_variable cv;
-  int n, waiting = 0, phase = 0;
-  explicit Barrier(int n_) : n(n_) {}
-  void wait() {
-    std::unique_lock<std::mutex> lk(m);
-    const int ph = phase;
-    if (++waiting == n) { waiting = 0; ++phase; cv.notify_all(); }
-    else cv.wait(lk, [&] { return phase != ph; });
-  }
-};
+using vo::shard::Agreement;
+using vo::shard::Barrier;
+using vo::shard::shard_range;      // the partition, the gathered buffer's layout and the go / no-go rule: vo/shard.hpp
 
 struct Pair {
   std::vector<float> ref_app, cur_app, ref_pts, cur_pts, model;
@@ -93,8 +78,8 @@ struct Shared {
   int world, P, n, rounds, repeats, per_call, blk;
   std::vector<ncclComm_t> comms;
   Barrier* bar;
+  Agreement* agree;                     // per rank: first failure; the common go / no-go before every collective
   std::vector<double> seconds;          // per rank: wall time of the timed passes
-  std::vector<std::string> error;       // per rank: first failure ("" = fine)
   std::vector<float> worst;             // per rank: worst |T - T_gt|
   std::vector<int> bad;                 // per rank: frames with a missing match / join / inlier
   std::vector<int> gather_mismatch;     // per rank: gathered rows that differ from their owner's poses
@@ -104,12 +89,12 @@ struct Shared {
 #define RANK_CHECK(call)                                                                         \
   do {                                                                                           \
     const int rc_ = (call);                                                                      \
-    if (rc_ != VO_OK && S.error[(size_t)rank].empty()) S.error[(size_t)rank] = std::string(#call) + ": " + vo_last_error(); \
+    if (rc_ != VO_OK) S.agree->fail(rank, std::string(#call) + ": " + vo_last_error());            \
   } while (0)
 #define NCCL_CHECK(call)                                                                         \
   do {                                                                                           \
     const ncclResult_t rc_ = (call);                                                             \
-    if (rc_ != ncclSuccess && S.error[(size_t)rank].empty()) S.error[(size_t)rank] = std::string(#call) + ": " + ncclGetErrorString(rc_); \
+    if (rc_ != ncclSuccess) S.agree->fail(rank, std::string(#call) + ": " + ncclGetErrorString(rc_)); \
   } while (0)
 
 template <class T>
@@ -140,11 +125,11 @@ void rank_main(int rank, Shared& S) {
     b.poses = dev_alloc<float>(ctx, 16 * (size_t)S.blk);       // blk rows: the gather needs equal-sized blocks (padding rows stay 0)
     owned = {ref_app, cur_app, ref_pts, cur_pts, model, model_pairs, b.matches, b.joined, b.model_moved, b.stats, b.tri_xyz,
              b.tri_pairs, b.counts, b.poses};
-    for (void* d : owned) if (!d && S.error[(size_t)rank].empty()) S.error[(size_t)rank] = std::string("device allocation failed: ") + vo_last_error();
-    if (S.error[(size_t)rank].empty()) {
+    for (void* d : owned) if (!d) S.agree->fail(rank, std::string("device allocation failed: ") + vo_last_error());
+    if (S.agree->ok(rank)) {
       std::vector<float> zero(16 * (size_t)S.blk, 0.f);
       RANK_CHECK(vo_memcpy_h2d(ctx, b.poses, zero.data(), zero.size() * sizeof(float)));
-      for (int f = 0; f < F && S.error[(size_t)rank].empty(); ++f) {       // this rank's pairs: generated here, uploaded, dropped
+      for (int f = 0; f < F && S.agree->ok(rank); ++f) {       // this rank's pairs: generated here, uploaded, dropped
         const Pair p = make_pair(n, 4000 + (uint64_t)(lo + f), K);
         const size_t at = (size_t)f * (size_t)n;
         RANK_CHECK(vo_memcpy_h2d(ctx, ref_app + 10 * at, p.ref_app.data(), p.ref_app.size() * sizeof(float)));
@@ -164,14 +149,16 @@ void rank_main(int rank, Shared& S) {
   for (int k = 0; k < 9; ++k) b.K[k] = K[k];
   b.kernel_threshold = 10000.f; b.keep_outliers = 0; b.n_iters = S.rounds; b.radius = 0.1f;
   float* gathered = ctx ? dev_alloc<float>(ctx, 16 * (size_t)S.blk * (size_t)S.world) : nullptr;
-  if (ctx && !gathered && S.error[(size_t)rank].empty()) S.error[(size_t)rank] = "device allocation failed (gather buffer)";
+  if (ctx && !gathered) S.agree->fail(rank, "device allocation failed (gather buffer)");
 
-  // one pass = this rank's share in calls of <= per_call frames (every stage one batched launch per call), then the gather
-  const int per_call = S.per_call > 0 ? S.per_call : F;
-  auto pass = [&]() {
-    for (int f0 = 0; f0 < F && S.error[(size_t)rank].empty(); f0 += per_call) {
+  // one pass = this rank's share in calls of <= per_call frames (every stage one batched launch per call), then -- once
+  // EVERY rank has come through its calls (Agreement: nobody enters a collective that another rank will not) -- the gather
+  const std::vector<vo::shard::Call> calls = vo::shard::calls_of(F, S.per_call);
+  auto pass = [&]() -> bool {
+    for (const vo::shard::Call& cl : calls) {
+      if (!S.agree->ok(rank)) break;
       vo_frame_batch c = b;
-      const int Fc = std::min(per_call, F - f0);
+      const int f0 = cl.first, Fc = cl.count;
       const size_t at = (size_t)f0 * (size_t)n;
       c.n_frames = Fc;
       c.ref_app = b.ref_app + 10 * at; c.cur_app = b.cur_app + 10 * at; c.ref_pts = b.ref_pts + 2 * at; c.cur_pts = b.cur_pts + 2 * at;
@@ -182,25 +169,24 @@ void rank_main(int rank, Shared& S) {
       c.counts = b.counts + 3 * (size_t)f0;                    // this call's [3][Fc] block
       RANK_CHECK(vo_frames_batch_dev(ctx, &c));
     }
+    if (!S.agree->all_ok()) return false;
     // the final exchange: SE(3) poses of all ranks (blk x 16 floats each), on the context's stream behind the last launch
     NCCL_CHECK(ncclAllGather(b.poses, gathered, 16 * (size_t)S.blk, ncclFloat, S.comms[(size_t)rank],
                              reinterpret_cast<hipStream_t>(vo_ctx_stream(ctx))));
+    return true;
   };
-  const bool ready = ctx && S.error[(size_t)rank].empty();
-  // (a rank that failed during set-up still joins every barrier, and every collective the others will wait in, as far
-  // as it can -- but set-up failures are fatal for the run: report and leave before the first collective)
-  S.bar->wait();
-  bool all_ready = true;
-  for (const std::string& e : S.error) all_ready = all_ready && e.empty();
-  if (all_ready && ready) {
-    pass();                                                    // sizes every workspace, warms the communicator
-    RANK_CHECK(vo_ctx_synchronize(ctx));
+  // a rank that failed during set-up still meets the others here; set-up failures end the run before the first collective
+  if (S.agree->all_ok()) {
+    bool good = pass();                                        // sizes every workspace, warms the communicator
+    if (good) RANK_CHECK(vo_ctx_synchronize(ctx));
     S.bar->wait();
     const auto t0 = std::chrono::steady_clock::now();
-    for (int r = 0; r < S.repeats; ++r) pass();
-    RANK_CHECK(vo_ctx_synchronize(ctx));
+    for (int r = 0; r < S.repeats && good; ++r) good = pass();
+    if (ctx) RANK_CHECK(vo_ctx_synchronize(ctx));
     S.bar->wait();                                             // the job is done when the slowest rank is
     S.seconds[(size_t)rank] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / S.repeats;
+  }
+  if (S.agree->all_ok()) {
     // checks: own frames against the generator's ground truth, own block of the gathered buffer, everybody's blocks
     std::vector<float> poses(16 * (size_t)std::max(F, 1)), stats(4 * (size_t)std::max(F, 1)), all(16 * (size_t)S.blk * (size_t)S.world);
     std::vector<int> counts(3 * (size_t)std::max(F, 1));
@@ -210,8 +196,8 @@ void rank_main(int rank, Shared& S) {
     RANK_CHECK(vo_memcpy_d2h(ctx, all.data(), gathered, all.size() * sizeof(float)));
     float worst = 0.f;
     int bad = 0;
-    for (int f0 = 0; f0 < F; f0 += per_call) {
-      const int Fc = std::min(per_call, F - f0);
+    for (const vo::shard::Call& cl : calls) {
+      const int f0 = cl.first, Fc = cl.count;
       for (int f = 0; f < Fc; ++f) {
         const int* c3 = counts.data() + 3 * (size_t)f0;        // [3][Fc]
         for (int k = 0; k < 16; ++k) worst = std::max(worst, std::fabs(poses[16 * (size_t)(f0 + f) + k] - gt[(size_t)(f0 + f)].m[k]));
@@ -219,27 +205,10 @@ void rank_main(int rank, Shared& S) {
       }
     }
     S.worst[(size_t)rank] = worst; S.bad[(size_t)rank] = bad;
-    int mism = 0;
-    for (int f = 0; f < F; ++f)
-      if (std::memcmp(&all[16 * ((size_t)rank * (size_t)S.blk + (size_t)f)], &poses[16 * (size_t)f], 16 * sizeof(float)) != 0) ++mism;
-    // every other rank's rows must be poses too: a rigid transform has last row (0 0 0 1) (col-major: elements 3, 7, 11, 15)
-    for (int r = 0; r < S.world; ++r) {
-      int l2, h2;
-      shard_range(S.P, r, S.world, l2, h2);
-      for (int f = 0; f < h2 - l2; ++f) {
-        const float* T = &all[16 * ((size_t)r * (size_t)S.blk + (size_t)f)];
-        if (!(T[3] == 0.f && T[7] == 0.f && T[11] == 0.f && T[15] == 1.f)) ++mism;
-      }
-    }
-    S.gather_mismatch[(size_t)rank] = mism;
-    if (rank == 0) {
-      S.all_poses.assign(16 * (size_t)S.P, 0.f);
-      for (int r = 0; r < S.world; ++r) {
-        int l2, h2;
-        shard_range(S.P, r, S.world, l2, h2);
-        std::memcpy(&S.all_poses[16 * (size_t)l2], &all[16 * (size_t)r * (size_t)S.blk], 16 * (size_t)(h2 - l2) * sizeof(float));
-      }
-    }
+    // own block of the gathered buffer == what this rank computed; every rank's rows are rigid transforms (vo/shard.hpp)
+    S.gather_mismatch[(size_t)rank] = vo::shard::own_block_mismatches(all.data(), S.P, S.world, rank, poses.data(), 16) +
+                                      vo::shard::rows_not_rigid(all.data(), S.P, S.world);
+    if (rank == 0) S.all_poses = vo::shard::to_global_order(all.data(), S.P, S.world, 16);
   }
   if (ctx) {
     for (void* d : owned) if (d) vo_dev_free(ctx, d);
@@ -264,15 +233,16 @@ int main(int argc, char** argv) {
   if (want > n_dev) { std::fprintf(stderr, "batch_frames_mgpu: %d GPUs asked for, %d present\n", want, n_dev); return 2; }
   if (S.P < want || S.n < 8 || S.rounds < 0 || S.repeats < 1) { std::fprintf(stderr, "batch_frames_mgpu: need pairs >= gpus, points >= 8, repeats >= 1\n"); return 2; }
   S.world = want;
-  { int lo, hi; shard_range(S.P, 0, S.world, lo, hi); S.blk = hi - lo; }       // rank 0 holds a largest block
+  S.blk = vo::shard::block_rows(S.P, S.world);                                  // rank 0 holds a largest block
   std::vector<int> devs((size_t)S.world);
   std::iota(devs.begin(), devs.end(), 0);
   S.comms.resize((size_t)S.world);
   const ncclResult_t rc = ncclCommInitAll(S.comms.data(), S.world, devs.data());
   if (rc != ncclSuccess) { std::fprintf(stderr, "ncclCommInitAll: %s\n", ncclGetErrorString(rc)); return 2; }
   Barrier bar(S.world);
-  S.bar = &bar;
-  S.seconds.assign((size_t)S.world, 0.0); S.error.assign((size_t)S.world, ""); S.worst.assign((size_t)S.world, 0.f);
+  Agreement agree(S.world, bar);
+  S.bar = &bar; S.agree = &agree;
+  S.seconds.assign((size_t)S.world, 0.0); S.worst.assign((size_t)S.world, 0.f);
   S.bad.assign((size_t)S.world, 0); S.gather_mismatch.assign((size_t)S.world, 0);
   std::vector<std::thread> th;
   for (int r = 0; r < S.world; ++r) th.emplace_back(rank_main, r, std::ref(S));
@@ -280,7 +250,7 @@ int main(int argc, char** argv) {
   for (ncclComm_t c : S.comms) ncclCommDestroy(c);
   int fail = 0;
   for (int r = 0; r < S.world; ++r)
-    if (!S.error[(size_t)r].empty()) { std::fprintf(stderr, "rank %d: %s\n", r, S.error[(size_t)r].c_str()); fail = 2; }
+    if (!agree.errors()[(size_t)r].empty()) { std::fprintf(stderr, "rank %d: %s\n", r, agree.errors()[(size_t)r].c_str()); fail = 2; }
   if (fail) return fail;
   const double sec = *std::max_element(S.seconds.begin(), S.seconds.end());
   const float worst = *std::max_element(S.worst.begin(), S.worst.end());

@@ -9,7 +9,11 @@
 // kernels frame by frame through Camera / PICPSolver / triangulate_points.
 // setMatchUpFront(true): the matcher needs the appearances alone, so all F-1 consecutive pairs are matched by ONE
 // vo_match_appearances_batch_dev call before the chain starts (frames of different sizes; the appearances are held as
-// [F][capacity][10], so the pairs (t-1, t) are two views of one array); same pairs, same order, same results.
+// [F][capacity][10], so the pairs (t-1, t) are two views of one array; more than 65535 pairs go in several calls); same
+// pairs, same order, same results.  setMatchesExternal(): the pairs come from somewhere else altogether -- the native
+// multi-GPU driver matches blocks of consecutive pairs on the node's GPUs and gathers them (apps/sequence_mgpu.cpp,
+// SURVEY 8(e)) -- as [row][capacity] pairs + one count per row in device memory of this context, row_of[t - 1] naming
+// the row of pair (t-1, t).  The mode in force when run() starts is the one counts() / cloud() read afterwards.
 #pragma once
 
 #include <algorithm>
@@ -68,22 +72,39 @@ class DeviceSequence {
   void setExact(bool on) { check(vo_picp_set_exact(solver_, on ? 1 : 0), "vo_picp_set_exact"); }
   //! match every consecutive pair in one batched call at the start of run() instead of one call per frame inside the chain
   void setMatchUpFront(bool on) {
-    if (on && !d_pm_) {
+    if (ran_) throw Error(VO_ERR_INVALID_ARG, "DeviceSequence: the matching mode cannot change after run()");
+    if (on && !d_pm_own_) {
       std::vector<int> sizes((size_t)F_);
       for (int t = 0; t < F_; ++t) sizes[(size_t)t] = (int)n(t);
       d_n_all_ = alloc<int>((size_t)F_);
       check(vo_memcpy_h2d(ctx_, d_n_all_, sizes.data(), sizes.size() * sizeof(int)), "DeviceSequence::setMatchUpFront");
-      d_pm_ = alloc<int32_t>(2 * cap_ * (size_t)(F_ - 1));
-      d_pm_cnt_ = alloc<int>((size_t)(F_ - 1));
+      d_pm_own_ = alloc<int32_t>(2 * cap_ * (size_t)(F_ - 1));
+      d_pm_cnt_own_ = alloc<int>((size_t)(F_ - 1));
     }
-    up_front_ = on;
+    mode_ = on ? UpFront : PerFrame;
   }
+  //! the pairs of every consecutive frame pair, computed elsewhere: d_pairs[row][capacity()] pairs (ref_idx, cur_idx) and
+  //! d_counts[row] in device memory of this context; pair (t-1, t) sits in row row_of[t - 1]  (row_of.size() == frames() - 1)
+  void setMatchesExternal(const int32_t* d_pairs, const int* d_counts, const std::vector<int>& row_of) {
+    if (ran_) throw Error(VO_ERR_INVALID_ARG, "DeviceSequence: the matching mode cannot change after run()");
+    if ((int)row_of.size() != F_ - 1 || !d_pairs || !d_counts) throw Error(VO_ERR_INVALID_ARG, "DeviceSequence::setMatchesExternal: one row per consecutive pair");
+    d_pm_ext_ = d_pairs; d_pm_cnt_ext_ = d_counts; row_of_ = row_of;
+    mode_ = External;
+  }
+  //! pairs per row of the arrays setMatchesExternal takes (the largest measurement set)
+  size_t capacity() const { return cap_; }
 
   //! enqueue the whole sequence; returns after the (host) epipolar initialisation, the chain runs on
   void run() {
-    if (up_front_)
-      check(vo_match_appearances_batch_dev(ctx_, F_ - 1, app_of(0), (int)cap_, d_n_all_, app_of(1), (int)cap_, d_n_all_ + 1, 0.1f,
-                                           d_pm_, d_pm_cnt_), "vo_match_appearances_batch_dev");
+    ran_ = true;
+    if (mode_ == UpFront) {
+      // the frame is a grid dimension of the batched matcher: at most 65535 pairs per call
+      for (int p0 = 0; p0 < F_ - 1; p0 += 65535) {
+        const int np = std::min(65535, F_ - 1 - p0);
+        check(vo_match_appearances_batch_dev(ctx_, np, app_of(p0), (int)cap_, d_n_all_ + p0, app_of(p0 + 1), (int)cap_, d_n_all_ + p0 + 1,
+                                             0.1f, d_pm_own_ + 2 * cap_ * (size_t)p0, d_pm_cnt_own_ + p0), "vo_match_appearances_batch_dev");
+      }
+    }
     // first pair: vo_complete.cpp:121-132
     match(1);
     int c0 = 0;
@@ -124,7 +145,7 @@ class DeviceSequence {
   void counts(int t, int& n_match, int& n_join, int& n_tri) const {
     int c[3];
     check(vo_memcpy_d2h(ctx_, c, d_counts_ + 3 * (size_t)t, sizeof(c)), "DeviceSequence::counts");
-    if (up_front_ && t >= 1) check(vo_memcpy_d2h(ctx_, c, cnt(t, 0), sizeof(int)), "DeviceSequence::counts");
+    if (mode_ != PerFrame && t >= 1) check(vo_memcpy_d2h(ctx_, c, cnt(t, 0), sizeof(int)), "DeviceSequence::counts");
     n_match = c[0]; n_join = c[1]; n_tri = c[2];
   }
   //! triangulated cloud of frame t >= 1 (in the frame of camera t), with the appearances of frame t's points
@@ -157,12 +178,21 @@ class DeviceSequence {
   size_t n(int t) const { return off_[(size_t)t + 1] - off_[(size_t)t]; }
   const float* pts_of(int t) const { return d_pts_ + 2 * off_[(size_t)t]; }
   const float* app_of(int t) const { return d_app_ + 10 * cap_ * (size_t)t; }
-  int* cnt(int t, int i) const { return (i == 0 && up_front_) ? d_pm_cnt_ + (t - 1) : d_counts_ + 3 * (size_t)t + i; }
-  int32_t* m_of(int t) const { return up_front_ ? d_pm_ + 2 * cap_ * (size_t)(t - 1) : d_m_; }
+  // where the pairs of (t-1, t) and their count live: the chain's own buffers, the up-front call's, or the caller's rows
+  int* cnt(int t, int i) const {
+    if (i == 0 && mode_ == UpFront) return d_pm_cnt_own_ + (t - 1);
+    if (i == 0 && mode_ == External) return const_cast<int*>(d_pm_cnt_ext_) + row_of_[(size_t)t - 1];
+    return d_counts_ + 3 * (size_t)t + i;
+  }
+  int32_t* m_of(int t) const {
+    if (mode_ == UpFront) return d_pm_own_ + 2 * cap_ * (size_t)(t - 1);
+    if (mode_ == External) return const_cast<int32_t*>(d_pm_ext_) + 2 * cap_ * (size_t)row_of_[(size_t)t - 1];
+    return d_m_;
+  }
   float* xyz_of(int t) const { return d_xyz_ + 3 * cap_ * (size_t)t; }
   int32_t* pairs_of(int t) const { return d_pairs_ + 2 * cap_ * (size_t)t; }
   void match(int t) {
-    if (up_front_) return;                       // pairs and count of frame t are already where m_of / cnt point
+    if (mode_ != PerFrame) return;               // pairs and count of frame t are already where m_of / cnt point
     check(vo_match_appearances_dev(ctx_, app_of(t - 1), (int)n(t - 1), app_of(t), (int)n(t), 0.1f, d_m_, cnt(t, 0)),
           "vo_match_appearances_dev");
   }
@@ -184,9 +214,13 @@ class DeviceSequence {
   const float* d_pose_ = nullptr;
   float *d_pts_ = nullptr, *d_app_ = nullptr, *d_model_t_ = nullptr, *d_xyz_ = nullptr, *d_tapp_ = nullptr, *d_traj_ = nullptr,
         *d_ident_ = nullptr;
-  int32_t *d_m_ = nullptr, *d_j_ = nullptr, *d_pairs_ = nullptr, *d_pm_ = nullptr;
-  int *d_counts_ = nullptr, *d_n_all_ = nullptr, *d_pm_cnt_ = nullptr;
-  bool up_front_ = false;
+  int32_t *d_m_ = nullptr, *d_j_ = nullptr, *d_pairs_ = nullptr, *d_pm_own_ = nullptr;
+  int *d_counts_ = nullptr, *d_n_all_ = nullptr, *d_pm_cnt_own_ = nullptr;
+  const int32_t* d_pm_ext_ = nullptr;
+  const int* d_pm_cnt_ext_ = nullptr;
+  std::vector<int> row_of_;
+  enum Mode { PerFrame, UpFront, External } mode_ = PerFrame;
+  bool ran_ = false;
   std::vector<void*> owned_;
 };
 

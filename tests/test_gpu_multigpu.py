@@ -30,6 +30,31 @@ def test_native_multi_gpu_driver_with_one_rank():
     assert r.returncode == 2 and "GPUs asked for" in r.stderr
 
 
+def test_native_sequence_driver_with_one_rank(tmp_path):
+    """apps/sequence_mgpu (second row: the consecutive pairs of a real sequence matched in blocks on the node's
+    GPUs, counts + padded pair lists all-gathered with RCCL, the chain on rank 0) on the reference's dataset with ONE rank:
+    every file it writes must equal, byte for byte, what `vo_complete --resident --match-up-front` writes -- fast and
+    reference-order arithmetic."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "apps"), "-s"])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    data = os.path.join(ROOT, "tests", "golden", "example_data", "data")
+    for flags in ([], ["--exact"]):
+        a, b = tmp_path / ("a" + "".join(flags)), tmp_path / ("b" + "".join(flags))
+        a.mkdir(); b.mkdir()
+        r = subprocess.run([os.path.join(BIN, "sequence_mgpu"), data, str(a), "1", "100"] + flags, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == 1 and d["frames"] == 121 and d["pairs_per_rank"] == 120 and d["matches_total"] == d["matches_found_by_the_ranks"] > 5000
+        r2 = subprocess.run([os.path.join(BIN, "vo_complete"), data, str(b), "100", "--resident", "--match-up-front"] + flags,
+                            capture_output=True, text=True, timeout=600, env=env)
+        assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr
+        for f in ("poses_raw.txt", "trajectory_est_complete.txt", "trajectory_est_data.txt", "map.txt", "map_appearances.txt"):
+            assert (a / f).read_bytes() == (b / f).read_bytes(), (f, flags)
+        assert len((a / "poses_raw.txt").read_text().splitlines()) == 121
+    r = subprocess.run([os.path.join(BIN, "sequence_mgpu"), data, str(tmp_path), "64"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 2 and "GPUs asked for" in r.stderr
+
+
 def test_bench_self_launch_route_with_one_rank():
     env = dict(os.environ, VO_BENCH_FORCE_LAUNCH="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-extras", "--steps", "20", "--warmup", "3"],

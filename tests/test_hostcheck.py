@@ -240,6 +240,21 @@ def test_point_cloud_update_follows_operator_equal(tmp_path):
     assert r.returncode == 0 and r.stdout.split() == ["4", "2"], r.stdout
 
 
+def test_multi_gpu_rank_bookkeeping_without_a_gpu(tmp_path):
+    """include/vo/shard.hpp -- what apps/batch_frames_mgpu.cpp and apps/sequence_mgpu.cpp do between the GPU calls: partition,
+    equal padded blocks, per-call slicing, the gathered buffer's layout, own-block / foreign-block checks, global order, and the
+    rule that no rank enters a collective unless all do -- with every rank a host thread over fake pose buffers: worlds of
+    2, 3 and 8 ranks, 13 and 1601 items, fewer items than ranks, a rank failing at set-up and one failing between two passes
+    (the program must come back, not hang)."""
+    exe = str(tmp_path / "shard_check")
+    root = os.path.join(HERE, "..")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I" + os.path.join(root, "include"),
+                           os.path.join(HERE, "hostcheck", "shard_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("shard_check: all ok"), r.stdout[-3000:]
+    assert r.stdout.count("-> ok") >= 40 and "FAILED" not in r.stdout
+
+
 # ---- host linear algebra of the epipolar initialisation (include/vo/epipolar.hpp, vo/linalg.hpp) ---------------------
 @pytest.fixture(scope="module")
 def epi():
