@@ -664,7 +664,14 @@ def batched_leg(torch, vo, ctx, stream, args):
         for P in (256, 512):
             r = _batched_run(torch, vo, ctx, stream, args, P)
             out["chip_full"].append({"pairs": P, "kernel_ms": r["kernel_ms"], "iters_per_sec": r["iters_per_sec"],
-                                     "achieved_GBs": r["roofline"]["achieved"], "frac": r["roofline"]["frac"]})
+                                     "achieved_GBs": r["roofline"]["achieved"], "frac": r["roofline"]["frac"],
+                                     "frac_algorithmic": r["frac_algorithmic"], "frac_traffic": r["frac_traffic"],
+                                     "working_set_MB": r["working_set_MB"],
+                                     "working_set_fits_infinity_cache": r["working_set_fits_infinity_cache"]})
+        past = [c for c in out["chip_full"] if not c["working_set_fits_infinity_cache"]]
+        if past:      # the point to read as an HBM fraction: its working set cannot live in the Infinity Cache
+            out["hbm_point"] = dict(past[-1], note="working set beyond the 256 MiB Infinity Cache: frac_traffic of this point is "
+                                                    "HBM traffic over time over 8 TB/s (DRAM-destined requests: profiles/r04_pmc_dram.txt)")
         # a few problems per call: the launch-per-round form (problem = grid dimension) against one workgroup per problem
         out["few_problems"] = []
         for P in (4, 16):
@@ -726,7 +733,18 @@ def _batched_run(torch, vo, ctx, stream, args, P):
     # per call: one gather pass (8 B pair + 20 B point data read, 20 B written) + iters streaming passes of 20 B
     alg = P * n * BYTES_PER_CORR_ITER * iters
     gbs = alg / (kernel_ms * 1e-3) / 1e9
+    # what of it can reach HBM at all: the first two trips of every thread (2 x 768 threads x 4 correspondences) stay in LDS
+    # after round 0 (PICP_BATCH_LDS_TRIPS, picp.hip); and a working set below the 256 MiB Infinity Cache is re-read from it
+    resident = min(2 * 768 * 4, n) / n * (iters - 1) / iters
+    traffic_model = alg * (1.0 - resident)
+    working_set = P * n * BYTES_PER_CORR_ITER
     return {"pairs": P, "ms_per_call": ms, "pack_ms": pack_ms, "kernel_ms": kernel_ms,
+            "frac_algorithmic": gbs / HBM_PEAK_GBS,
+            "frac_traffic": traffic_model / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "working_set_MB": working_set / 1e6, "working_set_fits_infinity_cache": bool(working_set < 256 * 2 ** 20),
+            "frac_note": "frac_algorithmic = 20 B x correspondences x rounds / time / 8 TB/s; frac_traffic = the same without the "
+                         "bytes that stay in LDS after round 0; a working set below 256 MiB is served (partly) by the Infinity "
+                         "Cache, whose hits FETCH_SIZE counts -- the HBM figure is the chip_full point whose working set exceeds it",
             "iters_per_sec": P * iters / (ms * 1e-3),
             "pair_solves_per_sec": P / (ms * 1e-3), "pose_err_vs_gt": err,
             "roofline": {"bound": "hbm", "kernel": "picp_batch_kernel<true,false>", "achieved": gbs, "peak": HBM_PEAK_GBS,
@@ -769,15 +787,22 @@ def cpu_leg(fp, pipe, args):
         n_thr = len(os.sched_getaffinity(0))
     except AttributeError:
         n_thr = os.cpu_count() or 1
-    n_thr = max(1, min(n_thr, 16))                 # a 1-GPU box's CPU share is 16 cores
-
-    def mt():
-        res["mt"] = o.picp_solve_mt(cam, fp["model"], fp["cur_pts"], corr, args.iters, n_thr, 10000.0)
-    t_mt, mt_reps = _median_time(mt, reps=int(max(5, min(200, 0.3 * args.cpu_seconds / max(t_one / n_thr, 1e-6)))))
-    rm = res["mt"]
-    all_cores = {"value": args.iters / t_mt, "unit": "iter/s", "cores": rm["threads"], "repetitions": mt_reps,
-                 "kind": "port, OpenMP over contiguous chunks with per-thread H/b partials (the reference itself has no threading)",
-                 "pose_diff_vs_single_thread": float(np.abs(rm["T"] - r["T"]).max())}
+    n_aff = max(1, n_thr)
+    # every core of the affinity mask ("all_cores"), and the thread counts below it that a 50k-point round can actually
+    # feed (a round is 1 MB of input: beyond a few dozen threads the per-round fork / join outweighs the work)
+    sweep = []
+    for n_thr in sorted({t for t in (16, 64, n_aff) if t <= n_aff}):
+        def mt():
+            res["mt"] = o.picp_solve_mt(cam, fp["model"], fp["cur_pts"], corr, args.iters, n_thr, 10000.0)
+        budget = 0.3 * args.cpu_seconds / max(1, len({t for t in (16, 64, n_aff) if t <= n_aff}))
+        t_mt, mt_reps = _median_time(mt, reps=int(max(5, min(200, budget / max(t_one / min(n_thr, 16), 1e-6)))))
+        rm = res["mt"]
+        sweep.append({"value": args.iters / t_mt, "unit": "iter/s", "cores": rm["threads"], "repetitions": mt_reps,
+                      "pose_diff_vs_single_thread": float(np.abs(rm["T"] - r["T"]).max())})
+    all_cores = dict(sweep[-1], kind="port, OpenMP over contiguous chunks with per-thread H/b partials (the reference itself has "
+                                     "no threading); cores = every core of this process's affinity mask",
+                     threads_sweep=[{"threads": e["cores"], "value": e["value"]} for e in sweep],
+                     best={"threads": max(sweep, key=lambda e: e["value"])["cores"], "value": max(e["value"] for e in sweep)})
     # separately labelled: the same C sources compiled -march=native on this host
     try:
         on = Oracle(32, library=native_lib())

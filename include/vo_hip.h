@@ -117,7 +117,8 @@ int vo_project_points_dev(vo_ctx *ctx, int rows, int cols, int z_near, int z_far
                           float *d_out_uv, int *d_counts);
 
 /* ---- PICPSolver (picp_solver.h:18-79, picp_solver.cpp) ----------------- */
-/* ctor: threshold 1000, damping 1, min inliers 0 (picp_solver.cpp:6-14) */
+/* ctor: threshold 1000, damping 1, min inliers 0 (picp_solver.cpp:6-14).  Damping has no setter -- as in the reference -- and the
+ * default mode's unpivoted 6x6 solve relies on it: H = sum(lambda J^T J) + 1 * I is positive definite whatever the frame holds. */
 int vo_picp_create(vo_ctx *ctx, vo_picp **out);
 int vo_picp_destroy(vo_picp *s);
 /* init(camera, world, image) (picp_solver.cpp:16-23).  The reference stores
@@ -235,7 +236,8 @@ int vo_match_appearances_dev(vo_ctx *ctx, const float *d_a1, int n1, const float
  * offsets/n_total tell the caller how much room to bring.  Unlike the matcher the roles are explicit: the
  * first set is searched whatever the sizes.  The approximate modes of the reference (fastSearch,
  * bestMatchFast: descend one side of each PCA split) depend on its tree: vo_kdtree_* below; their
- * answers are subsets of this call's / of vo_match_appearances'. */
+ * answers are subsets of this call's / of vo_match_appearances'.  Sets of up to 1 835 008 points each (1024 slices of the
+ * level-1 sort); the device arrays on 8-byte boundaries like every device entry point. */
 int vo_radius_search(vo_ctx *ctx, const float *tree_app, int n_tree, const float *query_app, int n_q,
                      float radius, int32_t *offsets, int32_t *indices, int capacity, int *n_total);
 /* device form: d_offsets[n_q + 1]; d_offsets[n_q] = hits found (also when > capacity: the surplus is dropped) */

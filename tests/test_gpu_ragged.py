@@ -170,3 +170,35 @@ def test_ragged_argument_checks_and_clamping(vo, ctx):
     assert sorted(out[0].tolist()) == [[i, 39 - i] for i in range(40)]
     for d in (d_a, d_b, d_out, d_cnt, d_n, d_big):
         ctx.free(d)
+
+
+def test_sizes_beyond_the_capacities_are_clamped_the_same_way_everywhere(vo, ctx, o32):
+    """unequal capacities (cap1 = 40, cap2 = 90) and a per-frame size beyond its capacity (n1 = 120 > cap1): the search and
+    the output compaction must clamp alike -- n1 becomes 40, so set 2 (n2 = 60) is the tree -- or the (ref, cur) columns of the
+    frame come out swapped.  Full scan and, with larger sets, the sorted search."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    for cap1, cap2, sizes in ((40, 90, [(120, 60), (40, 90), (7, 3), (-5, 20)]), (2500, 5200, [(9000, 3000), (2500, 5200), (100, 2600), (2000, 1500)])):
+        F = len(sizes)
+        a1 = rng.uniform(-1, 1, (F, cap1, 10)).astype(np.float32); a2 = rng.uniform(-1, 1, (F, cap2, 10)).astype(np.float32)
+        for f in range(F):                                   # copies, so that there is something to match
+            k = min(cap1, cap2) // 2
+            a2[f, :k] = a1[f, rng.permutation(cap1)[:k]]
+        n1 = np.array([s[0] for s in sizes], np.int32); n2 = np.array([s[1] for s in sizes], np.int32)
+        q = min(cap1, cap2)
+        d = [ctx.to_device(x) for x in (a1, a2, n1, n2)]
+        d_out, d_cnt = ctx.alloc(F * q * 8), ctx.alloc(F * 4)
+        try:
+            rc = ctx.lib.vo_match_appearances_batch_dev(ctx.h, C.c_int(F), C.c_void_p(d[0]), C.c_int(cap1), C.c_void_p(d[2]), C.c_void_p(d[1]),
+                                                        C.c_int(cap2), C.c_void_p(d[3]), C.c_float(0.1), C.c_void_p(d_out), C.c_void_p(d_cnt))
+            assert rc == 0, ctx.lib.vo_last_error()
+            cnt = np.zeros(F, np.int32); ctx.d2h(cnt, d_cnt)
+            out = np.zeros((F, q, 2), np.int32); ctx.d2h(out, d_out)
+        finally:
+            for x in d + [d_out, d_cnt]:
+                ctx.free(x)
+        for f in range(F):
+            m1, m2 = int(np.clip(n1[f], 0, cap1)), int(np.clip(n2[f], 0, cap2))
+            exp = o32.match(a1[f, :m1], a2[f, :m2])
+            assert np.array_equal(out[f, : cnt[f]], exp), (cap1, cap2, f)
+        assert cnt.sum() > 0

@@ -244,3 +244,33 @@ def test_degenerate_sequences_follow_the_reference_loop(vo, ctx, o32, case):
     sp.run()
     assert np.array_equal(sp.counts(), counts) and np.array_equal(sp.trajectory(), traj, equal_nan=True)
     sp.close()
+
+
+@pytest.mark.parametrize("case", ["empty5", "foreign5", "tiny5"])
+def test_degenerate_sequences_in_the_default_arithmetic(vo, ctx, o32, case):
+    """The same lost-track sequences through the DEFAULT solver mode, whose 6x6 solve does not pivot: with no usable
+    correspondence H is the damping alone (the identity: damping is fixed at 1 like the reference's, picp_solver.cpp:10 --
+    there is no setter on either side), with three it is rank-deficient plus the identity -- positive definite either way,
+    which is all the unpivoted factorisation needs.  Up to the first frame that loses track the chain must follow the
+    reference-order one (counts equal, poses within 1e-3); from there on NaN must appear where it appears there."""
+    seq = vo.synth.sequence(seed=3100, n_frames=12, n_visible=600)
+    fr = seq["frames"]
+    if case == "empty5":
+        fr[5] = dict(ids=np.zeros(0, np.int64), pts=np.zeros((0, 2), np.float32), app=np.zeros((0, 10), np.float32))
+    if case == "foreign5":
+        fr[5] = dict(ids=fr[5]["ids"], pts=fr[5]["pts"], app=np.random.default_rng(1).uniform(5, 6, fr[5]["app"].shape).astype(np.float32))
+    if case == "tiny5":
+        fr[5] = dict(ids=fr[5]["ids"][:3], pts=fr[5]["pts"][:3].copy(), app=fr[5]["app"][:3].copy())
+    out = {}
+    for exact in (True, False):
+        sp = vo.SequencePipeline(ctx, seq, n_iters=30, exact=exact)
+        sp.run()
+        out[exact] = (sp.trajectory(), sp.counts())
+        sp.close()
+    (te, ce), (tf, cf) = out[True], out[False]
+    assert np.array_equal(ce[:6], cf[:6])                                   # up to and including the degenerate frame: same counts
+    assert np.abs(te[:5] - tf[:5]).max() < 1e-3                              # the healthy part of the chain
+    assert np.isfinite(tf[5]).all() and np.isfinite(te[5]).all()             # the degenerate frame itself: a finite pose in both
+    if case in ("empty5", "foreign5"):
+        assert np.array_equal(tf[5], np.eye(4, dtype=np.float32))            # no correspondence: dx = 0, the pose stays the identity
+    assert np.array_equal(np.isnan(tf).any(axis=(1, 2)), np.isnan(te).any(axis=(1, 2)))     # poisoned frames: the same ones

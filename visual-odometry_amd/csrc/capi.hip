@@ -1221,6 +1221,7 @@ int vo_radius_search_dev(vo_ctx* c, const float* d_tree, int n_tree, const float
   VO_REQUIRE(n_tree >= 0 && n_q >= 0 && capacity >= 0, "negative count");
   VO_REQUIRE((n_tree == 0 || d_tree) && (n_q == 0 || d_qry) && (capacity == 0 || d_indices), "null array");
   VO_REQUIRE(match_cells_supported(n_tree, n_q), "more than 1 835 008 points in one set");
+  VO_REQUIRE(aligned8(d_tree, d_qry), "device array not on an 8-byte boundary");       // (the cell-hash path loads rows as 8-byte words)
   if (int r = set_device(c)) return r;
   void* ws = nullptr;
   if (n_tree > 0 && n_q > 0) if (int r = match_workspace(c, 3, n_tree, n_q, 1, &ws)) return r;

@@ -690,6 +690,7 @@ struct MatchOutArgs {
   int* counts;
   size_t best_stride, out_stride, counts_stride;   // per frame (blockIdx.y)
   const int* d_n1; const int* d_n2;                // ragged frames: per-frame set sizes (null: nq / tree_is_1 for all)
+  int cap1, cap2;                                  // ragged frames: capacities of the two sets (sizes are clamped to them, like the search kernels do)
 };
 
 // the frame's query count and roles: the larger set is the tree, a1 on ties (vo_complete.cpp:15-20)
@@ -697,7 +698,9 @@ __device__ __forceinline__ void match_out_frame(const MatchOutArgs& a, int& nq, 
   nq = a.nq; tree_is_1 = a.tree_is_1;
   if (a.d_n1) {
     int n1 = a.d_n1[blockIdx.y], n2 = a.d_n2[blockIdx.y];
-    n1 = n1 < 0 ? 0 : n1; n2 = n2 < 0 ? 0 : n2;
+    // the SAME clamp as match_kernel<RAGGED> / cell_sets: otherwise an out-of-contract size (n1 > cap1) could pick another
+    // tree here than the search did, and the (ref, cur) columns would come out swapped
+    n1 = n1 < 0 ? 0 : (n1 > a.cap1 ? a.cap1 : n1); n2 = n2 < 0 ? 0 : (n2 > a.cap2 ? a.cap2 : n2);
     tree_is_1 = n1 >= n2;
     const int q = tree_is_1 ? n2 : n1;
     nq = q < a.nq ? q : a.nq;
@@ -762,10 +765,10 @@ __global__ __launch_bounds__(CB) void match_compact_small_kernel(MatchOutArgs a,
 
 hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best, int nq, int tree_is_1,
                                 int32_t* d_out, int* d_n_out, int* d_scratch, int n_frames, size_t best_stride,
-                                size_t out_stride, const int* d_n1, const int* d_n2) {
+                                size_t out_stride, const int* d_n1, const int* d_n2, int cap1, int cap2) {
   const int nb = (nq + CB - 1) / CB;
   const size_t cs = n_frames > 1 ? compaction_scratch_ints(nq) : 0;
-  MatchOutArgs a{d_best, nq, tree_is_1, d_out, d_scratch, best_stride, n_frames > 1 ? out_stride : 0, cs, d_n1, d_n2};
+  MatchOutArgs a{d_best, nq, tree_is_1, d_out, d_scratch, best_stride, n_frames > 1 ? out_stride : 0, cs, d_n1, d_n2, cap1, cap2};
   if (nq <= SMALL_N) {
     hipLaunchKernelGGL(match_compact_small_kernel, dim3(1, n_frames), dim3(CB), 0, st, a, d_n_out);
     return hipGetLastError();

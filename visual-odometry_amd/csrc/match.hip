@@ -33,7 +33,7 @@ namespace vo {
 
 hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best, int nq, int tree_is_1,
                                 int32_t* d_out, int* d_n_out, int* d_scratch, int n_frames, size_t best_stride,
-                                size_t out_stride, const int* d_n1, const int* d_n2);
+                                size_t out_stride, const int* d_n1, const int* d_n2, int cap1 = 0, int cap2 = 0);
 
 constexpr int MB = 256;       // threads per workgroup
 constexpr int QPT = 2;        // queries per thread (full scan)
@@ -1968,7 +1968,7 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_match_compact(st, d_best, q, 1, d_out_pairs, d_n_out, d_scratch, n_frames, (size_t)q, out_stride, d_n1, d_n2);
+    return launch_match_compact(st, d_best, q, 1, d_out_pairs, d_n_out, d_scratch, n_frames, (size_t)q, out_stride, d_n1, d_n2, n1, n2);
   }
   const int tree_is_1 = n1 >= n2;                 // vo_complete.cpp:15-20 (ties: a1 is the tree)
   const float* tree = tree_is_1 ? d_a1 : d_a2;

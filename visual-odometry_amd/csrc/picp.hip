@@ -67,49 +67,15 @@ __device__ __forceinline__ float block_reduce_acc(float acc[NACC], float* s_red)
   return out;
 }
 
-// (rounds 1-2; -DVO_REDUCE_LDS builds it for A/B -- round 3 uses block_reduce_quad below: 4.70 -> 4.59 us per round)
-// Workgroup reduction of the round kernel (256 threads) through LDS only: on
-// the critical path (one wave per SIMD, ~5 cycles per issued instruction) the
-// instruction count matters more than LDS bandwidth.  Every thread stores its
-// 30 accumulators as eight 16-B writes (row stride 36 floats: conflict-free),
-// thread (slot = tid%32, part = tid/32) adds up the 32 rows of its part
-// (conflict-free 4-B reads), a second 8-row stage finishes: ~90 instructions
-// instead of ~180 for DPP + LDS.   s_acc: 256*36 floats, s_part: 8*32 floats.
-// Returns the sum of slot tid in threads 0..31 (fixed order).
+// Workgroup reduction of the round kernel (256 threads): rows of ACC_STRIDE floats in LDS (conflict-free 16-byte accesses),
+// a first stage over parts of rows, a second one over the parts.  (Rounds 1-2 stored all 30 accumulators of every thread:
+// git history, block_reduce_lds256.)
 constexpr int ACC_STRIDE = 36;
 constexpr int PICP_PARTS = PICP_BLOCK / 32;          // 32-row parts of the first reduction stage
 constexpr int PICP_GROUPS = PICP_BLOCK / 8;          // row groups of the partial-row fetch (8 threads per 128-B row)
 constexpr int STG_STRIDE = PICP_GROUPS + 4;          // floats per slot of the transposed staging (conflict-free 16-B reads)
 constexpr int PICP_SACC = PICP_BLOCK * ACC_STRIDE > 32 * STG_STRIDE ? PICP_BLOCK * ACC_STRIDE : 32 * STG_STRIDE;
-__device__ __forceinline__ float block_reduce_lds256(const float acc[NACC], float* s_acc, float* s_part) {
-  const int tid = threadIdx.x;
-  float4* row = reinterpret_cast<float4*>(s_acc + tid * ACC_STRIDE);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    float4 v;
-    v.x = acc[4 * q + 0];
-    v.y = acc[4 * q + 1];
-    v.z = (4 * q + 2 < NACC) ? acc[(4 * q + 2) < NACC ? 4 * q + 2 : 0] : 0.f;
-    v.w = (4 * q + 3 < NACC) ? acc[(4 * q + 3) < NACC ? 4 * q + 3 : 0] : 0.f;
-    row[q] = v;
-  }
-  __syncthreads();
-  const int slot = tid & 31, part = tid >> 5;
-  const float* src = s_acc + (part * 32) * ACC_STRIDE + slot;
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < 32; ++j) s += src[j * ACC_STRIDE];
-  s_part[part * 32 + slot] = s;
-  __syncthreads();
-  float out = 0.f;
-  if (tid < 32) {
-#pragma unroll
-    for (int g = 0; g < PICP_PARTS; ++g) out += s_part[g * 32 + tid];
-  }
-  return out;
-}
-
-// The same reduction with a quad pre-reduction in registers: two DPP adds per accumulator leave every quad's sum in its four
+// The reduction with a quad pre-reduction in registers: two DPP adds per accumulator leave every quad's sum in its four
 // lanes, lane q of the quad then stores accumulators 8q .. 8q+7 -- TWO 16-byte LDS writes per lane instead of eight (a
 // ds_write_b128 costs ~13 cycles of the wave's LDS path whatever it holds, and the four waves share that path) -- and the
 // first stage adds 8 rows per part instead of 32.  Rows: one per quad (PICP_BLOCK / 4), stride ACC_STRIDE.  Fixed order:
@@ -182,51 +148,9 @@ __device__ __forceinline__ void store_pose12(float* p, const Pose& P) {
   for (int i = 0; i < 3; ++i) p[9 + i] = P.t[i];
 }
 
-// ---- tail of oneRound (picp_solver.cpp:102-110), Eigen's pivot order (rounds 1-2; -DVO_TAIL_SERIAL builds it for A/B) ----
-// Stage 1 (any 42 threads, before a workgroup barrier): expand the reduced
-// accumulators into the full symmetric H (+damping) and -b in LDS.
-// Stage 2 (all 64 lanes of ONE wave, redundantly and identically, so nothing
-// diverges): pivot order from the diagonal, gather of P H P^T from LDS,
-// swap-free LDLT, dx.  The three sin/cos pairs are evaluated by three lanes at
-// once and shared through v_readlane.  Lane 0 publishes the new pose.
-//   s_sys: 48 floats of LDS: [0,36) H row-major, [36,42) -b, [42,48) scratch.
-__device__ __forceinline__ void picp_tail_expand(const float* s_tot, float* s_sys, float damping,
-                                                 float* H_out, float* b_out) {
-  const int t = threadIdx.x;
-  if (t < 36) {
-    const int r = t / 6, c = t - 6 * r;
-    const int lo = r < c ? r : c, hi = r < c ? c : r;
-    const int idx = (13 * lo - lo * lo) / 2 + (hi - lo);   // row-major upper triangle
-    float v = s_tot[idx];
-    if (r == c) v += 1.f * damping;                        // picp_solver.cpp:102
-    s_sys[t] = v;
-    if (H_out) H_out[r + 6 * c] = v;
-  } else if (t < 42) {
-    const float bv = s_tot[21 + (t - 36)];
-    s_sys[t] = -bv;                                        // picp_solver.cpp:109 solve(-b)
-    if (b_out) b_out[t - 36] = bv;
-  }
-}
-
-__device__ __forceinline__ Pose picp_tail_wave(float* s_sys, const Pose& T) {
-  float dx[6];
-  ldlt6_solve_perm(s_sys, s_sys + 36, s_sys + 42, dx);
-  const int lane = threadIdx.x & 63;
-  const int m = lane % 3;
-  const float ang = m == 0 ? dx[3] : (m == 1 ? dx[4] : dx[5]);
-  float sn, cs;
-  sincosf(ang, &sn, &cs);
-  const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 0));
-  const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 0));
-  const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 1));
-  const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 1));
-  const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 2));
-  const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 2));
-  const Pose dT = v2t_from_sincos(dx, sx, cx, sy, cy, sz, cz);
-  return pose_mul(dT, T);                                  // picp_solver.cpp:110
-}
-
-// ---- the tail without pivoting and without LDS (round 3, the default) -------------------------------------------
+// ---- tail of oneRound (picp_solver.cpp:102-110) without pivoting and without LDS ------------------------------------
+// (Rounds 1-2 followed Eigen's pivot order through LDS -- picp_tail_expand / picp_tail_wave, git history; the reference-order
+// mode still does: picp_update_t<true>.)
 // H = sum(lambda J^T J) + damping * I is symmetric positive definite by construction, and an LDL^T of such a matrix is
 // backward stable in ANY pivot order (no element growth: Higham, Accuracy and Stability, thm 10.3) -- Eigen pivots because
 // its LDLT also serves semidefinite and indefinite matrices.  The fast mode therefore eliminates in the natural order: no
@@ -392,9 +316,6 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
   }
   __shared__ __attribute__((aligned(16))) float s_acc[PICP_SACC];   // also the staging of the partial rows
   __shared__ float s_part[PICP_PARTS * 32];
-#ifdef VO_TAIL_SERIAL
-  __shared__ float s_sys[PICP_BLOCK / 64][48];
-#endif
   __shared__ float s_stat[4];
   const int tid = threadIdx.x;
   VO_STAMP(0);
@@ -411,23 +332,12 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
   // with the partial rows, as VECTOR loads: lane l fetches the column of the old pose it will multiply by in the tail
   // (picp_tail_direct: entries 3c .. 3c+2 of the 12 floats, c = l / 3 clamped to 3).
   float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f;
-#ifdef VO_TAIL_SERIAL
-  typedef float f4v __attribute__((ext_vector_type(4)));
-  f4v pz0 = {0.f, 0.f, 0.f, 0.f}, pz1 = pz0, pz2 = pz0;
-  if (PRE) {
-    int lane_zero;                                                     // 0, but opaque to the compiler: keeps the
-    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));                 // address in a VGPR, hence a vector load
-    const f4v* pp = reinterpret_cast<const f4v*>(S->pose[(it - 1) & 1]) + lane_zero;
-    pz0 = pp[0]; pz1 = pp[1]; pz2 = pp[2];
-  }
-#else
   if (PRE) {
     const int l = tid & 63;
     const int c3 = l < 3 ? 0 : (l < 6 ? 3 : (l < 9 ? 6 : 9));
     const float* pp = S->pose[(it - 1) & 1] + c3;
     pb0 = pp[0]; pb1 = pp[1]; pb2 = pp[2];
   }
-#endif
   if (PRE) {
     const int nb_pad = (nb + 255) & ~255;
     const float* prev = partials + (size_t)((it - 1) & 1) * nb_pad * PICP_PSTRIDE;
@@ -484,9 +394,6 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     // (+damping on the diagonal, picp_solver.cpp:102), lanes 36..41 -b, lanes 42..44 the
     // statistics.  Fixed order => every wave of every workgroup gets the same bits.
     const int wave = tid >> 6, lane = tid & 63;
-#ifdef VO_TAIL_SERIAL
-    float* sys = s_sys[wave];
-#endif
     float val = 0.f;                                         // this lane's entry of the system (picp_tail_direct)
     if (lane < 45) {
       int slot;
@@ -513,24 +420,9 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
         s_stat[lane - 42] = tsum;
       }
     }
-#ifdef VO_TAIL_SERIAL
-    if (lane < 42) sys[lane] = val;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
     VO_STAMP(2);
     {
-#ifdef VO_TAIL_SERIAL
-      Pose Tprev;
-      Tprev.R[0] = pz0.x; Tprev.R[1] = pz0.y; Tprev.R[2] = pz0.z; Tprev.R[3] = pz0.w;
-      Tprev.R[4] = pz1.x; Tprev.R[5] = pz1.y; Tprev.R[6] = pz1.z; Tprev.R[7] = pz1.w;
-      Tprev.R[8] = pz2.x; Tprev.t[0] = pz2.y; Tprev.t[1] = pz2.z; Tprev.t[2] = pz2.w;
-      const Pose Told = uniform_pose(Tprev);
-      const Pose Tn = picp_tail_wave(sys, Told);
-#else
       const Pose Tn = picp_tail_direct(val, pb0, pb1, pb2);
-#endif
       if (tid == 0 && blockIdx.x == 0) {
         store_pose12(S->pose[FINISH ? 0 : (it & 1)], Tn);
         if (FINISH) {
@@ -572,11 +464,7 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     picp_accumulate_t<PINHOLE, KEEP>(cam, T, thr, cx, cy, cz, cu, cv, acc);
   }
   VO_STAMP(4);
-#ifdef VO_REDUCE_LDS
-  const float tot = block_reduce_lds256(acc, s_acc, s_part);
-#else
   const float tot = block_reduce_quad(acc, s_acc, s_part);
-#endif
   VO_STAMP(5);
   if (tid < PICP_PSTRIDE) {
     float o = tot;   // slot 29 (inlier count) is an exact integer in float: < 2^24 correspondences
@@ -642,9 +530,6 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_small_kernel(const PicpParams
   __shared__ __attribute__((aligned(16))) float s_acc[PICP_SACC];
   __shared__ float s_part[PICP_PARTS * 32];
   __shared__ float s_tot[32];
-#ifdef VO_TAIL_SERIAL
-  __shared__ float s_sys[PICP_BLOCK / 64][48];
-#endif
   __shared__ float s_stat[4];
   const PackedCorr pk{const_cast<float*>(pk_base), pk_cap};
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -662,17 +547,10 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_small_kernel(const PicpParams
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
     if (have) picp_accumulate_t<PINHOLE, KEEP>(cam, T, thr, x, y, z, u, v, acc);
-#ifdef VO_REDUCE_LDS
-    const float tot = block_reduce_lds256(acc, s_acc, s_part);
-#else
     const float tot = block_reduce_quad(acc, s_acc, s_part);
-#endif
     if (tid < 32) s_tot[tid] = tid < NACC ? tot : 0.f;
     __syncthreads();
     // every wave builds the system and solves it on its own (as step (4) of picp_round_body)
-#ifdef VO_TAIL_SERIAL
-    float* sys = s_sys[wave];
-#endif
     float val = 0.f;
     if (lane < 45) {
       int slot;
@@ -696,17 +574,9 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_small_kernel(const PicpParams
         s_stat[lane - 42] = tsum;
       }
     }
-#ifdef VO_TAIL_SERIAL
-    if (lane < 42) sys[lane] = val;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const Pose Tn = picp_tail_wave(sys, T);
-#else
     float b0, b1, b2;
     pose_lane_operands(T, b0, b1, b2);
     const Pose Tn = picp_tail_direct(val, b0, b1, b2);
-#endif
     if (last && tid == 0) {
       store_pose12(S->pose[0], Tn);
       float T16[16];
@@ -799,19 +669,12 @@ __global__ void picp_batch_T0_out_kernel(BatchArgs a) {
 // The rotation lives in scalar registers; the translation is kept in three VECTOR registers: pc = fma(R, w, t) may read one
 // scalar operand only (constant bus), so a scalar t would cost a v_mov per component and correspondence in a loop that
 // is bound by VALU issue.
-#ifdef VO_BATCH_T_SCALAR
-#define VO_BATCH_T_VGPR(T)
-#else
 #define VO_BATCH_T_VGPR(T) asm volatile("" : "+v"((T).t[0]), "+v"((T).t[1]), "+v"((T).t[2]))
-#endif
 
 template <bool PINHOLE, bool KEEP>
 __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs a) {
   __shared__ float s_red[(PICP_BATCH_BLOCK / 64) * 4 * 32];
   __shared__ float s_tot[32];
-#ifdef VO_TAIL_SERIAL
-  __shared__ float s_sys[48];
-#endif
   __shared__ float s_pose[12];
   const int tid = threadIdx.x;
   const int p = blockIdx.x;
@@ -913,18 +776,10 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
     const float tot = block_reduce_acc<PICP_BATCH_BLOCK / 64>(acc, s_red);
     if (tid < 32) s_tot[tid] = tot;
     __syncthreads();
-#ifdef VO_TAIL_SERIAL
-    picp_tail_expand(s_tot, s_sys, a.damping, nullptr, nullptr);
-    __syncthreads();
-#endif
     if (tid < 64) {
-#ifdef VO_TAIL_SERIAL
-      const Pose Tn = picp_tail_wave(s_sys, T);
-#else
       float b0, b1, b2;
       pose_lane_operands(T, b0, b1, b2);
       const Pose Tn = picp_tail_direct(picp_lane_value(s_tot, a.damping, nullptr, nullptr), b0, b1, b2);
-#endif
       if (tid == 0) {
         store_pose12(s_pose, Tn);
         if (it == a.n_iters - 1 && a.stats_out) {

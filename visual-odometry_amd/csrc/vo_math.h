@@ -29,9 +29,8 @@ VO_HD float vo_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); 
 
 // 1/z of the default-mode linearisation: hardware reciprocal + one Newton step + the special-case fixup (0, inf, nan
 // as the IEEE quotient gives them) -- 4 instructions for the 10 of the correctly rounded quotient, at most 1 ulp from it
-// (-DVO_IEEE_RCP: the quotient).
 VO_HD float vo_recip_z(float z) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(VO_IEEE_RCP)
+#if defined(__HIP_DEVICE_COMPILE__)
   const float r = __builtin_amdgcn_rcpf(z);
   const float e = __builtin_fmaf(-z, r, 1.f);
   return __builtin_amdgcn_div_fixupf(__builtin_fmaf(r, e, r), z, 1.f);
@@ -182,7 +181,7 @@ VO_HD bool is_pinhole(const float K[9]) {
 // the depth gates, <= 3.7 for the image gates, <= 276 ulp of thr for chi^2 (= e0^2 + e1^2: the pixel error of (u, v) times
 // 2 |e|, 3e-5 relative at thr = 100); the test holds the bands 4 / 8 / 1024.  Taking the decisions on reference-order
 // values costs the batched solver 20 % (126 against 99 instructions per correspondence); a guard that
-// re-evaluates only near-gate correspondences was measured too -- its detection arithmetic alone (VO_GUARD_PROBE below)
+// re-evaluates only near-gate correspondences was measured too -- its detection arithmetic alone (commit "Decisions at the gates under rounding", -DVO_GUARD_PROBE)
 // costs 9 % -- and not kept; sums: H_rc += J0r*J0c ; H_rc += J1r*J1c (lambda, when it is not 1, folded into the left factor)
 // instead of (J0r*J0c + J1r*J1c)*lambda followed by an add.  The batched solver is bound by VALU issue, and this form
 // is ~20 instructions per correspondence shorter than the unfused one.  Reference-order arithmetic, decisions
@@ -221,22 +220,7 @@ VO_HD void picp_accumulate_t(const CamK& cam, const Pose& T, float thr, float wx
   }
   float lambda = inl ? 1.f : 0.f;
   if (keep_outliers) lambda = outl ? sqrtf(thr / chi) : lambda;                 // :80, :90
-#ifdef VO_GUARD_PROBE
-  // TIMING PROBE ONLY (never shipped): the detection half of a rigorous decision guard -- margins of the depth and image gates
-  // folded with min / min3, a per-lane slack for (u, v) from |1/z|, the chi^2 margin against a slack from |e0| + |e1| -- with
-  // placeholder per-problem constants; a lane found near a gate is dropped so that the arithmetic stays live.
-  bool use;
-  {
-    const float dz = fminf(pc2 - (float)cam.z_near, (float)cam.z_far - pc2);
-    const float duv = fminf(fminf(u, (float)(cam.cols - 1) - u), fminf(v, (float)(cam.rows - 1) - v));
-    const float s_lane = vo_fma(fabsf(iz), 0.02f, 2e-4f);
-    const float s_chi = vo_fma(fabsf(e0) + fabsf(e1), s_lane + s_lane, 4e-6f * chi);
-    const bool near = (fabsf(dz) <= 1e-5f) | (pc2 < (float)cam.z_far * 0.0078125f) | (fabsf(duv) <= s_lane) | (fabsf(chi - thr) <= s_chi);
-    use = lambda != 0.f && !near;
-  }
-#else
   const bool use = lambda != 0.f;
-#endif
   // Jp*K (:39-51): row 0 = iz * (K row 0 - u * K row 2), row 1 = iz * (K row 1 - v * K row 2) -- the reference's
   // iz*K_0c + (-ph0*iz^2)*K_2c with u = ph0*iz taken out.  A term that must not contribute has the generators of its
   // Jacobian zeroed, so that no inf/nan of a rejected projection reaches an accumulator.
