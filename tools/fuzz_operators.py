@@ -25,7 +25,7 @@ while time.time() < t_end:
     radius = float(rng.choice([0.1, 0.03, 0.3]))
     exp_m = o32.match(fp["ref_app"], fp["cur_app"], radius)
     ok = True
-    for mode in (1, 2, 3):
+    for mode in (1, 2, 3, 4, 5):              # 4 / 5: the exact-duplicate pass first, then 2 / 3 for the queries it leaves open
         ctx.lib.vo_match_set_mode(ctx.h, mode)
         if not np.array_equal(vo.compute_correspondences_images(fp["ref_app"], fp["cur_app"], radius, ctx=ctx), exp_m): ok = False; print("MATCH FAIL", n, seed, mode, radius)
     ctx.lib.vo_match_set_mode(ctx.h, 0)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised campaign for the calls that take frames of DIFFERENT sizes (vo_match_appearances_batch_dev, vo_frames_batch_ragged_dev): random
 numbers of frames, per-frame sizes from 0 to a few thousand points with either image the larger one, uniform / clustered / duplicated
-appearances, matcher mode automatic / full scan / cell hash, radii 0.03..0.3 -- every frame's pairs against the oracle; the whole loop body
+appearances, matcher mode automatic / full scan / cell hash / exact-duplicate pass + cell hash, radii 0.03..0.3 -- every frame's pairs against the oracle; the whole loop body
 (match -> join -> rounds in reference-order arithmetic -> triangulate) against the oracle frame by frame, bit for bit.
 usage (GPU box): tools/fuzz_ragged.py [seed] [seconds]"""
 import os, sys, time
@@ -34,7 +34,7 @@ while time.time() < t_end:
     big = rng.integers(0, 5) == 0
     sizes = [int(rng.choice([0, 1, rng.integers(2, 60), rng.integers(60, 900), rng.integers(900, 6000 if big else 2500)])) for _ in range(F)]
     radius = float(rng.choice([0.1, 0.03, 0.3]))
-    mode = int(rng.choice([0, 1, 3]))
+    mode = int(rng.choice([0, 1, 3, 5]))       # 5: the exact-duplicate pass in front of the cell-hash search (what 0 picks from 8 large frames on)
     ctx.lib.vo_match_set_mode(ctx.h, mode)
     if rng.integers(0, 3) < 2:
         sets = [appearance_sets(n, int(rng.integers(0, 3))) for n in sizes]

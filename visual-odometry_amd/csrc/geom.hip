@@ -691,7 +691,11 @@ struct MatchOutArgs {
   size_t best_stride, out_stride, counts_stride;   // per frame (blockIdx.y)
   const int* d_n1; const int* d_n2;                // ragged frames: per-frame set sizes (null: nq / tree_is_1 for all)
   int cap1, cap2;                                  // ragged frames: capacities of the two sets (sizes are clamped to them, like the search kernels do)
+  const int* unres;                                // hash-first (or null): per-frame count of queries the exact-duplicate pass left open.  A frame
+                                                   //   with none has every pair at its final slot already (the lookup wrote pair q at slot q): the
+                                                   //   counting pass reports full blocks without reading a key, the writing pass returns
 };
+extern const int SMALL_COMPACT = SMALL_N;
 
 // the frame's query count and roles: the larger set is the tree, a1 on ties (vo_complete.cpp:15-20)
 __device__ __forceinline__ void match_out_frame(const MatchOutArgs& a, int& nq, int& tree_is_1) {
@@ -713,6 +717,11 @@ __global__ __launch_bounds__(CB) void match_count_kernel(MatchOutArgs a) {
   const int q = blockIdx.x * CB + threadIdx.x;
   int nq, tree_is_1;
   match_out_frame(a, nq, tree_is_1);
+  if (a.unres && a.unres[blockIdx.y] == 0) {              // every query matched: this block's count is its number of queries
+    const int left = nq - (int)blockIdx.x * CB;
+    if (threadIdx.x == 0) a.counts[blockIdx.y * a.counts_stride + blockIdx.x] = left < 0 ? 0 : (left > CB ? CB : left);
+    return;
+  }
   const bool ok = q < nq && (unsigned)(best[q] & 0xffffffffull) != 0xffffffffu;
   int total;
   block_rank(ok, s_wave, total);
@@ -724,6 +733,7 @@ __global__ __launch_bounds__(CB) void match_scatter_kernel(MatchOutArgs a) {
   const unsigned long long* best = a.best + blockIdx.y * a.best_stride;
   int32_t* out = a.out + 2 * blockIdx.y * a.out_stride;
   const int q = blockIdx.x * CB + threadIdx.x;
+  if (a.unres && a.unres[blockIdx.y] == 0) return;        // the lookup wrote every pair where it belongs
   int nq, tree_is_1;
   match_out_frame(a, nq, tree_is_1);
   unsigned idx = 0xffffffffu;
@@ -765,10 +775,10 @@ __global__ __launch_bounds__(CB) void match_compact_small_kernel(MatchOutArgs a,
 
 hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best, int nq, int tree_is_1,
                                 int32_t* d_out, int* d_n_out, int* d_scratch, int n_frames, size_t best_stride,
-                                size_t out_stride, const int* d_n1, const int* d_n2, int cap1, int cap2) {
+                                size_t out_stride, const int* d_n1, const int* d_n2, int cap1, int cap2, const int* d_unres) {
   const int nb = (nq + CB - 1) / CB;
   const size_t cs = n_frames > 1 ? compaction_scratch_ints(nq) : 0;
-  MatchOutArgs a{d_best, nq, tree_is_1, d_out, d_scratch, best_stride, n_frames > 1 ? out_stride : 0, cs, d_n1, d_n2, cap1, cap2};
+  MatchOutArgs a{d_best, nq, tree_is_1, d_out, d_scratch, best_stride, n_frames > 1 ? out_stride : 0, cs, d_n1, d_n2, cap1, cap2, d_unres};
   if (nq <= SMALL_N) {
     hipLaunchKernelGGL(match_compact_small_kernel, dim3(1, n_frames), dim3(CB), 0, st, a, d_n_out);
     return hipGetLastError();

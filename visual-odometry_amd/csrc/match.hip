@@ -33,7 +33,9 @@ namespace vo {
 
 hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best, int nq, int tree_is_1,
                                 int32_t* d_out, int* d_n_out, int* d_scratch, int n_frames, size_t best_stride,
-                                size_t out_stride, const int* d_n1, const int* d_n2, int cap1 = 0, int cap2 = 0);
+                                size_t out_stride, const int* d_n1, const int* d_n2, int cap1 = 0, int cap2 = 0,
+                                const int* d_unres = nullptr);
+extern const int SMALL_COMPACT;   // (geom.hip) up to this many items the compaction is one launch that reads every key: no frame is skipped
 
 constexpr int MB = 256;       // threads per workgroup
 constexpr int QPT = 2;        // queries per thread (full scan)
@@ -1522,6 +1524,9 @@ struct HashArgs {
   size_t hashes_stride;
   int* unres;                 // [n_frames] queries left open
   unsigned long long* best;
+  int32_t* out_pairs;         // the call's pair output (or null): the lookup writes pair j of a frame at slot j -- the final
+  size_t out_stride;          //   place when every query of the frame finds its copy (then the compaction has nothing to do)
+  int tree_is_1;              // roles of a call with one size for all frames (ragged frames: from the sizes)
   float r2;
   int n_frames, log2p, ib, qblocks, hblocks;   // parts = 1 << log2p; ib: index bits of a word (the tag takes the other 31 - ib)
 };
@@ -1794,12 +1799,16 @@ __global__ __launch_bounds__(256) void hash_probe_kernel(HashArgs a) {
   __syncthreads();
   int n_open = 0;
   unsigned long long* best = a.best + f * a.best_stride;
+  const bool tree_is_1 = a.d_n1 ? tree == a.tree + f * a.tree_stride : a.tree_is_1 != 0;      // (cell_sets swaps the sets when set 2 is the tree)
 #pragma unroll
   for (int u = 0; u < HJ_Q; ++u) {
     const bool live = j[u] < nq;
     const bool open = live && found[u] == 0xffffffffu;
     n_open += __popcll(__ballot(open));
     if (live) best[j[u]] = open ? (((unsigned long long)__float_as_uint(a.r2) << 32) | 0xffffffffull) : (unsigned long long)found[u];
+    // pair j at slot j: where it belongs when no query of the frame stays open (match_count / match_scatter then skip the frame)
+    if (live && !open && a.out_pairs)
+      reinterpret_cast<int2*>(a.out_pairs + 2 * f * a.out_stride)[j[u]] = tree_is_1 ? make_int2((int)found[u], j[u]) : make_int2(j[u], (int)found[u]);
   }
   if (lane == 0 && n_open > 0) atomicAdd(&s_open, n_open);
   __syncthreads();
@@ -1841,7 +1850,8 @@ size_t match_hash_workspace_bytes(int nt, int n_frames) { return hash_ws_bytes(n
 // (tree, qry, nt, nq): the two sets in their roles, or (set 1, set 2, capacities) with the per-frame sizes d_n1 / d_n2
 static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, const float* qry, int nq, float r2,
                                     unsigned long long* d_best, void* ws, int n_frames, size_t tree_stride, size_t qry_stride,
-                                    size_t best_stride, const int* d_n1, const int* d_n2, int** d_unres_out) {
+                                    size_t best_stride, const int* d_n1, const int* d_n2, int** d_unres_out, int32_t* d_out_pairs,
+                                    size_t out_stride, int tree_is_1) {
   HashPlan p;
   const int nt_plan = d_n1 ? (nt > nq ? nt : nq) : nt;
   if (!hash_plan(nt_plan, p)) return hipErrorInvalidValue;
@@ -1856,6 +1866,7 @@ static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, c
   a.hashes_stride = hash_rows_bytes(nt_plan) / sizeof(unsigned);
   a.hblocks = (nt_plan + 255) / 256;
   a.best = d_best; a.r2 = r2;
+  a.out_pairs = d_out_pairs; a.out_stride = out_stride; a.tree_is_1 = tree_is_1;
   a.n_frames = n_frames; a.log2p = p.log2p; a.ib = p.ib;
   const int q_cap = d_n1 ? (nt < nq ? nt : nq) : nq;       // ragged: either set may be the queries, never more than the smaller capacity
   a.qblocks = (q_cap + 256 * HJ_Q - 1) / (256 * HJ_Q);
@@ -1945,7 +1956,7 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
       void* ws = d_prune_ws;
       if (hash_first) {
         hipError_t eh = launch_hash_first(st, d_a1, n1, d_a2, n2, r2, d_best, d_prune_ws, n_frames, a1_stride, a2_stride, (size_t)q,
-                                          d_n1, d_n2, &d_unres);
+                                          d_n1, d_n2, &d_unres, q > SMALL_COMPACT ? d_out_pairs : nullptr, out_stride, 1);
         if (eh != hipSuccess) return eh;
         ws = static_cast<char*>(d_prune_ws) + hash_ws_bytes(n1 > n2 ? n1 : n2, n_frames);
       }
@@ -1968,7 +1979,7 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_match_compact(st, d_best, q, 1, d_out_pairs, d_n_out, d_scratch, n_frames, (size_t)q, out_stride, d_n1, d_n2, n1, n2);
+    return launch_match_compact(st, d_best, q, 1, d_out_pairs, d_n_out, d_scratch, n_frames, (size_t)q, out_stride, d_n1, d_n2, n1, n2, d_unres);
   }
   const int tree_is_1 = n1 >= n2;                 // vo_complete.cpp:15-20 (ties: a1 is the tree)
   const float* tree = tree_is_1 ? d_a1 : d_a2;
@@ -1981,7 +1992,8 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
   void* ws = d_prune_ws;
   if (hash_first && nq > 0 && nt > 0 && (variant == 2 || variant == 3)) {
     hipError_t eh = launch_hash_first(st, tree, nt, qry, nq, r2, d_best, d_prune_ws, n_frames, n_frames > 1 ? ts : 0,
-                                      n_frames > 1 ? qs : 0, best_stride, nullptr, nullptr, &d_unres);
+                                      n_frames > 1 ? qs : 0, best_stride, nullptr, nullptr, &d_unres,
+                                      nq > SMALL_COMPACT ? d_out_pairs : nullptr, n_frames > 1 ? out_stride : 0, tree_is_1);
     if (eh != hipSuccess) return eh;
     ws = static_cast<char*>(d_prune_ws) + hash_ws_bytes(nt, n_frames);
   }
@@ -2012,7 +2024,7 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_match_compact(st, d_best, nq, tree_is_1, d_out_pairs, d_n_out, d_scratch, n_frames, best_stride,
-                              out_stride, nullptr, nullptr);
+                              out_stride, nullptr, nullptr, 0, 0, d_unres);
 }
 
 hipError_t launch_match(hipStream_t st, const float* d_a1, int n1, const float* d_a2, int n2,
