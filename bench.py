@@ -325,6 +325,35 @@ def _valu_roofline(kernels, seconds, scope, pick=max):
                     "lanes active; lane_utilisation says how many are)"}
 
 
+MATCHER_CHAIN = ("vo::hash_rows_kernel", "vo::hash_table_kernel<14>", "vo::hash_probe_kernel<14>", "vo::cell_bounds_kernel",
+                 "vo::cell_place_kernel", "vo::cell_offsets_kernel", "vo::cell_fine_kernel", "vo::cell_search_kernel<0>",
+                 "vo::match_count_kernel", "vo::match_scatter_kernel")
+
+
+def _matcher_roofline(frames, points, seconds):
+    """The matcher stage of the batched call since round 4: row hashes, hash tables in LDS, one lookup per query (match.hip
+    "hash-first"); the cell-hash kernels behind it only touch frames with open queries (none in this workload).  It streams
+    every row once and gathers one tree row per query: HBM-side algorithmic bytes over time, the counter traffic of its
+    kernels beside it, and -- SURVEY 8(d) asked for the matcher's VALU share -- the executed VALU stream as before."""
+    alg = FRAME_ALG_BYTES["match"] * (points / 50000.0) * frames
+    out = {"bound": "hbm", "scope": f"matcher stage of {frames} frames (exact-duplicate pass + skipped cell-hash search + compaction), one call",
+           "kernels": list(MATCHER_CHAIN), "achieved": alg / seconds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": alg / seconds / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_call": alg, "traffic": None}
+    try:
+        c = json.load(open(_pmc_file()))["batched_frames_call"]
+        f = sum(v for k, v in c["FETCH_SIZE_KB_by_kernel"].items() if k in MATCHER_CHAIN)
+        w = sum(v for k, v in c["WRITE_SIZE_KB_by_kernel"].items() if k in MATCHER_CHAIN)
+        out["traffic"] = (f + w) * 1024.0
+        out["traffic_over_algorithmic"] = out["traffic"] / alg
+        out["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE of the stage's kernels as reported (8-byte coalesced and scattered loads: "
+                               "uncalibrated width; 8-byte coalesced streams read as half their bytes in tools/pmc_match.sh), from "
+                               + os.path.basename(_pmc_file()))
+    except (OSError, KeyError, ValueError, TypeError):
+        out["traffic_note"] = "no committed PMC summary of the batched call"
+    out["valu"] = _valu_roofline(MATCHER_CHAIN, seconds, "the same kernels")
+    return out
+
+
 def _pmc_frames_call():
     """HBM bytes of one whole vo_frames_batch_dev call (200 x 50k), summed over its kernels, from the same summary"""
     try:
@@ -450,9 +479,7 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
             "frames_per_sec": frames * world / (ms * 1e-3), "us_per_frame_per_gpu": ms * 1e3 / frames, "pose_err_vs_gt": err,
             "seeds": f"4000+p, p = {frames * rank}..{frames * rank + frames - 1} on this rank",
             "matcher_ms_per_batch": match_ms,
-            "matcher_roofline": _valu_roofline(("vo::cell_bounds_kernel", "vo::cell_place_kernel", "vo::cell_offsets_kernel", "vo::cell_fine_kernel",
-                                                "vo::cell_search_kernel<0>", "vo::match_count_kernel", "vo::match_scatter_kernel"),
-                                               match_ms * 1e-3, f"matcher chain of {frames} frames (cell-hash search), one call")
+            "matcher_roofline": _matcher_roofline(frames, args.points, match_ms * 1e-3)
             if (frames, args.points) == (200, 50000) else None,
             "roofline": {"bound": "hbm", "scope": "whole frame (all stages of one vo_frames_batch_dev call)", "achieved": gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -757,6 +784,21 @@ def _batched_run(torch, vo, ctx, stream, args, P):
                                  "pack_ms (the gather pass is a separate kernel); iters_per_sec uses the whole call"}}
 
 
+def _cgroup_cpu_quota():
+    """CPU cores granted by the cgroup (v2 cpu.max, v1 cfs quota), or None when unlimited / unknown"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / p if q > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def _median_time(fn, reps=5, warm=1):
     for _ in range(warm):
         fn()
@@ -788,19 +830,23 @@ def cpu_leg(fp, pipe, args):
     except AttributeError:
         n_thr = os.cpu_count() or 1
     n_aff = max(1, n_thr)
-    # every core of the affinity mask ("all_cores"), and the thread counts below it that a 50k-point round can actually
-    # feed (a round is 1 MB of input: beyond a few dozen threads the per-round fork / join outweighs the work)
+    # "all the cores this job may use" = the affinity mask capped by the cgroup's CPU quota: a 1-GPU box shows 256 cores in
+    # the mask and grants about 16 of them (cpu.max) -- 256 OpenMP threads on a 16-core quota do not finish a round
+    quota = _cgroup_cpu_quota()
+    n_use = max(1, min(n_aff, int(quota + 0.5))) if quota else min(n_aff, 16)
     sweep = []
-    for n_thr in sorted({t for t in (16, 64, n_aff) if t <= n_aff}):
+    counts = sorted({t for t in (16, n_use) if t <= n_use} or {n_use})
+    for n_thr in counts:
         def mt():
             res["mt"] = o.picp_solve_mt(cam, fp["model"], fp["cur_pts"], corr, args.iters, n_thr, 10000.0)
-        budget = 0.3 * args.cpu_seconds / max(1, len({t for t in (16, 64, n_aff) if t <= n_aff}))
+        budget = 0.3 * args.cpu_seconds / len(counts)
         t_mt, mt_reps = _median_time(mt, reps=int(max(5, min(200, budget / max(t_one / min(n_thr, 16), 1e-6)))))
         rm = res["mt"]
         sweep.append({"value": args.iters / t_mt, "unit": "iter/s", "cores": rm["threads"], "repetitions": mt_reps,
                       "pose_diff_vs_single_thread": float(np.abs(rm["T"] - r["T"]).max())})
     all_cores = dict(sweep[-1], kind="port, OpenMP over contiguous chunks with per-thread H/b partials (the reference itself has "
-                                     "no threading); cores = every core of this process's affinity mask",
+                                     "no threading); cores = every core this job may use: affinity mask capped by the cgroup CPU quota",
+                     affinity_mask_cores=n_aff, cgroup_cpu_quota=quota,
                      threads_sweep=[{"threads": e["cores"], "value": e["value"]} for e in sweep],
                      best={"threads": max(sweep, key=lambda e: e["value"])["cores"], "value": max(e["value"] for e in sweep)})
     # separately labelled: the same C sources compiled -march=native on this host

@@ -43,7 +43,10 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
     cur, last = None, None
     for r in rows:
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if name == "vo::cell_bounds_kernel" and int(r["Grid_Size"]) == 200 * 1024:
+        # a call over 200 x 50k frames starts with the matcher's first kernel: the row hashes of the exact-duplicate pass
+        # (8 XCD classes x 25 frames x 196 workgroups of 256 threads), or -- VO_MATCH_HASH=0 -- the sampled bounds
+        if (name == "vo::hash_rows_kernel" and int(r["Grid_Size"]) == 8 * 25 * 196 * 256) or \
+           (name == "vo::cell_bounds_kernel" and int(r["Grid_Size"]) == 200 * 1024 and cur is None):
             cur = collections.OrderedDict()
         if cur is not None and name.startswith("vo::"):
             cur[name] = cur.get(name, 0.0) + float(r["Counter_Value"])
