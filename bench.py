@@ -302,6 +302,8 @@ def _pmc_valu(kernels, pick=max):
         ks = json.load(open(files[-1]))["kernels"]
         total, util_w = 0.0, 0.0
         for k in kernels:
+            if k not in ks:                      # (a kernel that did nothing in the counter pass -- a skipped fallback -- has no row)
+                continue
             g = ks[k]["by_grid"]
             e = g[pick(g, key=lambda x: int(x))]
             total += e["valu_insts_per_launch"]

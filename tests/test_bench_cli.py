@@ -88,9 +88,10 @@ def test_committed_counter_summaries_feed_the_roofline_objects():
     for kernels, pick in ((("vo::match_init_kernel", "vo::match_kernel<false>", "vo::match_count_kernel", "vo::match_scatter_kernel"), min),
                           (("vo::match_minmax_kernel", "vo::match_bucket_hist_kernel", "vo::match_bucket_offsets_kernel",
                             "vo::match_bucket_place_kernel", "vo::match_pruned_kernel", "vo::match_count_kernel", "vo::match_scatter_kernel"), min),
-                          (("vo::cell_bounds_kernel", "vo::cell_place_kernel", "vo::cell_offsets_kernel", "vo::cell_fine_kernel",
-                            "vo::cell_search_kernel<0>", "vo::match_count_kernel", "vo::match_scatter_kernel"), max)):
+                          (b.MATCHER_CHAIN, max)):       # the batched call's matcher stage: exact-duplicate pass (+ the skipped search)
         insts, util, why = b._pmc_valu(kernels, pick)
         assert insts is not None and insts > 1e6 and 0.5 < util <= 1.0, (kernels, why)
+    m = b._matcher_roofline(200, 50000, 0.5e-3)
+    assert m["bound"] == "hbm" and m["traffic"] is not None and 0.5 < m["traffic_over_algorithmic"] < 3.0, m
     r = b._valu_roofline(("vo::match_init_kernel", "vo::match_kernel<false>"), 0.6e-3, "test", min)
     assert r["bound"] == "valu" and 0.3 < r["frac"] < 0.8                 # the full scan: about half the FP32 vector peak
