@@ -715,10 +715,14 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
     int i = tid * 4 + PICP_BATCH_LDS_TRIPS * PICP_BATCH_BLOCK * 4;
     bool have = i < n4;
     float4 x, y, z, u, v;
-    if (have) {
-      x = *reinterpret_cast<const float4*>(X + i); y = *reinterpret_cast<const float4*>(Y + i);
-      z = *reinterpret_cast<const float4*>(Z + i); u = *reinterpret_cast<const float4*>(U + i);
-      v = *reinterpret_cast<const float4*>(V + i);
+    // UNCONDITIONAL loads, here and in the loop below (a trip beyond the problem re-reads a valid one and is not used): under a
+    // predicate the compiler cannot count what is in flight, and waits for the NEXT trip's loads before it finishes the
+    // current one (s_waitcnt vmcnt(4) ... vmcnt(0) right behind their issue) -- the double buffering then hides nothing
+    {
+      const int ic = have ? i : 0;
+      x = *reinterpret_cast<const float4*>(X + ic); y = *reinterpret_cast<const float4*>(Y + ic);
+      z = *reinterpret_cast<const float4*>(Z + ic); u = *reinterpret_cast<const float4*>(U + ic);
+      v = *reinterpret_cast<const float4*>(V + ic);
     }
 #pragma unroll
     for (int c = 0; c < PICP_BATCH_LDS_TRIPS; ++c) {
@@ -748,10 +752,11 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
     while (have) {
       i += PICP_BATCH_BLOCK * 4;
       bool have2 = i < n4;
-      if (have2) {
-        x2 = *reinterpret_cast<const float4*>(X + i); y2 = *reinterpret_cast<const float4*>(Y + i);
-        z2 = *reinterpret_cast<const float4*>(Z + i); u2 = *reinterpret_cast<const float4*>(U + i);
-        v2 = *reinterpret_cast<const float4*>(V + i);
+      {
+        const int ic = have2 ? i : i - PICP_BATCH_BLOCK * 4;      // (the trip being linearised: valid)
+        x2 = *reinterpret_cast<const float4*>(X + ic); y2 = *reinterpret_cast<const float4*>(Y + ic);
+        z2 = *reinterpret_cast<const float4*>(Z + ic); u2 = *reinterpret_cast<const float4*>(U + ic);
+        v2 = *reinterpret_cast<const float4*>(V + ic);
       }
       picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x.x, y.x, z.x, u.x, v.x, acc);
       picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x.y, y.y, z.y, u.y, v.y, acc);
@@ -760,10 +765,11 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
       if (!have2) break;
       i += PICP_BATCH_BLOCK * 4;
       have = i < n4;
-      if (have) {
-        x = *reinterpret_cast<const float4*>(X + i); y = *reinterpret_cast<const float4*>(Y + i);
-        z = *reinterpret_cast<const float4*>(Z + i); u = *reinterpret_cast<const float4*>(U + i);
-        v = *reinterpret_cast<const float4*>(V + i);
+      {
+        const int ic = have ? i : i - PICP_BATCH_BLOCK * 4;
+        x = *reinterpret_cast<const float4*>(X + ic); y = *reinterpret_cast<const float4*>(Y + ic);
+        z = *reinterpret_cast<const float4*>(Z + ic); u = *reinterpret_cast<const float4*>(U + ic);
+        v = *reinterpret_cast<const float4*>(V + ic);
       }
       picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x2.x, y2.x, z2.x, u2.x, v2.x, acc);
       picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x2.y, y2.y, z2.y, u2.y, v2.y, acc);
