@@ -717,7 +717,10 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
     float4 x, y, z, u, v;
     // UNCONDITIONAL loads, here and in the loop below (a trip beyond the problem re-reads a valid one and is not used): under a
     // predicate the compiler cannot count what is in flight, and waits for the NEXT trip's loads before it finishes the
-    // current one (s_waitcnt vmcnt(4) ... vmcnt(0) right behind their issue) -- the double buffering then hides nothing
+    // current one (s_waitcnt vmcnt(4) ... vmcnt(0) right behind their issue): the double buffering then hides nothing inside
+    // a wave.  With three waves per SIMD the other two cover most of it: 1.61 -> 1.56 ms per 200 x 50k x 50 rounds on one box,
+    // 1.57 -> 1.59 on another -- inside the box-to-box spread; kept for the wait counts.  (A ring of three buffers, or the same
+    // two as arrays indexed by a constant, spill at the 170 registers three waves per SIMD leave: 1.74 / 1.60 ms.)
     {
       const int ic = have ? i : 0;
       x = *reinterpret_cast<const float4*>(X + ic); y = *reinterpret_cast<const float4*>(Y + ic);
