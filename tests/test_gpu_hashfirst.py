@@ -96,3 +96,31 @@ def test_hash_first_many_slices_and_batches(vo, ctx, o32):
         for k in range(12):
             assert np.array_equal(got[k], o32.match(a1[k], a2[k])), k
     c1.close(); c5.close()
+
+
+def test_hash_first_in_batched_calls_of_equal_frames(vo, o32):
+    """vo_match_appearances_batch_dev on frames of ONE size (the non-ragged path: blockIdx.z frames in the bucket-pruned
+    kernels, XCD-mapped frames in the cell-hash ones) with the exact-duplicate pass in front: 3 and 9 frames per call, frames
+    whose share of open queries runs from none to all -- every frame's pairs equal to the oracle's, modes 4 and 5."""
+    rng = np.random.default_rng(47)
+    n = 2600
+    for F in (3, 9):
+        fps = []
+        for k in range(F):
+            f = vo.synth.frame_pair(n, seed=900 + k)
+            a = f["cur_app"].copy()
+            n_open = int(len(a) * k / max(F - 1, 1))
+            idx = rng.permutation(len(a))[:n_open]
+            a[idx] += rng.normal(0, 0.01, (n_open, 10)).astype(np.float32)       # near copies: only the search finds them
+            f = dict(f); f["cur_app"] = a
+            fps.append(f)
+        for mode in (4, 5):
+            c = vo.Context(0)
+            assert c.lib.vo_match_set_mode(c.h, mode) == 0
+            bp = vo.BatchPipeline(c, fps, n_iters=1)
+            bp.match_only()
+            cnt = bp.counts()[0]
+            for k in range(F):
+                exp = o32.match(fps[k]["ref_app"], fps[k]["cur_app"])
+                assert cnt[k] == len(exp) and np.array_equal(bp.fetch("match", k), exp), (F, mode, k)
+            bp.close(); c.close()
