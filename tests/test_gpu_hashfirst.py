@@ -124,3 +124,48 @@ def test_hash_first_in_batched_calls_of_equal_frames(vo, o32):
                 exp = o32.match(fps[k]["ref_app"], fps[k]["cur_app"])
                 assert cnt[k] == len(exp) and np.array_equal(bp.fetch("match", k), exp), (F, mode, k)
             bp.close(); c.close()
+
+
+def _row_hash(rows):
+    """match.hip: row_hash, restated (uint32 arithmetic) -- white-box: used only to BUILD inputs that overflow a part"""
+    w = np.ascontiguousarray(rows, np.float32).view(np.uint32).astype(np.uint64)
+    M = np.uint64(0xffffffff)
+    rotl = lambda x, r: ((x << np.uint64(r)) | (x >> np.uint64(32 - r))) & M
+    x = w[:, 0]
+    for k in range(1, 10):
+        x = (rotl(x, 7) + w[:, k]) & M if k & 1 else rotl(x, 11) ^ w[:, k]
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x2c1b3c6d)) & M
+    x ^= x >> np.uint64(12); x = (x * np.uint64(0x297a2d39)) & M
+    x ^= x >> np.uint64(15)
+    return x.astype(np.uint32)
+
+
+def test_hash_first_part_overflow_falls_back_to_the_search(vo, o32):
+    """A tree whose rows all hash into ONE part of the table (picked with the numpy restatement of the hash): the part's queue
+    overflows, the part is stored empty and every query goes to the search -- among them copies that exist twice in the
+    tree, whose LOWER index must come back (a table that had taken only some of the rows could hold the higher one)."""
+    rng = np.random.default_rng(53)
+    pool = rng.uniform(-1, 1, (120000, 10)).astype(np.float32)
+    h = _row_hash(pool)
+    # 17 000 tree points: hash_plan gives 2^14-word parts, 4 of them (log2p = 2, average share 6400, queue 9600)
+    part0 = pool[(h >> np.uint32(30)) == 0]
+    assert len(part0) > 17000
+    tree = part0[:17000].copy()
+    tree[9000:9200] = tree[100:300]                              # 200 rows twice: the copy at the lower index must win
+    q = np.concatenate([tree[100:300], tree[5000:6000], rng.uniform(-1, 1, (300, 10)).astype(np.float32)])
+    q = q[rng.permutation(len(q))]
+    exp = o32.match(tree, q)
+    assert len(exp) == 1200 and set(exp[:, 0]) >= set(range(100, 300)) and not (set(exp[:, 0]) & set(range(9000, 9200)))
+    for mode in (4, 5):
+        c = vo.Context(0)
+        assert c.lib.vo_match_set_mode(c.h, mode) == 0
+        for _ in range(3):                                       # (the queues' record order varies from run to run)
+            assert np.array_equal(vo.compute_correspondences_images(tree, q, ctx=c), exp), mode
+        c.close()
+    # the same rows spread over all parts (no overflow): the pass answers them itself, same pairs
+    mixed = pool[:17000].copy(); mixed[9000:9200] = mixed[100:300]
+    q2 = np.concatenate([mixed[100:300], mixed[5000:6000]])
+    c = vo.Context(0)
+    assert c.lib.vo_match_set_mode(c.h, 5) == 0
+    assert np.array_equal(vo.compute_correspondences_images(mixed, q2, ctx=c), o32.match(mixed, q2))
+    c.close()

@@ -1493,8 +1493,8 @@ __global__ __launch_bounds__(CS_THREADS, CS_THREADS * CS_WG_PER_CU / 256) void c
 //     has magnitude >= ulp(2^-40)/2 = 2^-64, its square 2^-128 is a normal float, and a sum of non-negative terms with one
 //     positive term is positive.  (Without the bound tiny differences square to 0 by underflow: such rows go to the
 //     general search, like NaN / inf rows, which no distance test can pass.)
-//   * the frame's table is cut into P parts BY HASH (top bits), S 32-bit words each, one workgroup per part: it streams ALL
-//     the frame's tree rows (the P workgroups of a frame share an XCD, hence its L2), keeps the safe rows of its part and
+//   * the frame's table is cut into P parts BY HASH (top bits), S 32-bit words each; a streaming map hashes every tree row once
+//     and queues (hash, index) records per part, one workgroup per part takes its queue and
 //     inserts them into an open-addressing table in LDS (word = tag | index, index in the low `ib` bits; linear probing from
 //     an even home slot; a row equal to one already present takes the SMALLER index into that entry by atomicMin after
 //     comparing the two rows, so the table holds one entry per distinct row -- the lowest index, which is the tie rule of this
@@ -1520,9 +1520,10 @@ struct HashArgs {
   const int* d_n1; const int* d_n2;
   unsigned* tables;           // frame 0's table: parts << log2s words; frame f = tables + f * tables_stride
   size_t tables_stride;
-  unsigned* hashes;           // frame 0's row hashes (tree order); frame f = hashes + f * hashes_stride
-  size_t hashes_stride;
-  int* unres;                 // [n_frames] queries left open
+  uint2* queues;              // [n_frames][parts][qcap] records (hash, tree index): step 1 -> step 2
+  int* cursors;               // [n_frames][HJ_MAXP] records per part (zeroed per call, beside unres)
+  int qcap;                   // records a part's queue holds
+  int* unres;                 // [n_frames] queries left open (zeroed per call)
   unsigned long long* best;
   int32_t* out_pairs;         // the call's pair output (or null): the lookup writes pair j of a frame at slot j -- the final
   size_t out_stride;          //   place when every query of the frame finds its copy (then the compaction has nothing to do)
@@ -1548,11 +1549,11 @@ __device__ __forceinline__ bool rows_equal(const Row10& a, const Row10& b) {
 }
 __device__ __forceinline__ unsigned rotl32(unsigned x, int r) { return (x << r) | (x >> (32 - r)); }
 // One 32-bit hash per row; its top bits pick the part, its low bits the home slot, the bits in between are the tag.
-// Every workgroup of a frame hashes EVERY row of the tree (it keeps those of its part), in waves whose lanes all run the
-// same code, so the hash is on the critical path of the build: rotate-and-combine over the ten words (alternating add and
-// xor, two full-rate instructions per word) and two multiply-xorshift rounds at the end -- 32-bit multiplies are
-// quarter-rate, MurmurHash3's thirty of them made the build VALU-bound at 65 us per workgroup and 50k rows.  Nothing
-// but speed depends on the hash's quality: a part that fills up leaves rows without an entry, their queries to the search.
+// Rotate-and-combine over the ten words (alternating add and xor, two full-rate instructions per word) and two
+// multiply-xorshift rounds at the end -- 32-bit multiplies are quarter-rate: MurmurHash3's thirty of them made an earlier
+// form of the build, in which every part's workgroup hashed every row, VALU-bound at 65 us per workgroup and 50k rows.
+// Nothing but speed depends on the hash's quality: a part that overflows is stored empty, its queries go to the search.
+// (tests/test_gpu_hashfirst.py restates it in numpy to build trees that overflow a part on purpose.)
 __device__ __forceinline__ unsigned row_hash(const Row10& r) {
   unsigned x = __float_as_uint(r.v[0]);
 #pragma unroll
@@ -1618,25 +1619,49 @@ __device__ __forceinline__ Row10 run_row(const RowRun& r, float2* strip) {      
   return o;
 }
 
-// step 1: the hash of every tree row, in row order (a plain map over the rows: the whole chip streams them once)
+// step 1: the hash of every tree row -- a plain map over the rows, the whole chip streams them once -- written as (hash, index)
+// records into one QUEUE PER PART of the frame's table: a workgroup ranks its 256 rows inside their parts with LDS atomics,
+// reserves a run in every part's queue with one global atomic per part, and stores its records there.  (The order of a
+// queue's records varies from run to run; nothing downstream depends on it: the table keeps the lowest index of equal rows
+// whatever the order of insertion.)  A queue holds 1.5 x the average part; the cursor counts beyond it, which step 2 reads
+// as "this part overflowed".
+constexpr int HJ_MAXP = 32;                         // parts per frame, at most (hash_plan: log2p <= 5)
 __global__ __launch_bounds__(256) void hash_rows_kernel(HashArgs a) {
   int f, blk;
   if (!xcd_frame_block(a.hblocks, a.n_frames, f, blk)) return;
   const float* tree; const float* qry; int nt, nq;
   cell_sets(a, f, tree, qry, nt, nq);
-  if (blk == 0 && threadIdx.x == 0) a.unres[f] = 0;         // (the lookup kernel is a later launch)
   if (blk * 256 >= nt) return;
   __shared__ float2 s_strip[4][HJ_STRIP];
-  const int i = blk * 256 + threadIdx.x;
-  const Row10 r = run_row(run_load(tree, nt, i >> 6), s_strip[threadIdx.x >> 6]);
-  if (i < nt) a.hashes[f * a.hashes_stride + i] = row_hash(r);
+  __shared__ int s_cnt[HJ_MAXP], s_base[HJ_MAXP];
+  const int tid = threadIdx.x;
+  if (tid < HJ_MAXP) s_cnt[tid] = 0;
+  const int i = blk * 256 + tid;
+  const Row10 r = run_row(run_load(tree, nt, i >> 6), s_strip[tid >> 6]);
+  const unsigned h = row_hash(r);
+  const unsigned part = hj_part(h, a.log2p);
+  __syncthreads();
+  int pos = 0;
+  if (i < nt) pos = atomicAdd(&s_cnt[part], 1);
+  __syncthreads();
+  if (tid < (1 << a.log2p)) {
+    const int c = s_cnt[tid];
+    s_base[tid] = c ? atomicAdd(&a.cursors[(size_t)f * HJ_MAXP + tid], c) : 0;
+  }
+  __syncthreads();
+  if (i < nt) {
+    const int slot = s_base[part] + pos;
+    if (slot < a.qcap) a.queues[((size_t)f << a.log2p) * a.qcap + (size_t)part * a.qcap + slot] = make_uint2(h, (unsigned)i);
+  }
 }
 
-// step 2: one workgroup per (frame, part) reads ALL the frame's hashes (200 KB at 50k points, from the XCD's L2), queues
-// the entries of its own part per wave -- (word, home slot), compacted by ballot, so that insertion runs with every lane
-// busy: its compare-and-swap chain is a serial LDS round trip per step, which a wave with a quarter of its lanes active pays
-// four times as often -- and inserts them 64 at a time.  (A first version had every part's workgroup stream all ROWS and hash
-// them itself: 61 us per workgroup and 50k points, the chip 4 x 200 workgroups of it -- bound by those quarter-full chains.)
+// step 2: one workgroup per (frame, part) takes its queue -- every lane a record -- and inserts into an open-addressing table in
+// LDS, then stores the part as one contiguous image.  (Earlier forms, same box, 200 x 50k: every part's workgroup streaming all
+// ROWS and hashing them itself, 287-317 us -- quarter-full compare-and-swap chains; all HASHES read by every part's workgroup and
+// compacted by ballot into a per-wave queue, 85 us; the queues written by step 1: ~35 us.)  A part whose queue overflowed, or
+// whose table cannot take a row within HJ_PROBES slots (a degenerate hash), is stored EMPTY: all its queries stay open and go
+// to the search -- a table that lacks some rows could hold a copy's higher index without the lower one.
+constexpr unsigned HJ_PROBES = 512;
 template <int LOG2S>
 __global__ __launch_bounds__(HJ_THREADS) void hash_table_kernel(HashArgs a) {
   constexpr unsigned S = 1u << LOG2S;
@@ -1646,65 +1671,46 @@ __global__ __launch_bounds__(HJ_THREADS) void hash_table_kernel(HashArgs a) {
   cell_sets(a, f, tree, qry, nt, nq);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   __shared__ __attribute__((aligned(16))) unsigned s_tab[S];
-  __shared__ uint2 s_q[HJ_NW][128];
+  __shared__ int s_ovf;
+  if (tid == 0) s_ovf = 0;
   for (unsigned k = tid; k < S / 4; k += HJ_THREADS) reinterpret_cast<uint4*>(s_tab)[k] = make_uint4(HJ_EMPTY, HJ_EMPTY, HJ_EMPTY, HJ_EMPTY);
+  const int filled = a.cursors[(size_t)f * HJ_MAXP + part];
+  const int count = filled < a.qcap ? filled : a.qcap;
   __syncthreads();
   const unsigned imask = (1u << a.ib) - 1u;
-  const unsigned* hashes = a.hashes + f * a.hashes_stride;
-  uint2* q = s_q[wave];
-  int qhead = 0, qcount = 0;                                // wave-uniform
-  auto insert = [&](bool have, uint2 e) {                   // e = (word, home slot)
-    if (!have) return;
-    const unsigned word = e.x;
-    unsigned s = e.y;
-    for (unsigned n = 0; n < S; ++n) {                      // (a full part: the row gets no entry, its queries stay open)
-      const unsigned old = atomicCAS(&s_tab[s], HJ_EMPTY, word);
-      if (old == HJ_EMPTY) break;
-      if ((old >> a.ib) == (word >> a.ib)) {
-        // same tag: the same row?  (the entry's index may be lowered meanwhile -- by a copy of the same row)
-        const Row10 o = load_row_now(tree + 10 * (size_t)(old & imask)), r = load_row_now(tree + 10 * (size_t)(word & imask));
-        if (rows_equal(o, r)) { atomicMin(&s_tab[s], word); break; }
-      }
-      s = (s + 1u) & (S - 1u);
-    }
-  };
-  const int n_groups = (nt + 255) >> 8;                     // 256 hashes per wave and pass: one 16-byte load per lane
-  auto group_load = [&](int g) {
-    const long long at = 256ll * g + 4 * lane;
-    uint4 h = make_uint4(0u, 0u, 0u, 0u);
-    if (at + 3 < nt) h = *reinterpret_cast<const uint4*>(hashes + at);
-    else if (at < nt) { h.x = hashes[at]; if (at + 1 < nt) h.y = hashes[at + 1]; if (at + 2 < nt) h.z = hashes[at + 2]; }
-    return h;
-  };
-  uint4 h4 = make_uint4(0u, 0u, 0u, 0u);
-  if (wave < n_groups) h4 = group_load(wave);
-  for (int g = wave; g < n_groups; g += HJ_NW) {
-    const uint4 cur = h4;
-    if (g + HJ_NW < n_groups) h4 = group_load(g + HJ_NW);
-    const unsigned hv[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = 256 * g + 4 * lane + u;
-      const unsigned h = hv[u];
-      const bool own = i < nt && hj_part(h, a.log2p) == (unsigned)part;
-      const unsigned long long m = __ballot(own);
-      if (own) {
-        const int pos = qcount + __popcll(m & ((1ull << lane) - 1ull));
-        q[(qhead + pos) & 127] = make_uint2((hj_tag<LOG2S>(h, a.ib) << a.ib) | (unsigned)i, hj_home<LOG2S>(h));
-      }
-      qcount += __popcll(m);
-      if (qcount >= 64) {                                   // (wave-uniform)
-        __builtin_amdgcn_wave_barrier();
-        insert(true, q[(qhead + lane) & 127]);
-        qhead = (qhead + 64) & 127; qcount -= 64;
+  const uint2* q = a.queues + ((size_t)f << a.log2p) * a.qcap + (size_t)part * a.qcap;
+  if (filled <= a.qcap) {
+    const int n_groups = (count + 63) >> 6;
+    uint2 e = make_uint2(0u, 0u);
+    if (wave < n_groups) e = q[64 * wave + lane < count ? 64 * wave + lane : 0];
+    for (int g = wave; g < n_groups; g += HJ_NW) {
+      const uint2 cur = e;
+      const int nxt = 64 * (g + HJ_NW) + lane;
+      e = q[nxt < count ? nxt : 0];                          // (unconditional: the next group's record, or record 0 again)
+      if (64 * g + lane < count) {
+        const unsigned h = cur.x;
+        const unsigned word = (hj_tag<LOG2S>(h, a.ib) << a.ib) | cur.y;
+        unsigned s = hj_home<LOG2S>(h);
+        bool done = false;
+        for (unsigned n = 0; n < HJ_PROBES; ++n) {
+          const unsigned old = atomicCAS(&s_tab[s], HJ_EMPTY, word);
+          if (old == HJ_EMPTY) { done = true; break; }
+          if ((old >> a.ib) == (word >> a.ib)) {
+            // same tag: the same row?  (the entry's index may be lowered meanwhile -- by a copy of the same row)
+            const Row10 o = load_row_now(tree + 10 * (size_t)(old & imask)), r = load_row_now(tree + 10 * (size_t)(word & imask));
+            if (rows_equal(o, r)) { atomicMin(&s_tab[s], word); done = true; break; }
+          }
+          s = (s + 1u) & (S - 1u);
+        }
+        if (!done) s_ovf = 1;
       }
     }
   }
-  __builtin_amdgcn_wave_barrier();
-  insert(lane < qcount, q[(qhead + lane) & 127]);
   __syncthreads();
+  const bool drop = filled > a.qcap || s_ovf != 0;
   uint4* dst = reinterpret_cast<uint4*>(a.tables + f * a.tables_stride + ((size_t)part << LOG2S));
-  for (unsigned k = tid; k < S / 4; k += HJ_THREADS) dst[k] = reinterpret_cast<const uint4*>(s_tab)[k];
+  const uint4 none = make_uint4(HJ_EMPTY, HJ_EMPTY, HJ_EMPTY, HJ_EMPTY);
+  for (unsigned k = tid; k < S / 4; k += HJ_THREADS) dst[k] = drop ? none : reinterpret_cast<const uint4*>(s_tab)[k];
 }
 
 // step 3: the lookup, in query order.  A query's chain is three dependent round trips -- its row, its table word, the
@@ -1816,7 +1822,7 @@ __global__ __launch_bounds__(256) void hash_probe_kernel(HashArgs a) {
 }
 
 // 2^log2p parts of 2^log2s words for a tree of nt points: at most ~0.39 * 2^log2s points per part on average (load factor)
-struct HashPlan { int log2s, log2p, ib; };
+struct HashPlan { int log2s, log2p, ib, qcap; };
 #ifndef VO_HJ_MAXL
 #define VO_HJ_MAXL 2
 #endif
@@ -1834,15 +1840,17 @@ static bool hash_plan(int nt, HashPlan& p) {
   if ((long long)nt > ((long long)fill[l] << p.log2p)) return false;   // more than 204 800 points: the general search alone
   p.ib = 1;
   while ((1 << p.ib) < nt) ++p.ib;
+  p.qcap = fill[l] + fill[l] / 2;                    // a part's queue: 1.5 x its average share (table load <= 0.59)
   return true;
 }
 static size_t hash_table_bytes(const HashPlan& p) { return align256(sizeof(unsigned) * ((size_t)1 << (p.log2s + p.log2p))); }
-static size_t hash_rows_bytes(int nt) { return align256(sizeof(unsigned) * (size_t)nt); }
-// workspace of the pass: the open-query counters, then the tables, then the row hashes
+static size_t hash_queue_bytes(const HashPlan& p) { return align256(sizeof(uint2) * ((size_t)p.qcap << p.log2p)); }
+static size_t hash_head_bytes(int n_frames) { return align256(sizeof(int) * (size_t)n_frames * (1 + HJ_MAXP)); }   // open-query counters + queue cursors
+// workspace of the pass: the counters (zeroed per call), then the tables, then the queues
 static size_t hash_ws_bytes(int nt, int n_frames) {
   HashPlan p;
   if (!hash_plan(nt, p)) return 0;
-  return align256(sizeof(int) * (size_t)n_frames) + (hash_table_bytes(p) + hash_rows_bytes(nt)) * (size_t)n_frames;
+  return hash_head_bytes(n_frames) + (hash_table_bytes(p) + hash_queue_bytes(p)) * (size_t)n_frames;
 }
 bool match_hash_supported(int nt, int n_frames) { (void)n_frames; HashPlan p; return hash_plan(nt, p); }
 size_t match_hash_workspace_bytes(int nt, int n_frames) { return hash_ws_bytes(nt, n_frames); }
@@ -1860,11 +1868,14 @@ static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, c
   a.tree_stride = tree_stride; a.qry_stride = qry_stride; a.best_stride = best_stride;
   a.d_n1 = d_n1; a.d_n2 = d_n2;
   a.unres = static_cast<int*>(ws);
-  a.tables = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + align256(sizeof(int) * (size_t)n_frames));
+  a.cursors = a.unres + n_frames;
+  a.tables = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + hash_head_bytes(n_frames));
   a.tables_stride = hash_table_bytes(p) / sizeof(unsigned);
-  a.hashes = a.tables + a.tables_stride * (size_t)n_frames;
-  a.hashes_stride = hash_rows_bytes(nt_plan) / sizeof(unsigned);
+  a.queues = reinterpret_cast<uint2*>(a.tables + a.tables_stride * (size_t)n_frames);
+  a.qcap = p.qcap;
   a.hblocks = (nt_plan + 255) / 256;
+  hipError_t e0 = hipMemsetAsync(ws, 0, sizeof(int) * (size_t)n_frames * (1 + HJ_MAXP), st);
+  if (e0 != hipSuccess) return e0;
   a.best = d_best; a.r2 = r2;
   a.out_pairs = d_out_pairs; a.out_stride = out_stride; a.tree_is_1 = tree_is_1;
   a.n_frames = n_frames; a.log2p = p.log2p; a.ib = p.ib;
