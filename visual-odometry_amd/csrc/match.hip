@@ -1510,7 +1510,10 @@ __global__ __launch_bounds__(CS_THREADS, CS_THREADS * CS_WG_PER_CU / 256) void c
 // and is skipped altogether by a frame that has none.  Results are identical to the general search alone for every input
 // (tests/test_gpu_parity.py::test_matcher_variants_agree, tests/test_gpu_hashfirst.py).
 constexpr unsigned HJ_EMPTY = 0xffffffffu;
-constexpr int HJ_THREADS = 768;                     // 12 waves: the table (<= 128 KiB) and a 2560-byte strip per wave fill the CU's LDS
+#ifndef VO_HJ_THREADS
+#define VO_HJ_THREADS 768
+#endif
+constexpr int HJ_THREADS = VO_HJ_THREADS;           // 12 waves (two workgroups of the table step per CU at 2^14-word parts)
 constexpr int HJ_NW = HJ_THREADS / 64;
 constexpr int HJ_STRIP = 320;                       // float2 per strip: 64 rows of 40 bytes
 
