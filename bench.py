@@ -324,7 +324,9 @@ def _valu_roofline(kernels, seconds, scope, pick=max):
             "frac": tf / FP32_VECTOR_PEAK_TFLOPS, "valu_wave_instructions": insts, "lane_utilisation": util,
             "note": "achieved = executed VALU wave-instructions (" + note + ") x 64 lanes x 2 flop / live time of the stage: the share "
                     "of the FP32 vector issue rate the instruction stream occupies (an instruction is counted as an FMA with all "
-                    "lanes active; lane_utilisation says how many are)"}
+                    "lanes active; lane_utilisation says how many are).  The peak is one wave64 FMA per 2 cycles and SIMD; measured "
+                    "issue of plain FP32 streams on this part is 2.5 (VOP2) to 3.3-3.8 (VOP3) cycles (tools/micro/valu_rate.hip), "
+                    "i.e. a practical ceiling of 53-80 % of it"}
 
 
 MATCHER_CHAIN = ("vo::hash_rows_kernel", "vo::hash_table_kernel<14>", "vo::hash_probe_kernel<14>", "vo::cell_bounds_kernel",
