@@ -47,6 +47,26 @@ void hc_picp_accumulate_pinhole(int rows, int cols, int zn, int zf, const float*
   }
 }
 
+// the batched solver's instantiations (MUL0: a rejected term is zeroed through vo_mul0 -- on the host the same rule spelled out):
+// `general` != 0 takes the 3x3-K form.  Contributing terms must get the bits of the forms above; rejected ones exact zeros.
+void hc_picp_accumulate_mul0(int rows, int cols, int zn, int zf, const float* K, const float* T16, float thr, int keep, int general,
+                             const float* world, const float* meas, const int* corr, int n, float* acc) {
+  const CamK cam = mk(rows, cols, zn, zf, K);
+  const Pose T = pose_from_T16(T16);
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float* w = world + 3 * corr[2 * i + 1];
+    const float* z = meas + 2 * corr[2 * i];
+    if (general) {
+      if (keep) picp_accumulate_t<false, true, true, true>(cam, T, thr, w[0], w[1], w[2], z[0], z[1], acc);
+      else picp_accumulate_t<false, false, true, true>(cam, T, thr, w[0], w[1], w[2], z[0], z[1], acc);
+    } else {
+      if (keep) picp_accumulate_t<true, true, true, true>(cam, T, thr, w[0], w[1], w[2], z[0], z[1], acc);
+      else picp_accumulate_t<true, false, true, true>(cam, T, thr, w[0], w[1], w[2], z[0], z[1], acc);
+    }
+  }
+}
+
 int hc_is_pinhole(const float* K) { return is_pinhole(K) ? 1 : 0; }
 
 void hc_picp_update(const float* acc, float damping, const float* T16, float* T16_out, float* H, float* b) {

@@ -68,6 +68,21 @@ def test_picp_term_and_update(hc, o32, o64, vo):
                                       p(cm(np.eye(4), 4)), C.c_float(thr), keep, p(fp["model"]), p(fp["cur_pts"]),
                                       p(j), len(j), p(accp))
         assert accp.tobytes() == acc.tobytes()          # pinhole specialisation == general 3x3 K, bit for bit
+        # the batched solver's form (rejected terms zeroed through the 0 * x = 0 product instead of eight selects): same sums,
+        # pinhole and general -- also with points whose rejected projection holds inf / NaN (z = 0, far outside the image)
+        for general in (0, 1):
+            accm = np.zeros(30, np.float32)
+            hc.hc_picp_accumulate_mul0(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], p(cm(fp["K"], 3)), p(cm(np.eye(4), 4)),
+                                       C.c_float(thr), keep, general, p(fp["model"]), p(fp["cur_pts"]), p(j), len(j), p(accm))
+            assert np.array_equal(accm, acc), (thr, keep, general)
+        bad = fp["model"].copy()
+        bad[j[:40, 1], 2] = 0.0; bad[j[40:60, 1], 0] = 1e30; bad[j[60:70, 1], 2] = np.inf; bad[j[70:80, 1], 2] = 1e-40
+        accb = np.zeros(30, np.float32); accn = np.zeros(30, np.float32)
+        hc.hc_picp_accumulate(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], p(cm(fp["K"], 3)), p(cm(np.eye(4), 4)),
+                              C.c_float(thr), keep, p(bad), p(fp["cur_pts"]), p(j), len(j), p(accb))
+        hc.hc_picp_accumulate_mul0(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], p(cm(fp["K"], 3)), p(cm(np.eye(4), 4)),
+                                   C.c_float(thr), keep, 0, p(bad), p(fp["cur_pts"]), p(j), len(j), p(accn))
+        assert np.isfinite(accb).all() and np.array_equal(accn, accb)
         H = np.zeros((6, 6), np.float32)
         H[np.triu_indices(6)] = acc[:21]
         H = H + np.triu(H, 1).T

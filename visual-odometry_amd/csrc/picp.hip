@@ -742,10 +742,10 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
           cx = s_cache[c][0][tid]; cy = s_cache[c][1][tid]; cz = s_cache[c][2][tid];
           cu = s_cache[c][3][tid]; cv = s_cache[c][4][tid];
         }
-        picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, cx.x, cy.x, cz.x, cu.x, cv.x, acc);
-        picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, cx.y, cy.y, cz.y, cu.y, cv.y, acc);
-        picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, cx.z, cy.z, cz.z, cu.z, cv.z, acc);
-        picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, cx.w, cy.w, cz.w, cu.w, cv.w, acc);
+        picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, cx.x, cy.x, cz.x, cu.x, cv.x, acc);
+        picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, cx.y, cy.y, cz.y, cu.y, cv.y, acc);
+        picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, cx.z, cy.z, cz.z, cu.z, cv.z, acc);
+        picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, cx.w, cy.w, cz.w, cu.w, cv.w, acc);
       }
     }
     // register double buffering: the next trip's five 16-B loads are in flight while the current four correspondences are
@@ -761,10 +761,10 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
         z2 = *reinterpret_cast<const float4*>(Z + ic); u2 = *reinterpret_cast<const float4*>(U + ic);
         v2 = *reinterpret_cast<const float4*>(V + ic);
       }
-      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x.x, y.x, z.x, u.x, v.x, acc);
-      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x.y, y.y, z.y, u.y, v.y, acc);
-      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x.z, y.z, z.z, u.z, v.z, acc);
-      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x.w, y.w, z.w, u.w, v.w, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, x.x, y.x, z.x, u.x, v.x, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, x.y, y.y, z.y, u.y, v.y, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, x.z, y.z, z.z, u.z, v.z, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, x.w, y.w, z.w, u.w, v.w, acc);
       if (!have2) break;
       i += PICP_BATCH_BLOCK * 4;
       have = i < n4;
@@ -774,13 +774,13 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
         z = *reinterpret_cast<const float4*>(Z + ic); u = *reinterpret_cast<const float4*>(U + ic);
         v = *reinterpret_cast<const float4*>(V + ic);
       }
-      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x2.x, y2.x, z2.x, u2.x, v2.x, acc);
-      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x2.y, y2.y, z2.y, u2.y, v2.y, acc);
-      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x2.z, y2.z, z2.z, u2.z, v2.z, acc);
-      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, x2.w, y2.w, z2.w, u2.w, v2.w, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, x2.x, y2.x, z2.x, u2.x, v2.x, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, x2.y, y2.y, z2.y, u2.y, v2.y, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, x2.z, y2.z, z2.z, u2.z, v2.z, acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, x2.w, y2.w, z2.w, u2.w, v2.w, acc);
     }
     for (int i = n4 + tid; i < n; i += PICP_BATCH_BLOCK) {
-      picp_accumulate_t<PINHOLE, KEEP, STATS>(cam, T, a.thr, X[i], Y[i], Z[i], U[i], V[i], acc);
+      picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, X[i], Y[i], Z[i], U[i], V[i], acc);
     }
     const float tot = block_reduce_acc<PICP_BATCH_BLOCK / 64>(acc, s_red);
     if (tid < 32) s_tot[tid] = tot;

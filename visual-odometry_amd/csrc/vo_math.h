@@ -39,6 +39,28 @@ VO_HD float vo_recip_z(float z) {
 #endif
 }
 
+// x * y with 0 * anything = 0, NaN and infinity included (v_mul_legacy_f32; _n: x * (-y)).  The default-mode linearisation zeroes
+// the reciprocal depth of a correspondence that must not contribute; with this product everything derived from it is an exact
+// zero whatever the rejected projection left in the other factor -- four selects instead of eight per correspondence.
+VO_HD float vo_mul0(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return (a == 0.f || b == 0.f) ? 0.f : a * b;
+#endif
+}
+VO_HD float vo_mul0_n(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r;
+  asm("v_mul_legacy_f32_e64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return (a == 0.f || b == 0.f) ? 0.f : a * (-b);
+#endif
+}
+
 // A correspondence whose index lies outside its point array is DROPPED by the gather kernels: its world x carries this
 // bit pattern (a quiet NaN with a payload no arithmetic produces) and the linearisation skips it.  A world point that
 // really is NaN is not such a marker: it goes through the arithmetic like in the reference (and poisons the pose, like
@@ -186,7 +208,10 @@ VO_HD bool is_pinhole(const float K[9]) {
 // instead of (J0r*J0c + J1r*J1c)*lambda followed by an add.  The batched solver is bound by VALU issue, and this form
 // is ~20 instructions per correspondence shorter than the unfused one.  Reference-order arithmetic, decisions
 // included, is picp_term_exact below (vo_picp_set_exact).
-template <bool PINHOLE, bool KEEP, bool STATS = true>
+// MUL0: the zeroing of a term that must not contribute through vo_mul0 (four selects instead of eight; same values for every
+// contributing term).  The batched solver, bound by VALU issue, takes it (-2 %: 1.56 -> 1.53 ms per 200 x 50k x 50 rounds); the
+// launch-per-round kernels, a latency chain, do not (the VOP3 products lengthen it: 4.57 -> 4.60 us per round).
+template <bool PINHOLE, bool KEEP, bool STATS = true, bool MUL0 = false>
 VO_HD void picp_accumulate_t(const CamK& cam, const Pose& T, float thr, float wx, float wy, float wz,
                              float zu, float zv, float acc[NACC]) {
   constexpr bool keep_outliers = KEEP;
@@ -223,42 +248,49 @@ VO_HD void picp_accumulate_t(const CamK& cam, const Pose& T, float thr, float wx
   const bool use = lambda != 0.f;
   // Jp*K (:39-51): row 0 = iz * (K row 0 - u * K row 2), row 1 = iz * (K row 1 - v * K row 2) -- the reference's
   // iz*K_0c + (-ph0*iz^2)*K_2c with u = ph0*iz taken out.  A term that must not contribute has the generators of its
-  // Jacobian zeroed, so that no inf/nan of a rejected projection reaches an accumulator.
+  // Jacobian zeroed, so that no inf/nan of a rejected projection reaches an accumulator.  MUL0: it gets iz = 0, and every
+  // product that could meet an inf / NaN is taken with vo_mul0 (0 * anything = 0): all its Jacobian entries are exact zeros;
+  // what still needs a select are the residuals (they multiply the zero entries in plain FMAs) and the coordinates that
+  // enter an FMA as a factor.
   iz = use ? iz : 0.f;
   e0 = use ? e0 : 0.f;
   e1 = use ? e1 : 0.f;
-  const float p0 = use ? pc0 : 0.f, p1 = use ? pc1 : 0.f, p2 = use ? pc2 : 0.f;
-  const float un = use ? -u : 0.f, vn = use ? -v : 0.f;
+  const float p0 = (MUL0 || use) ? pc0 : 0.f, p2 = use ? pc2 : 0.f;
+  const float un = (MUL0 || use) ? -u : 0.f, vn = (MUL0 || use) ? -v : 0.f;
+  auto mul = [](float a, float b) { return MUL0 ? vo_mul0(a, b) : a * b; };
+  auto mul_n = [](float a, float b) { return MUL0 ? vo_mul0_n(a, b) : a * (-b); };
   float J0[6], J1[6];
   if (PINHOLE) {
+    const float p1 = (MUL0 || use) ? pc1 : 0.f;
     const float a = iz * cam.K[0], b = iz * cam.K[4];
-    const float c0 = iz * (cam.K[6] + un), c1 = iz * (cam.K[7] + vn);
+    const float c0 = mul(iz, cam.K[6] + un), c1 = mul(iz, cam.K[7] + vn);
     J0[0] = a;   J0[1] = 0.f; J0[2] = c0;
     J1[0] = 0.f; J1[1] = b;   J1[2] = c1;
     // J = (Jp K)[I | skew(-pc)]
-    J0[3] = c0 * p1;
-    J1[3] = vo_fma(b, -p2, c1 * p1);
-    J0[4] = vo_fma(a, p2, c0 * (-p0));
-    J1[4] = c1 * (-p0);
-    J0[5] = a * (-p1);
-    J1[5] = b * p0;
+    J0[3] = mul(c0, p1);
+    J1[3] = vo_fma(b, -p2, mul(c1, p1));
+    J0[4] = vo_fma(a, p2, mul_n(c0, p0));
+    J1[4] = mul_n(c1, p0);
+    J0[5] = mul_n(a, p1);
+    J1[5] = mul(b, p0);
   } else {
     // (the same roundings as the pinhole form for a pinhole K: fma(x, 0, k) = k, fma(x, 1, k) = k + x)
+    const float p1 = use ? pc1 : 0.f;
     float A0[3], A1[3];
     for (int c = 0; c < 3; ++c) {
-      A0[c] = iz * vo_fma(un, cam.K[2 + 3 * c], cam.K[3 * c]);
-      A1[c] = iz * vo_fma(vn, cam.K[2 + 3 * c], cam.K[1 + 3 * c]);
+      A0[c] = mul(iz, vo_fma(un, cam.K[2 + 3 * c], cam.K[3 * c]));
+      A1[c] = mul(iz, vo_fma(vn, cam.K[2 + 3 * c], cam.K[1 + 3 * c]));
     }
     // skew(v) = [0 -v2 v1; v2 0 -v0; -v1 v0 0] with v = -pc  (utils.h:96-102)
-    const float v0 = -p0, v1 = -p1, v2 = -p2;
+    const float v1 = -p1, v2 = -p2;
     J0[0] = A0[0]; J0[1] = A0[1]; J0[2] = A0[2];
     J1[0] = A1[0]; J1[1] = A1[1]; J1[2] = A1[2];
-    J0[3] = vo_fma(A0[1], v2, A0[2] * (-v1));
-    J1[3] = vo_fma(A1[1], v2, A1[2] * (-v1));
-    J0[4] = vo_fma(A0[0], -v2, A0[2] * v0);
-    J1[4] = vo_fma(A1[0], -v2, A1[2] * v0);
-    J0[5] = vo_fma(A0[0], v1, A0[1] * (-v0));
-    J1[5] = vo_fma(A1[0], v1, A1[1] * (-v0));
+    J0[3] = vo_fma(A0[1], v2, mul(A0[2], p1));
+    J1[3] = vo_fma(A1[1], v2, mul(A1[2], p1));
+    J0[4] = vo_fma(A0[0], -v2, mul_n(A0[2], p0));
+    J1[4] = vo_fma(A1[0], -v2, mul_n(A1[2], p0));
+    J0[5] = vo_fma(A0[0], v1, mul(A0[1], p0));
+    J1[5] = vo_fma(A1[0], v1, mul(A1[1], p0));
   }
   // left factors, scaled by lambda only when it can differ from 1
   float L0[6], L1[6];
