@@ -5,6 +5,8 @@
 // all-gather of the 4x4 poses over xGMI (ncclCommInitAll; each rank thread enqueues its ncclAllGather on its context's
 // stream).  There is no data-path collective: the gather is the only exchange.
 //   usage: batch_frames_mgpu [gpus=0 (all)] [pairs=1600] [points=50000] [rounds=50] [repeats=3] [frames_per_call=0 (all)]
+// VO_MGPU_SHARE_GPU=1 in the environment: a REHEARSAL on a box with one GPU -- `gpus` ranks, every one its own context on device
+// 0, the all-gather staged through host memory (RCCL refuses several ranks on one device); its rate is not a scaling number.
 // Prints one line per run and one JSON object; exits 0 only when every frame of every rank found all its matches / joins /
 // inliers, every pose is the generator's ground truth and every rank holds every other rank's poses after the gather.
 // Plain C++ over include/vo_hip.h + rccl.h + the HIP runtime API (device count, nothing else).
@@ -76,6 +78,8 @@ Pair make_pair(int n, uint64_t seed, const float K[9]) {
 
 struct Shared {
   int world, P, n, rounds, repeats, per_call, blk;
+  bool share = false;                   // rehearsal: all ranks on device 0, the gather through the host
+  std::vector<float> host_poses;        // rehearsal: [world * blk][16]
   std::vector<ncclComm_t> comms;
   Barrier* bar;
   Agreement* agree;                     // per rank: first failure; the common go / no-go before every collective
@@ -109,7 +113,7 @@ void rank_main(int rank, Shared& S) {
   shard_range(S.P, rank, S.world, lo, hi);
   const int F = hi - lo, n = S.n;
   vo_ctx* ctx = nullptr;
-  RANK_CHECK(vo_ctx_create(rank, nullptr, &ctx));              // its own stream on device `rank`
+  RANK_CHECK(vo_ctx_create(S.share ? 0 : rank, nullptr, &ctx));   // its own stream on device `rank`
   const size_t Fn = (size_t)F * (size_t)n;
   vo_frame_batch b{};
   std::vector<vo::Isometry3f> gt;
@@ -171,8 +175,15 @@ void rank_main(int rank, Shared& S) {
     }
     if (!S.agree->all_ok()) return false;
     // the final exchange: SE(3) poses of all ranks (blk x 16 floats each), on the context's stream behind the last launch
-    NCCL_CHECK(ncclAllGather(b.poses, gathered, 16 * (size_t)S.blk, ncclFloat, S.comms[(size_t)rank],
-                             reinterpret_cast<hipStream_t>(vo_ctx_stream(ctx))));
+    if (S.share) {                                             // by hand: own block to the host, barrier, everybody's blocks back
+      RANK_CHECK(vo_memcpy_d2h(ctx, &S.host_poses[16 * (size_t)rank * (size_t)S.blk], b.poses, sizeof(float) * 16 * (size_t)S.blk));
+      S.bar->wait();
+      RANK_CHECK(vo_memcpy_h2d(ctx, gathered, S.host_poses.data(), sizeof(float) * S.host_poses.size()));
+      S.bar->wait();                                           // (the host buffer is rewritten by the next pass)
+    } else {
+      NCCL_CHECK(ncclAllGather(b.poses, gathered, 16 * (size_t)S.blk, ncclFloat, S.comms[(size_t)rank],
+                               reinterpret_cast<hipStream_t>(vo_ctx_stream(ctx))));
+    }
     return true;
   };
   // a rank that failed during set-up still meets the others here; set-up failures end the run before the first collective
@@ -229,16 +240,22 @@ int main(int argc, char** argv) {
   S.per_call = argc > 6 ? std::atoi(argv[6]) : 0;
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { std::fprintf(stderr, "batch_frames_mgpu: no HIP device (the path has no CPU fallback)\n"); return 2; }
+  const char* share_env = std::getenv("VO_MGPU_SHARE_GPU");
+  S.share = share_env && share_env[0] == '1';
   if (want <= 0) want = n_dev;
-  if (want > n_dev) { std::fprintf(stderr, "batch_frames_mgpu: %d GPUs asked for, %d present\n", want, n_dev); return 2; }
+  if (want > n_dev && !S.share) { std::fprintf(stderr, "batch_frames_mgpu: %d GPUs asked for, %d present\n", want, n_dev); return 2; }
   if (S.P < want || S.n < 8 || S.rounds < 0 || S.repeats < 1) { std::fprintf(stderr, "batch_frames_mgpu: need pairs >= gpus, points >= 8, repeats >= 1\n"); return 2; }
   S.world = want;
   S.blk = vo::shard::block_rows(S.P, S.world);                                  // rank 0 holds a largest block
-  std::vector<int> devs((size_t)S.world);
-  std::iota(devs.begin(), devs.end(), 0);
-  S.comms.resize((size_t)S.world);
-  const ncclResult_t rc = ncclCommInitAll(S.comms.data(), S.world, devs.data());
-  if (rc != ncclSuccess) { std::fprintf(stderr, "ncclCommInitAll: %s\n", ncclGetErrorString(rc)); return 2; }
+  if (S.share) {
+    S.host_poses.assign(16 * (size_t)S.world * (size_t)S.blk, 0.f);
+  } else {
+    std::vector<int> devs((size_t)S.world);
+    std::iota(devs.begin(), devs.end(), 0);
+    S.comms.resize((size_t)S.world);
+    const ncclResult_t rc = ncclCommInitAll(S.comms.data(), S.world, devs.data());
+    if (rc != ncclSuccess) { std::fprintf(stderr, "ncclCommInitAll: %s\n", ncclGetErrorString(rc)); return 2; }
+  }
   Barrier bar(S.world);
   Agreement agree(S.world, bar);
   S.bar = &bar; S.agree = &agree;
@@ -260,7 +277,8 @@ int main(int argc, char** argv) {
               S.world, S.P, S.n, S.rounds, S.blk, sec * 1e3, S.P / sec, worst, bad, mism);
   std::printf("{\"app\": \"batch_frames_mgpu\", \"n_gpus\": %d, \"pairs_total\": %d, \"points\": %d, \"rounds\": %d, \"frames_per_sec\": %.1f, "
               "\"seconds_per_pass\": %.6f, \"scaling\": \"strong\", \"gather\": \"ncclAllGather of %d x 16 floats per rank\", "
-              "\"worst_pose_err\": %.3e, \"bad_frames\": %d, \"gather_mismatches\": %d}\n",
-              S.world, S.P, S.n, S.rounds, S.P / sec, sec, S.blk, worst, bad, mism);
+              "\"worst_pose_err\": %.3e, \"bad_frames\": %d, \"gather_mismatches\": %d%s}\n",
+              S.world, S.P, S.n, S.rounds, S.P / sec, sec, S.blk, worst, bad, mism,
+              S.share ? ", \"rehearsal\": \"VO_MGPU_SHARE_GPU=1: all ranks on ONE GPU, gather staged through the host -- not a scaling run\"" : "");
   return (bad == 0 && mism == 0 && worst < 2e-3f) ? 0 : 1;
 }

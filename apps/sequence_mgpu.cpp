@@ -6,6 +6,9 @@
 // together by two ncclAllGather over xGMI, and rank 0 runs the chain on them (vo::DeviceSequence::setMatchesExternal).
 // Same outputs as `vo_complete --resident --match-up-front`, bit for bit (tests/test_gpu_multigpu.py).
 //   usage: sequence_mgpu <data dir> [output dir] [gpus=0 (all)] [rounds=100] [--exact]
+// VO_MGPU_SHARE_GPU=1 in the environment: a REHEARSAL on a box with one GPU -- `gpus` ranks, every one its own context on device
+// 0, the two all-gathers staged through host memory (RCCL refuses several ranks on one device): blocks, padding, row mapping and
+// the chain on the gathered pairs run exactly as they will on a multi-GPU node; nothing it prints is a scaling number.
 // Plain C++ over include/vo/*.hpp + vo_hip.h + rccl.h + the HIP runtime API (device count, nothing else).
 #include <cstdio>
 #include <iostream>
@@ -26,6 +29,9 @@ namespace {
 
 struct Shared {
   int world = 1, P = 0;                  // ranks; consecutive pairs (frames - 1)
+  bool share = false;                    // rehearsal: all ranks on device 0, gathers through the host
+  std::vector<int> host_counts;          // rehearsal: [world * blk]
+  std::vector<int32_t> host_pairs;       //            [world * blk][cap] pairs
   size_t cap = 1;                        // pairs per row: the largest measurement set
   int blk = 0;                           // rows per rank in the gathered buffers
   const std::vector<PointCloudVector<2>>* frames = nullptr;
@@ -64,7 +70,7 @@ void rank_main(int rank, Shared& S) {
   vo_ctx* own = nullptr;
   vo_ctx* ctx = nullptr;
   if (rank == 0) ctx = default_context().handle();           // the chain runs on this context: same stream, same memory
-  else { RANK_CHECK(vo_ctx_create(rank, nullptr, &own)); ctx = own; }
+  else { RANK_CHECK(vo_ctx_create(S.share ? 0 : rank, nullptr, &own)); ctx = own; }
   float* d_app = nullptr; int* d_n = nullptr; int32_t* d_pairs = nullptr; int* d_cnt = nullptr;
   int32_t* g_pairs = nullptr; int* g_counts = nullptr;
   if (ctx) {
@@ -91,11 +97,20 @@ void rank_main(int rank, Shared& S) {
     }
   }
   if (S.agree->all_ok()) {                                   // nobody enters the collectives unless everybody does
-    hipStream_t st = reinterpret_cast<hipStream_t>(vo_ctx_stream(ctx));
-    NCCL_CHECK(ncclGroupStart());
-    NCCL_CHECK(ncclAllGather(d_cnt, g_counts, (size_t)S.blk, ncclInt32, S.comms[(size_t)rank], st));
-    NCCL_CHECK(ncclAllGather(d_pairs, g_pairs, 2 * cap * (size_t)S.blk, ncclInt32, S.comms[(size_t)rank], st));
-    NCCL_CHECK(ncclGroupEnd());
+    if (S.share) {
+      // the all-gathers by hand: own block to the host, barrier, everybody's blocks back (same layout: rank r at r * blk)
+      RANK_CHECK(vo_memcpy_d2h(ctx, &S.host_counts[(size_t)rank * (size_t)S.blk], d_cnt, sizeof(int) * (size_t)S.blk));
+      RANK_CHECK(vo_memcpy_d2h(ctx, &S.host_pairs[2 * cap * (size_t)rank * (size_t)S.blk], d_pairs, sizeof(int32_t) * 2 * cap * (size_t)S.blk));
+      S.bar->wait();
+      RANK_CHECK(vo_memcpy_h2d(ctx, g_counts, S.host_counts.data(), sizeof(int) * S.host_counts.size()));
+      RANK_CHECK(vo_memcpy_h2d(ctx, g_pairs, S.host_pairs.data(), sizeof(int32_t) * S.host_pairs.size()));
+    } else {
+      hipStream_t st = reinterpret_cast<hipStream_t>(vo_ctx_stream(ctx));
+      NCCL_CHECK(ncclGroupStart());
+      NCCL_CHECK(ncclAllGather(d_cnt, g_counts, (size_t)S.blk, ncclInt32, S.comms[(size_t)rank], st));
+      NCCL_CHECK(ncclAllGather(d_pairs, g_pairs, 2 * cap * (size_t)S.blk, ncclInt32, S.comms[(size_t)rank], st));
+      NCCL_CHECK(ncclGroupEnd());
+    }
     RANK_CHECK(vo_ctx_synchronize(ctx));
     std::vector<int> cnt((size_t)S.blk, 0);
     RANK_CHECK(vo_memcpy_d2h(ctx, cnt.data(), d_cnt, cnt.size() * sizeof(int)));
@@ -137,8 +152,10 @@ int main(int argc, char* argv[]) {
   const int rounds = pos.size() > 3 ? std::atoi(pos[3].c_str()) : 100;
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { std::fprintf(stderr, "sequence_mgpu: no HIP device (the path has no CPU fallback)\n"); return 2; }
+  const char* share_env = std::getenv("VO_MGPU_SHARE_GPU");
+  const bool share = share_env && share_env[0] == '1';
   if (want <= 0) want = n_dev;
-  if (want > n_dev) { std::fprintf(stderr, "sequence_mgpu: %d GPUs asked for, %d present\n", want, n_dev); return 2; }
+  if (want > n_dev && !share) { std::fprintf(stderr, "sequence_mgpu: %d GPUs asked for, %d present\n", want, n_dev); return 2; }
   try {
     save_gt_trajectory(path + "trajectory.dat", out + "trajectory_gt.txt");
     const std::regex pattern("^meas-\\d.*\\.dat$");
@@ -163,15 +180,20 @@ int main(int argc, char* argv[]) {
     Camera cam(int_params[3], int_params[2], int_params[0], int_params[1], k);
 
     Shared S;
-    S.world = want; S.P = (int)frames.size() - 1; S.frames = &frames;
+    S.world = want; S.P = (int)frames.size() - 1; S.frames = &frames; S.share = share;
     for (const auto& f : frames) S.cap = std::max(S.cap, f.size());
     S.blk = shard::block_rows(S.P, S.world);
     S.pairs_matched.assign((size_t)S.world, 0);
-    std::vector<int> devs((size_t)S.world);
-    std::iota(devs.begin(), devs.end(), 0);
-    S.comms.resize((size_t)S.world);
-    const ncclResult_t rc = ncclCommInitAll(S.comms.data(), S.world, devs.data());
-    if (rc != ncclSuccess) { std::fprintf(stderr, "ncclCommInitAll: %s\n", ncclGetErrorString(rc)); return 2; }
+    if (share) {
+      S.host_counts.assign((size_t)S.world * (size_t)S.blk, 0);
+      S.host_pairs.assign(2 * S.cap * (size_t)S.world * (size_t)S.blk, 0);
+    } else {
+      std::vector<int> devs((size_t)S.world);
+      std::iota(devs.begin(), devs.end(), 0);
+      S.comms.resize((size_t)S.world);
+      const ncclResult_t rc = ncclCommInitAll(S.comms.data(), S.world, devs.data());
+      if (rc != ncclSuccess) { std::fprintf(stderr, "ncclCommInitAll: %s\n", ncclGetErrorString(rc)); return 2; }
+    }
     Barrier bar(S.world);
     Agreement agree(S.world, bar);
     S.bar = &bar; S.agree = &agree;
@@ -216,8 +238,9 @@ int main(int argc, char* argv[]) {
     write_poses_raw(out + "poses_raw.txt", trajectory);
     const long by_ranks = std::accumulate(S.pairs_matched.begin(), S.pairs_matched.end(), 0L);
     std::printf("{\"app\": \"sequence_mgpu\", \"n_gpus\": %d, \"frames\": %d, \"pairs_per_rank\": %d, \"matches_total\": %ld, "
-                "\"matches_found_by_the_ranks\": %ld, \"gather\": \"2 x ncclAllGather (counts, %zu padded pairs per row)\"}\n",
-                S.world, seq.frames(), S.blk, total_matches, by_ranks, S.cap);
+                "\"matches_found_by_the_ranks\": %ld, \"gather\": \"%s (counts, %zu padded pairs per row)\"%s}\n",
+                S.world, seq.frames(), S.blk, total_matches, by_ranks, share ? "staged through the host" : "2 x ncclAllGather", S.cap,
+                share ? ", \"rehearsal\": \"VO_MGPU_SHARE_GPU=1: all ranks on ONE GPU -- not a scaling run\"" : "");
     vo_dev_free(default_context().handle(), S.g_pairs);
     vo_dev_free(default_context().handle(), S.g_counts);
     return total_matches == by_ranks ? 0 : 1;

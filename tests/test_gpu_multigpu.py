@@ -55,6 +55,40 @@ def test_native_sequence_driver_with_one_rank(tmp_path):
     assert r.returncode == 2 and "GPUs asked for" in r.stderr
 
 
+def test_native_drivers_with_three_ranks_rehearsed_on_the_one_gpu(tmp_path):
+    """VO_MGPU_SHARE_GPU=1: the native drivers with THREE ranks -- each its own context and host thread, all on this box's one
+    GPU, the all-gathers staged through the host (RCCL refuses several ranks on one device).  Uneven blocks (13 pairs = 5 + 4 + 4;
+    120 consecutive pairs = 40 + 40 + 40), padding rows, per-call slicing, own-block / foreign-block checks, the row mapping of the
+    gathered pair lists and the chain on them run as they will on a multi-GPU node; the sequence driver's files must still equal
+    `vo_complete --resident --match-up-front` byte for byte."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "apps"), "-s"])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VO_MGPU_SHARE_GPU="1")
+    r = subprocess.run([os.path.join(BIN, "batch_frames_mgpu"), "3", "13", "3000", "20", "2", "2"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 3 and d["pairs_total"] == 13 and d["bad_frames"] == 0 and d["gather_mismatches"] == 0 and "rehearsal" in d
+    assert d["worst_pose_err"] < 2e-3
+    data = os.path.join(ROOT, "tests", "golden", "example_data", "data")
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    r = subprocess.run([os.path.join(BIN, "sequence_mgpu"), data, str(a), "3", "100"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 3 and d["pairs_per_rank"] == 40 and d["matches_total"] == d["matches_found_by_the_ranks"] > 5000 and "rehearsal" in d
+    env1 = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r2 = subprocess.run([os.path.join(BIN, "vo_complete"), data, str(b), "100", "--resident", "--match-up-front"], capture_output=True,
+                        text=True, timeout=600, env=env1)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr
+    for f in ("poses_raw.txt", "trajectory_est_complete.txt", "map.txt", "map_appearances.txt"):
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
+    # seven ranks, 120 pairs = 18 x 1 + 17 x 6: blocks of different sizes, padding rows in the gathered lists
+    c = tmp_path / "c"; c.mkdir()
+    r = subprocess.run([os.path.join(BIN, "sequence_mgpu"), data, str(c), "7", "100"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    assert (c / "poses_raw.txt").read_bytes() == (b / "poses_raw.txt").read_bytes()
+
+
 def test_bench_self_launch_route_with_one_rank():
     env = dict(os.environ, VO_BENCH_FORCE_LAUNCH="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-extras", "--steps", "20", "--warmup", "3"],
