@@ -587,7 +587,7 @@ static int picp_prepare(vo_picp* s, const int32_t* d_pairs, int n_pairs, const i
     {
       // two buffers of round_up(grid,256) rows; rows >= grid are never written and must read as zero
       const size_t rows = ((size_t)s->grid + 255) & ~(size_t)255;
-      const size_t bytes = sizeof(float) * 2 * rows * PICP_PSTRIDE;
+      const size_t bytes = sizeof(float) * 2 * rows * PICP_PSTRIDE * PICP_REPLICAS;
       if (bytes > s->partials.cap || s->grid != s->zeroed_for_grid) {
         VO_HIP_CHECK(s->partials.ensure(bytes, c->stream));
         VO_HIP_CHECK(hipMemsetAsync(s->partials.p, 0, s->partials.cap, c->stream));
@@ -933,7 +933,7 @@ static int picp_batch_prepare(vo_ctx* c, int n_problems, int rows, int cols, int
     // problem as a grid dimension) instead of one workgroup per problem
     a.grid = picp_grid_for((int)a.cap, c->n_cu);
     const size_t rows = ((size_t)a.grid + 255) & ~(size_t)255;
-    const size_t part_bytes = sizeof(float) * 2 * rows * PICP_PSTRIDE * (size_t)n_problems;
+    const size_t part_bytes = sizeof(float) * 2 * rows * PICP_PSTRIDE * PICP_REPLICAS * (size_t)n_problems;
     const size_t states_cap = c->batch_states.cap;
     VO_HIP_CHECK(c->batch_states.ensure(sizeof(PicpState) * (size_t)n_problems + sizeof(PicpParams), c->stream));
     if (c->batch_states.cap != states_cap) c->batch_params_dev = nullptr;               // reallocated: nothing uploaded yet

@@ -340,7 +340,7 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
   }
   if (PRE) {
     const int nb_pad = (nb + 255) & ~255;
-    const float* prev = partials + (size_t)((it - 1) & 1) * nb_pad * PICP_PSTRIDE;
+    const float* prev = partials + (size_t)(blockIdx.x % PICP_REPLICAS) * 2 * nb_pad * PICP_PSTRIDE + (size_t)((it - 1) & 1) * nb_pad * PICP_PSTRIDE;
     const float4* src = reinterpret_cast<const float4*>(prev + (size_t)(tid >> 3) * PICP_PSTRIDE) + (tid & 7);
     constexpr int NJ = 256 / PICP_GROUPS;              // loads per thread and pass of 256 rows
     for (int b0 = 0; b0 < nb; b0 += 256) {
@@ -469,7 +469,9 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
   if (tid < PICP_PSTRIDE) {
     float o = tot;   // slot 29 (inlier count) is an exact integer in float: < 2^24 correspondences
     if (tid >= NACC) o = 0.f;
-    partials[((size_t)(it & 1) * ((nb + 255) & ~255) + blockIdx.x) * PICP_PSTRIDE + tid] = o;
+#pragma unroll
+    for (int r = 0; r < PICP_REPLICAS; ++r)
+      partials[(size_t)r * 2 * ((nb + 255) & ~255) * PICP_PSTRIDE + ((size_t)(it & 1) * ((nb + 255) & ~255) + blockIdx.x) * PICP_PSTRIDE + tid] = o;
   }
   VO_STAMP(6);
 }
@@ -1015,7 +1017,7 @@ static hipError_t launch_picp_exact_batch(hipStream_t st, const BatchArgs& b) {
 template <bool PINHOLE, bool KEEP>
 static void launch_rounds_batch_t(hipStream_t st, const BatchArgs& a) {
   const size_t rows = ((size_t)a.grid + 255) & ~(size_t)255;
-  const RoundBatch rb{a.n_pairs, a.cap, 2 * rows * PICP_PSTRIDE, a.T_out, a.stats_out};
+  const RoundBatch rb{a.n_pairs, a.cap, 2 * rows * PICP_PSTRIDE * PICP_REPLICAS, a.T_out, a.stats_out};
   const PackedCorr pk{a.packed, a.cap};
   const dim3 g(a.grid, a.n_problems), b(PICP_BLOCK);
   if (a.n_iters <= 0) {       // no round: the starting poses are the result

@@ -22,6 +22,14 @@ namespace vo {
 constexpr int PICP_BLOCK = VO_PICP_BLOCK;   // threads per workgroup of the single-problem kernels (256, 512 or 1024: DESIGN.md section 4.1)
 constexpr int PICP_PSTRIDE = 32;      // floats per workgroup partial (NACC padded)
 constexpr int PICP_MAX_BLOCKS = 2048; // grid cap (grid-stride beyond it)
+#ifndef VO_PICP_REPLICAS
+#define VO_PICP_REPLICAS 2
+#endif
+// Copies of the workgroup partial rows.  Every workgroup of a launch reads ALL the rows the previous launch wrote -- 196
+// workgroups fetching the same 25 KB at the same instant from the memory side (the rows come from all eight XCDs): with two
+// copies (a writer stores its row twice, a reader takes copy blockIdx.x % 2) the round of the 50k headline takes 4.48-4.50
+// instead of 4.57-4.58 us; four copies 4.50, eight 4.55 (the stores), three 4.63 (the modulo).
+constexpr int PICP_REPLICAS = VO_PICP_REPLICAS;
 constexpr int PICP_BATCH_BLOCK = 768;   // 12 waves: 3 per SIMD, 168 VGPRs each (room for load double-buffering)
 constexpr int PICP_BATCH_LDS_TRIPS = 2;   // trips of the batched solver held in LDS across rounds (2 x 60 KiB)
 
