@@ -169,3 +169,80 @@ def test_hash_first_part_overflow_falls_back_to_the_search(vo, o32):
     assert c.lib.vo_match_set_mode(c.h, 5) == 0
     assert np.array_equal(vo.compute_correspondences_images(mixed, q2, ctx=c), o32.match(mixed, q2))
     c.close()
+
+
+def test_few_open_queries_have_the_tree_streamed_past_them(vo, o32):
+    """Mode 5 with a FEW queries left open by the exact-duplicate pass (match.hip: open_collect_kernel / open_scan_kernel: the
+    open queries ordered by cell, the tree streamed once past them) -- counts on both sides of the route's limits (nq / 16,
+    2560), open queries that tie between several tree points (lowest index), that sit exactly at the radius (strictly inside
+    only), whose nearest neighbour is a row the pass must not hash (zeros), that crowd into one cell (the route declines),
+    that come at the END of the query array (new landmarks appended), NaN / inf rows; single calls, both roles, and a
+    ragged batch.  Every result equal to the oracle's and to the plain search's (mode 3)."""
+    rng = np.random.default_rng(59)
+    c3, c5 = _ctxs(vo, (3, 5))
+    R = np.float32(0.1)
+
+    def both(a, b, radius=0.1, oracle=True):
+        # the plain search (mode 3) is held to the oracle; the pass (mode 5) to the plain search -- the largest cases skip the
+        # oracle's brute force (seconds each on the CPU)
+        exp = vo.compute_correspondences_images(a, b, radius=radius, ctx=c3)
+        if oracle: assert np.array_equal(exp, o32.match(a, b, radius))
+        assert np.array_equal(vo.compute_correspondences_images(a, b, radius=radius, ctx=c5), exp)
+        assert np.array_equal(vo.compute_correspondences_images(b, a, radius=radius, ctx=c5), exp[:, ::-1])
+        return exp
+
+    n = 48000
+    tree = rng.uniform(-1, 1, (n, 10)).astype(np.float32)
+    q0 = tree[rng.permutation(n)][:44000].copy()
+    for n_open in (1, 7, 300, 2559, 2560, 2561, 2749, 2750, 2751, 6000):      # 44000 / 16 = 2750
+        q = q0.copy()
+        idx = rng.permutation(len(q))[:n_open]
+        q[idx] += rng.normal(0, 0.01, (n_open, 10)).astype(np.float32)        # near copies: most still inside the radius
+        q[idx[: n_open // 3]] = rng.uniform(-1, 1, (n_open // 3, 10)).astype(np.float32)   # strangers: most have no match
+        exp = both(tree, q, oracle=n_open in (7, 2560, 2751))
+        assert len(exp) >= len(q) - n_open
+    # new landmarks appended at the end of the query array (whole lookup workgroups of open queries)
+    q = np.concatenate([q0[:30000], tree[:1500] + np.float32(0.004)]).astype(np.float32)
+    assert len(both(tree, q, oracle=False)) > 31000
+    # ties: an open query in the middle of two tree points at bitwise equal distance (copies of one row, displaced): lowest index
+    t2 = tree.copy()
+    t2[40000:40050] = t2[100:150]                                             # the same rows twice
+    q = q0[:12000].copy()
+    q[:50] = t2[100:150]; q[:50, 0] += np.float32(0.03)                       # 0.03 from both copies
+    exp = both(t2, q)
+    hit = {int(b): int(a) for a, b in exp}
+    assert all(hit[k] == 100 + k for k in range(50))
+    # exactly at the radius: with radius 0.25 and one component displaced by 0.25 the squared distance equals radius^2 bit for
+    # bit (both are the float 0.0625): no match; one ulp closer: a match
+    t3 = tree[:16000].copy(); t3[:, 0] = np.float32(0.5) * np.sign(t3[:, 0]) * np.abs(t3[:, 0])      # keep x +- 0.25 exact-ish
+    t3[:200, 0] = np.float32(0.25)
+    q = t3[rng.permutation(16000)][:14000].copy()
+    q[:100] = t3[:100]; q[:100, 0] = np.float32(0.5)                          # d = 0.25 exactly
+    q[100:200] = t3[100:200]; q[100:200, 0] = np.nextafter(np.float32(0.5), np.float32(0))
+    exp = both(t3, q, radius=0.25)
+    hit = {int(b): int(a) for a, b in exp}
+    assert not any(k in hit for k in range(100)) and all(hit[k] == k for k in range(100, 200))
+    # rows the pass leaves to the search although they HAVE a copy (a zero component), NaN and inf rows, among few open queries
+    t4 = tree[:20000].copy(); t4[50:90, 6] = 0.0; t4[300, 2] = np.nan; t4[301, 3] = np.inf
+    q = t4[rng.permutation(20000)][:18000].copy()
+    q[:40] = t4[50:90]; q[40] = t4[300]; q[41] = t4[301]; q[42, 9] = -np.inf
+    exp = both(t4, q)
+    hit = {int(b): int(a) for a, b in exp}
+    assert all(hit[k] == 50 + k for k in range(40)) and 40 not in hit and 41 not in hit and 42 not in hit
+    # crowded: 1500 open queries within one cell's width of one another (the route declines: the sorted search takes them)
+    q = q0[:30000].copy()
+    q[:1500] = (tree[7] + rng.uniform(-0.02, 0.02, (1500, 10))).astype(np.float32)
+    both(tree, q, oracle=False)
+    # a ragged batch in mode 5: frames with 0, 1, a few, many open queries, either image the larger one
+    a1, a2 = [], []
+    for k, n_open in enumerate((0, 1, 40, 500, 900, 0, 9, 3000, 150, 0)):
+        nk = int(rng.integers(9000, 16000))
+        t = rng.uniform(-1, 1, (nk, 10)).astype(np.float32)
+        qq = t[rng.permutation(nk)][: int(nk * 0.9)].copy()
+        qq[:n_open] += rng.normal(0, 0.015, (n_open, 10)).astype(np.float32)
+        if k % 2: a1.append(t); a2.append(qq)
+        else: a1.append(qq); a2.append(t)
+    got = vo.match_batch_ragged(c5, a1, a2)
+    for k in range(len(a1)):
+        assert np.array_equal(got[k], o32.match(a1[k], a2[k])), k
+    c3.close(); c5.close()

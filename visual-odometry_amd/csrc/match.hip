@@ -778,8 +778,15 @@ __device__ __forceinline__ float pick10(const float* v, int k) {
 
 // per-frame workspace of the cell variant (bytes, every block 256-aligned)
 struct CellWs {
-  size_t cp, dir, t1, ql1, coarse_start, tree_word, tree_idx, q1, start_t, start_rel, total;
+  size_t cp, dir, t1, ql1, coarse_start, tree_word, tree_idx, q1, start_t, start_rel, open_start, open_rec, total;
 };
+#ifndef VO_OPEN_DIV
+#define VO_OPEN_DIV 16
+#endif
+constexpr int OPEN_DIV_DEFAULT = VO_OPEN_DIV;   // the tree is streamed past a frame's open queries when they are <= 1 / 16 of its queries (and <= OPEN_MAX)
+constexpr int OPEN_MAX = 2560;           // open queries per frame the tree can be streamed past (open_scan_kernel stages 9 records each in LDS)
+constexpr int OPEN_RECS = 9 * OPEN_MAX;  //   a query is entered into every (c0, c1) column of its box
+constexpr int OPEN_SROW_WS = 1024 * 8 + 8;   // (= OPEN_SROW below)
 constexpr int SROW = HCOARSE + 1;        // ints per coarse bin in the absolute start table (its fine bins + its own end)
 static int cell_slices(int n) { const int s = (n + CELL_SLICE - 1) / CELL_SLICE; return s < 1 ? 1 : s; }
 static CellWs cell_ws_layout(int nt, int nq) {
@@ -797,6 +804,9 @@ static CellWs cell_ws_layout(int nt, int nq) {
   w.start_t = o; o += align256(sizeof(int) * (size_t)HCOARSE * SROW); // first tree slot of every cell, rows of SROW per coarse bin
   w.start_rel = o; o += align256(sizeof(unsigned short) * (size_t)HCOARSE * HROW);   // the same relative to the bin's first slot
                                                                       //   (16-bit, rows of HROW: what the search stages)
+  // few open queries behind the exact-duplicate pass: their records ordered by coarse bin (open_collect_kernel -> open_scan_kernel)
+  w.open_start = o; o += align256(sizeof(unsigned short) * OPEN_SROW_WS);       // 16-bit first slot of every bin (c0, c1, c2)
+  w.open_rec = o; o += align256(sizeof(unsigned) * 2 * OPEN_RECS);              // filter words, then original indices
   w.total = o;
   return w;
 }
@@ -821,6 +831,10 @@ struct CellArgs {
   const int* unres;         // hash-first (or null): per-frame count of queries the exact-duplicate pass left open.  A frame with
                             //   none is skipped by every kernel; a query that pass has answered (key_answered(best[q])) is not
                             //   sorted in, so the search neither visits nor overwrites it
+  int* todo;                // hash-first (or null): per-frame count of open queries left to the SORTED search -- unres[f], or 0 when
+                            //   the frame's few open queries were settled by streaming the tree past them (open_scan_kernel)
+  int open_div;             // that route is taken by a frame with at most min(OPEN_MAX, nq / open_div) open queries (0: never)
+  const int* open_list;     // [n_frames][OPEN_MAX]: the open queries' indices as the lookup listed them
 };
 
 // the two sets of frame f with their roles: the larger one is the tree, set 1 on ties (vo_complete.cpp:15-20).  A: CellArgs
@@ -1527,6 +1541,9 @@ struct HashArgs {
   int* cursors;               // [n_frames][HJ_MAXP] records per part (zeroed per call, beside unres)
   int qcap;                   // records a part's queue holds
   int* unres;                 // [n_frames] queries left open (zeroed per call)
+  int* open_list;             // [n_frames][OPEN_MAX] their indices when there are at most OPEN_MAX, in no particular order (hash_open_kernel)
+  size_t queue_stride;        // uint2 per frame of `queues`; the lookup reuses a frame's queues for its workgroups' open queries:
+  int seg_counts;             //   ints [0, seg_counts) the segments (256 HJ_Q per workgroup), behind them one count per workgroup
   unsigned long long* best;
   int32_t* out_pairs;         // the call's pair output (or null): the lookup writes pair j of a frame at slot j -- the final
   size_t out_stride;          //   place when every query of the frame finds its copy (then the compaction has nothing to do)
@@ -1753,7 +1770,7 @@ __global__ __launch_bounds__(256) void hash_probe_kernel(HashArgs a) {
   Row10 q[HJ_Q];
   unsigned h[HJ_Q], found[HJ_Q];
   bool look[HJ_Q];
-  uint2 w01[HJ_Q];
+  uint4 w03[HJ_Q];
 #pragma unroll
   for (int u = 0; u < HJ_Q; ++u) {
     q[u] = run_row(run[u], s_strip[wave]);
@@ -1764,18 +1781,30 @@ __global__ __launch_bounds__(256) void hash_probe_kernel(HashArgs a) {
 #pragma unroll
   for (int u = 0; u < HJ_Q; ++u) {                         // the table words: unconditional loads (a lane that does not look reads slot 0)
     const unsigned* t = tab + ((size_t)hj_part(h[u], a.log2p) << LOG2S);
-    w01[u] = *reinterpret_cast<const uint2*>(t + (look[u] ? hj_home<LOG2S>(h[u]) : 0u));
+    w03[u] = *reinterpret_cast<const uint4*>(t + (look[u] ? hj_home<LOG2S>(h[u]) : 0u));   // (8-byte aligned: the home slot is even)
   }
   unsigned cand[HJ_Q];
   bool slow[HJ_Q];
 #pragma unroll
   for (int u = 0; u < HJ_Q; ++u) {
     const unsigned tag = hj_tag<LOG2S>(h[u], a.ib);
-    const bool e0 = w01[u].x == HJ_EMPTY, e1 = w01[u].y == HJ_EMPTY;
-    const bool m0 = !e0 && (w01[u].x >> a.ib) == tag, m1 = !e0 && !e1 && (w01[u].y >> a.ib) == tag;
-    cand[u] = m0 ? (w01[u].x & imask) : (m1 ? (w01[u].y & imask) : 0xffffffffu);
-    // settled without a candidate: the chain ends inside the word.  Not settled: no candidate and no end -> walk.
-    slow[u] = look[u] && cand[u] == 0xffffffffu && !(e0 || e1);
+    // the chain from the home slot, four slots of it: it ends at the first empty slot; the first tag that agrees before that
+    // names the candidate.  Neither within the window -> walk.  (A home slot two before the part's end: slots 2 and 3 of the
+    // load lie behind the part -- the chain wraps --, so the window is two slots there.)
+    const bool four = hj_home<LOG2S>(h[u]) != S - 2u;
+    const unsigned ws[4] = {w03[u].x, w03[u].y, w03[u].z, w03[u].w};
+    bool open_end = true;                                  // no end, no candidate so far
+    cand[u] = 0xffffffffu;
+    bool ended = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool seen = k < 2 || four;
+      const bool e = seen && ws[k] == HJ_EMPTY, m = seen && ws[k] != HJ_EMPTY && (ws[k] >> a.ib) == tag;
+      if (open_end && e) { ended = true; open_end = false; }
+      if (open_end && m) { cand[u] = ws[k] & imask; open_end = false; }
+    }
+    // settled without a candidate: the chain ends inside the window.  Not settled: no candidate and no end -> walk.
+    slow[u] = look[u] && cand[u] == 0xffffffffu && !ended;
     if (!look[u]) cand[u] = 0xffffffffu;
   }
   Row10 t[HJ_Q];
@@ -1806,22 +1835,300 @@ __global__ __launch_bounds__(256) void hash_probe_kernel(HashArgs a) {
     }
   }
   __syncthreads();
-  int n_open = 0;
   unsigned long long* best = a.best + f * a.best_stride;
   const bool tree_is_1 = a.d_n1 ? tree == a.tree + f * a.tree_stride : a.tree_is_1 != 0;      // (cell_sets swaps the sets when set 2 is the tree)
+  // The frame's open queries are counted and listed WITHOUT a global atomic: a workgroup ranks its own in LDS, stores their
+  // indices in its own segment (the part queues of step 1 are free by now) and its count beside them; hash_open_kernel adds
+  // the counts up per frame.  (One atomicAdd per workgroup on the frame's counter -- 196 on one address per frame, executed
+  // at the memory side -- cost the lookup 60 us per 200 x 50k frames as soon as most workgroups held an open query.)
+  int* seg = reinterpret_cast<int*>(a.queues + f * a.queue_stride);
 #pragma unroll
   for (int u = 0; u < HJ_Q; ++u) {
     const bool live = j[u] < nq;
     const bool open = live && found[u] == 0xffffffffu;
-    n_open += __popcll(__ballot(open));
+    const unsigned long long bal = __ballot(open);
+    const int n_w = __popcll(bal);
+    int wbase = 0;
+    if (lane == 0 && n_w > 0) wbase = atomicAdd(&s_open, n_w);
+    const int slot = __shfl(wbase, 0) + __popcll(bal & ((1ull << lane) - 1ull));
+    if (open) seg[blk * (256 * HJ_Q) + slot] = j[u];
     if (live) best[j[u]] = open ? (((unsigned long long)__float_as_uint(a.r2) << 32) | 0xffffffffull) : (unsigned long long)found[u];
     // pair j at slot j: where it belongs when no query of the frame stays open (match_count / match_scatter then skip the frame)
     if (live && !open && a.out_pairs)
       reinterpret_cast<int2*>(a.out_pairs + 2 * f * a.out_stride)[j[u]] = tree_is_1 ? make_int2((int)found[u], j[u]) : make_int2(j[u], (int)found[u]);
   }
-  if (lane == 0 && n_open > 0) atomicAdd(&s_open, n_open);
   __syncthreads();
-  if (tid == 0 && s_open > 0) atomicAdd(&a.unres[f], s_open);
+  if (tid == 0) seg[a.seg_counts + blk] = s_open;
+}
+
+// step 4: one workgroup per frame adds the lookup workgroups' counts up (unres[f]) and, when there are few enough, strings
+// their segments together into the frame's list of open queries (open_collect_kernel)
+__global__ __launch_bounds__(256) void hash_open_kernel(HashArgs a) {
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* tree; const float* qry; int nt, nq;
+  cell_sets(a, f, tree, qry, nt, nq);
+  const int nblk = (nq + 256 * HJ_Q - 1) / (256 * HJ_Q);
+  const int* seg = reinterpret_cast<const int*>(a.queues + f * a.queue_stride);
+  const int* cnt = seg + a.seg_counts;
+  __shared__ int s_w[4];
+  __shared__ int s_carry;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  // pass 1: the total
+  int mine = 0;
+  for (int b = tid; b < nblk; b += 256) mine += cnt[b];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+  if (lane == 0) s_w[wave] = mine;
+  __syncthreads();
+  const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  if (tid == 0) a.unres[f] = total;
+  if (total == 0 || total > OPEN_MAX) return;              // (uniform) no list wanted
+  __syncthreads();
+  // pass 2: exclusive prefix of the counts, 256 workgroups per trip, and the segments copied behind one another
+  int* list = a.open_list + (size_t)f * OPEN_MAX;
+  for (int b0 = 0; b0 < nblk; b0 += 256) {
+    const int b = b0 + tid;
+    const int c = b < nblk ? cnt[b] : 0;
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int at = s_carry + incl - c;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) at += w < wave ? s_w[w] : 0;
+    for (int k = 0; k < c; ++k) list[at + k] = seg[b * (256 * HJ_Q) + k];      // (few: <= OPEN_MAX over the whole frame)
+    __syncthreads();
+    if (tid == 0) s_carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+  }
+}
+
+// ---- few open queries: the tree streamed past them -------------------------------------------------------------------
+// A frame whose exact-duplicate pass left only a FEW queries open (new landmarks: a per cent or two of a tracking frame) would
+// still pay the whole sorted search -- its cost is sorting the TREE into cells, whatever the number of queries (measured,
+// 200 x 50k frames: 1 % open queries 1.11 ms for the matcher stage against 0.53 with none and 1.12 without the pass).  For such
+// a frame the roles are turned round: the open queries (<= OPEN_MAX, and <= nq / open_div) are ordered by the coarse bin
+// (c0, c1) of the SAME grid as the cell-hash search (one workgroup per frame, open_collect_kernel), and the tree is streamed
+// ONCE past them (open_scan_kernel): a tree point t can only be within the radius of queries whose cells lie in
+// [cell(t - R), cell(t + R)] per component -- fl(t - R) <= q <= fl(t + R) for every float q with |t - q| < r < R because
+// rounding is monotone, and the cell function is monotone -- i.e. of <= 3 runs of the ordered list (contiguous along c1).  Every
+// candidate goes through the search's filter (one v_sad_u8 on the quantised components 0..3, proof at the cell variant) and a
+// survivor is decided from the two full rows in the reference's operation order; the result enters the query's key by
+// atomicMin on (distance bits, tree index) -- the smallest distance, the lowest index among equals, strictly inside the radius:
+// the reference's rule, whatever the order in which tree points arrive.  ~9 M / 400 candidates per tree point (M open queries):
+// at M = 500 a pass over the rows (~0.1 ms per 200 x 50k frames) instead of 0.6 ms of sorting.
+// A frame with more open queries, or whose open queries crowd into few bins (the pass would degenerate into M x nt filter
+// tests), keeps the sorted search: todo[f] = unres[f].
+constexpr int OPEN_THREADS = 1024;
+constexpr int OPEN_PER_THREAD = (OPEN_MAX + OPEN_THREADS - 1) / OPEN_THREADS;
+constexpr int OPEN_BINS = HNC * HNC * HNC;            // (c0, c1, c2), numbered (c0 * HNC + c1) * HNC + c2 whatever the grid
+constexpr int OPEN_BPT = 8;                           // bins per thread in the scan of their counts
+constexpr int OPEN_SROW = OPEN_THREADS * OPEN_BPT + 8;   // u16 entries of the start table (bins beyond the grid hold the total)
+static_assert(OPEN_BINS <= OPEN_THREADS * OPEN_BPT && OPEN_RECS < 65536, "bins per thread / 16-bit starts");
+static_assert(OPEN_SROW_WS == OPEN_SROW, "workspace block of the start table");
+// one workgroup per frame: the open queries, each entered into the <= 9 columns (c0, c1) of ITS box at its own c2 -- a tree point
+// then finds every query it can be within the radius of in ONE run of the list, its own column along c2 (open_scan_kernel)
+__global__ __launch_bounds__(OPEN_THREADS) void open_collect_kernel(CellArgs a) {
+  const int f = blockIdx.x;
+  const int open = a.unres[f];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (open == 0) { if (tid == 0) a.todo[f] = 0; return; }
+  const float* tree; const float* qry; int nt, nq;
+  cell_sets(a, f, tree, qry, nt, nq);
+  int cap = a.open_div > 0 ? nq / a.open_div : 0;
+  cap = cap < OPEN_MAX ? cap : OPEN_MAX;
+  if (open > cap || nt <= 0) { if (tid == 0) a.todo[f] = open; return; }       // (uniform)
+  char* ws = a.ws + f * a.ws_stride;
+  const int* list = a.open_list + (size_t)f * OPEN_MAX;  // (all `open` entries are there: open <= OPEN_MAX)
+  __shared__ int s_cnt[OPEN_THREADS * OPEN_BPT];
+  __shared__ int s_max;
+  __shared__ int s_w[OPEN_THREADS / 64];
+#pragma unroll
+  for (int k = 0; k < OPEN_BPT; ++k) s_cnt[tid + k * OPEN_THREADS] = 0;
+  if (tid == 0) s_max = 0;
+  const int m = open;
+  __syncthreads();
+  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
+  int qi[OPEN_PER_THREAD], c2[OPEN_PER_THREAD], c0lo[OPEN_PER_THREAD], c1lo[OPEN_PER_THREAD], w0[OPEN_PER_THREAD], w1[OPEN_PER_THREAD];
+  int rank[OPEN_PER_THREAD][9];
+  unsigned word[OPEN_PER_THREAD];
+#pragma unroll
+  for (int u = 0; u < OPEN_PER_THREAD; ++u) {
+    const int k = tid + u * OPEN_THREADS;
+    qi[u] = 0; c2[u] = 0; c0lo[u] = 0; c1lo[u] = 0; w0[u] = -1; w1[u] = -1; word[u] = 0;      // (w0 < 0: no query here)
+    if (k < m) {
+      qi[u] = list[k];
+      qi[u] = (unsigned)qi[u] < (unsigned)nq ? qi[u] : 0;    // (always inside: the lookup wrote it; never an address from an unchecked word)
+      float v10[10];
+      load10(qry + 10 * (size_t)qi[u], v10);
+      const float x0 = pick10(v10, cp.dim[0]), x1 = pick10(v10, cp.dim[1]);
+      c0lo[u] = cell_of(x0 - cp.R, cp.lo[0], cp.scale[0], cp.nc[0]);
+      c1lo[u] = cell_of(x1 - cp.R, cp.lo[1], cp.scale[1], cp.nc[1]);
+      w0[u] = cell_of(x0 + cp.R, cp.lo[0], cp.scale[0], cp.nc[0]) - c0lo[u];
+      w1[u] = cell_of(x1 + cp.R, cp.lo[1], cp.scale[1], cp.nc[1]) - c1lo[u];
+      c2[u] = cell_of(pick10(v10, cp.dim[2]), cp.lo[2], cp.scale[2], cp.nc[2]);
+      word[u] = filter_word(v10[0], v10[1], v10[2], v10[3], cp);
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < 3; ++i0)
+#pragma unroll
+      for (int i1 = 0; i1 < 3; ++i1) {
+        rank[u][3 * i0 + i1] = -1;
+        if (i0 <= w0[u] && i1 <= w1[u])
+          rank[u][3 * i0 + i1] = atomicAdd(&s_cnt[((c0lo[u] + i0) * HNC + c1lo[u] + i1) * HNC + c2[u]], 1);
+      }
+  }
+  __syncthreads();
+  // exclusive scan of the bins' counts (OPEN_BPT consecutive bins per thread), the fullest bin, and whether a box was wider
+  // than three cells in a component (cells are >= R wide, so it cannot be -- but nothing may hang on that: then the sorted search)
+  int c[OPEN_BPT], sum = 0, most = 0;
+#pragma unroll
+  for (int k = 0; k < OPEN_BPT; ++k) { c[k] = s_cnt[tid * OPEN_BPT + k]; sum += c[k]; most = c[k] > most ? c[k] : most; }
+#pragma unroll
+  for (int u = 0; u < OPEN_PER_THREAD; ++u) if (w0[u] > 2 || w1[u] > 2) most = 0x7fffffff;
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+  if (lane == 63) s_w[wave] = incl;
+  if (most > 0) atomicMax(&s_max, most);
+  __syncthreads();
+  // crowded bins: the stream would test every tree point near them against all their queries
+  if (s_max > 32 + m / 16) { if (tid == 0) a.todo[f] = open; return; }         // (uniform)
+  int ex = incl - sum, total = 0;
+#pragma unroll
+  for (int w = 0; w < OPEN_THREADS / 64; ++w) { ex += w < wave ? s_w[w] : 0; total += s_w[w]; }
+  unsigned short* ostart = reinterpret_cast<unsigned short*>(ws + a.w.open_start);
+  {
+    unsigned pk[OPEN_BPT / 2];
+    int run = ex;
+#pragma unroll
+    for (int k = 0; k < OPEN_BPT; ++k) {
+      s_cnt[tid * OPEN_BPT + k] = run;                    // (this thread's own counters, read above)
+      if (k & 1) pk[k / 2] |= (unsigned)run << 16; else pk[k / 2] = (unsigned)run;
+      run += c[k];
+    }
+    reinterpret_cast<uint4*>(ostart)[tid] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  }
+  if (tid < 8) ostart[OPEN_THREADS * OPEN_BPT + tid] = (unsigned short)total;   // (the entries behind the last bin: the list's length)
+  if (tid == 0) a.todo[f] = 0;
+  __syncthreads();
+  unsigned* oword = reinterpret_cast<unsigned*>(ws + a.w.open_rec);
+  unsigned* oidx = oword + OPEN_RECS;
+#pragma unroll
+  for (int u = 0; u < OPEN_PER_THREAD; ++u)
+#pragma unroll
+    for (int i0 = 0; i0 < 3; ++i0)
+#pragma unroll
+      for (int i1 = 0; i1 < 3; ++i1)
+        if (rank[u][3 * i0 + i1] >= 0) {
+          const int slot = s_cnt[((c0lo[u] + i0) * HNC + c1lo[u] + i1) * HNC + c2[u]] + rank[u][3 * i0 + i1];
+          oword[slot] = word[u]; oidx[slot] = (unsigned)qi[u];
+        }
+}
+
+// The tree streamed past the list.  A workgroup stages the frame's start table and filter words ONCE (72 KB at most: one
+// workgroup per CU, so nothing hides that round trip but the length of the work behind it) and every wave then takes
+// `runs_per_wave` consecutive runs of 64 rows, the next run's loads in flight while the current one is looked up.
+constexpr int OPEN_SCAN_THREADS = 1024;
+constexpr int OPEN_SCAN_WAVES = OPEN_SCAN_THREADS / 64;
+__global__ __launch_bounds__(OPEN_SCAN_THREADS) void open_scan_kernel(CellArgs a, int tblocks, int runs_per_wave) {
+  int f, blk;
+  if (!xcd_frame_block(tblocks, a.n_frames, f, blk)) return;
+  const int m = a.unres[f];
+  if (m == 0 || a.todo[f] != 0) return;                   // no open query, or the sorted search takes them
+  const float* tree; const float* qry; int nt, nq;
+  cell_sets(a, f, tree, qry, nt, nq);
+  const int rows_per_wg = OPEN_SCAN_WAVES * 64 * runs_per_wave;
+  if ((long long)blk * rows_per_wg >= nt) return;         // (uniform)
+  char* ws = a.ws + f * a.ws_stride;
+  __shared__ __attribute__((aligned(16))) unsigned short s_start[OPEN_SROW];
+  __shared__ unsigned s_word[OPEN_RECS + 4];
+  __shared__ float2 s_strip[OPEN_SCAN_WAVES][HJ_STRIP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int chunk0 = (blk * OPEN_SCAN_WAVES + wave) * runs_per_wave;
+  const int n_chunks = (nt + 63) >> 6;
+  RowRun cur = run_load(tree, nt, chunk0 < n_chunks ? chunk0 : 0);
+  RowRun cur2 = run_load(tree, nt, chunk0 + 1 < n_chunks ? chunk0 + 1 : 0);
+  const unsigned short* ostart = reinterpret_cast<const unsigned short*>(ws + a.w.open_start);
+  const unsigned* oword = reinterpret_cast<const unsigned*>(ws + a.w.open_rec);
+  const unsigned* oidx = oword + OPEN_RECS;
+  for (int k = tid; k < OPEN_SROW / 8; k += OPEN_SCAN_THREADS) reinterpret_cast<uint4*>(s_start)[k] = reinterpret_cast<const uint4*>(ostart)[k];
+  const int n_stage = 9 * m < OPEN_RECS ? 9 * m : OPEN_RECS;      // (>= the list's length, known without waiting for it)
+  for (int k = tid; k < n_stage; k += OPEN_SCAN_THREADS) s_word[k] = oword[k];
+  const CellParams cp = *reinterpret_cast<const CellParams*>(ws + a.w.cp);
+  unsigned long long* best = a.best + f * a.best_stride;
+  const int T = cp.T;
+  __syncthreads();
+  // Two runs per pass: the kernel is a chain of LDS round trips (strip, start table, filter words), and two independent
+  // chains in a wave hide each other's.  The pair after this one is in flight meanwhile.
+  auto lookup = [&](const float* mine, int& b, int& e) {       // this lane's run of the list: [b, e)
+    // the hashed components straight from the strip (this wave's, still holding the run): one LDS read each instead of a
+    // ten-way select on registers
+    const float x0 = mine[cp.dim[0]], x1 = mine[cp.dim[1]], x2 = mine[cp.dim[2]];
+    const int c0 = cell_of(x0, cp.lo[0], cp.scale[0], cp.nc[0]), c1 = cell_of(x1, cp.lo[1], cp.scale[1], cp.nc[1]);
+    const int c2lo = cell_of(x2 - cp.R, cp.lo[2], cp.scale[2], cp.nc[2]), c2hi = cell_of(x2 + cp.R, cp.lo[2], cp.scale[2], cp.nc[2]);
+    const int base = (c0 * HNC + c1) * HNC;
+    b = s_start[base + c2lo];                             // (both unconditional: one round trip)
+    e = s_start[base + c2hi + 1];
+  };
+  // the decision: the reference's unfused left-to-right sum (brute_force_search.h:34), strictly inside the radius; the
+  // smallest (distance, tree index) wins whatever the order in which tree points arrive
+  auto decide = [&](const Row10& t, const int ti, const int p) {
+    const unsigned qi = oidx[p];
+    const Row10 q = load_row(qry + 10 * (size_t)qi);
+    float d = t.v[0] - q.v[0];
+    float s2 = d * d;
+#pragma unroll
+    for (int c = 1; c < 10; ++c) { d = t.v[c] - q.v[c]; s2 += d * d; }
+    if (s2 < a.r2)
+      atomicMin(&best[qi], ((unsigned long long)__float_as_uint(s2) << 32) | (unsigned long long)(unsigned)ti);
+  };
+  // A filter survivor costs two dependent memory round trips (the query's index, then its row) -- and with a per cent of the
+  // queries open most runs of 64 tree rows hold one: decided on the spot they were the kernel's time (16 waves per CU cannot
+  // hide that many).  So a lane PARKS its first two survivors (tree index, list position) and decides them after its last
+  // run, all lanes' loads in flight together; the tree row is fetched again then (L2: the frame was just streamed).
+  int park_ti0 = -1, park_p0 = 0, park_ti1 = -1, park_p1 = 0;
+  auto visit = [&](const Row10& t, const int ti, int b, const int e) {
+    if (b >= e) return;
+    const unsigned tw = filter_word(t.v[0], t.v[1], t.v[2], t.v[3], cp);
+    for (; b < e; b += 4) {
+      unsigned w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = s_word[b + k];    // (s_word is padded: a read behind the list is ignored)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (b + k < e && sad4(w[k], tw) <= T) {
+          if (park_ti0 < 0) { park_ti0 = ti; park_p0 = b + k; }
+          else if (park_ti1 < 0) { park_ti1 = ti; park_p1 = b + k; }
+          else decide(t, ti, b + k);
+        }
+      }
+    }
+  };
+  const float* mine = reinterpret_cast<const float*>(s_strip[wave]) + 10 * lane;
+  for (int u = 0; u < runs_per_wave && chunk0 + u < n_chunks; u += 2) {    // (wave-uniform)
+    const int n2 = chunk0 + u + 2, n3 = chunk0 + u + 3;
+    const RowRun ahead = run_load(tree, nt, n2 < n_chunks ? n2 : 0);       // (unconditional: see run_load)
+    const RowRun ahead2 = run_load(tree, nt, n3 < n_chunks ? n3 : 0);
+    const bool two = u + 1 < runs_per_wave && chunk0 + u + 1 < n_chunks;
+    const Row10 tA = run_row(cur, s_strip[wave]);
+    int bA, eA, bB, eB;
+    lookup(mine, bA, eA);
+    const Row10 tB = run_row(cur2, s_strip[wave]);
+    lookup(mine, bB, eB);
+    cur = ahead; cur2 = ahead2;
+    const int tiA = 64 * (chunk0 + u) + lane, tiB = tiA + 64;
+    visit(tA, tiA, bA, tiA < nt ? eA : 0);
+    visit(tB, tiB, bB, (two && tiB < nt) ? eB : 0);
+  }
+  {
+    const Row10 t0 = load_row(tree + 10 * (size_t)(park_ti0 >= 0 ? park_ti0 : 0));     // (unconditional: both rows in flight together)
+    const Row10 t1 = load_row(tree + 10 * (size_t)(park_ti1 >= 0 ? park_ti1 : 0));
+    if (park_ti0 >= 0) decide(t0, park_ti0, park_p0);
+    if (park_ti1 >= 0) decide(t1, park_ti1, park_p1);
+  }
 }
 
 // 2^log2p parts of 2^log2s words for a tree of nt points: at most ~0.39 * 2^log2s points per part on average (load factor)
@@ -1848,12 +2155,13 @@ static bool hash_plan(int nt, HashPlan& p) {
 }
 static size_t hash_table_bytes(const HashPlan& p) { return align256(sizeof(unsigned) * ((size_t)1 << (p.log2s + p.log2p))); }
 static size_t hash_queue_bytes(const HashPlan& p) { return align256(sizeof(uint2) * ((size_t)p.qcap << p.log2p)); }
-static size_t hash_head_bytes(int n_frames) { return align256(sizeof(int) * (size_t)n_frames * (1 + HJ_MAXP)); }   // open-query counters + queue cursors
+static size_t hash_head_bytes(int n_frames) { return align256(sizeof(int) * (size_t)n_frames * (2 + HJ_MAXP)); }   // open-query counters, the sorted search's share of them (todo), queue cursors
 // workspace of the pass: the counters (zeroed per call), then the tables, then the queues
+static size_t hash_list_bytes(int n_frames) { return align256(sizeof(int) * (size_t)n_frames * OPEN_MAX); }   // the open queries' indices
 static size_t hash_ws_bytes(int nt, int n_frames) {
   HashPlan p;
   if (!hash_plan(nt, p)) return 0;
-  return hash_head_bytes(n_frames) + (hash_table_bytes(p) + hash_queue_bytes(p)) * (size_t)n_frames;
+  return hash_head_bytes(n_frames) + hash_list_bytes(n_frames) + (hash_table_bytes(p) + hash_queue_bytes(p)) * (size_t)n_frames;
 }
 bool match_hash_supported(int nt, int n_frames) { (void)n_frames; HashPlan p; return hash_plan(nt, p); }
 size_t match_hash_workspace_bytes(int nt, int n_frames) { return hash_ws_bytes(nt, n_frames); }
@@ -1871,19 +2179,23 @@ static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, c
   a.tree_stride = tree_stride; a.qry_stride = qry_stride; a.best_stride = best_stride;
   a.d_n1 = d_n1; a.d_n2 = d_n2;
   a.unres = static_cast<int*>(ws);
-  a.cursors = a.unres + n_frames;
-  a.tables = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + hash_head_bytes(n_frames));
+  a.cursors = a.unres + 2 * (size_t)n_frames;          // (unres + n_frames: todo[], written by open_collect_kernel)
+  a.open_list = reinterpret_cast<int*>(static_cast<char*>(ws) + hash_head_bytes(n_frames));
+  a.tables = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + hash_head_bytes(n_frames) + hash_list_bytes(n_frames));
   a.tables_stride = hash_table_bytes(p) / sizeof(unsigned);
   a.queues = reinterpret_cast<uint2*>(a.tables + a.tables_stride * (size_t)n_frames);
   a.qcap = p.qcap;
   a.hblocks = (nt_plan + 255) / 256;
-  hipError_t e0 = hipMemsetAsync(ws, 0, sizeof(int) * (size_t)n_frames * (1 + HJ_MAXP), st);
+  hipError_t e0 = hipMemsetAsync(ws, 0, sizeof(int) * (size_t)n_frames * (2 + HJ_MAXP), st);
   if (e0 != hipSuccess) return e0;
   a.best = d_best; a.r2 = r2;
   a.out_pairs = d_out_pairs; a.out_stride = out_stride; a.tree_is_1 = tree_is_1;
   a.n_frames = n_frames; a.log2p = p.log2p; a.ib = p.ib;
   const int q_cap = d_n1 ? (nt < nq ? nt : nq) : nq;       // ragged: either set may be the queries, never more than the smaller capacity
   a.qblocks = (q_cap + 256 * HJ_Q - 1) / (256 * HJ_Q);
+  a.queue_stride = (size_t)p.qcap << p.log2p;
+  a.seg_counts = a.qblocks * 256 * HJ_Q;                  // (4 (seg_counts + qblocks) <= 8 queue_stride: a queue holds 1.5 x the tree)
+  if (4 * ((size_t)a.seg_counts + (size_t)a.qblocks) > 8 * a.queue_stride) return hipErrorInvalidValue;
   const dim3 gb(xcd_grid(1 << p.log2p, n_frames)), gp(xcd_grid(a.qblocks, n_frames)), tb(HJ_THREADS);
   hipLaunchKernelGGL(hash_rows_kernel, dim3(xcd_grid(a.hblocks, n_frames)), dim3(256), 0, st, a);
   switch (p.log2s) {
@@ -1896,6 +2208,7 @@ static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, c
     default: hipLaunchKernelGGL(hash_table_kernel<15>, gb, tb, 0, st, a);
              hipLaunchKernelGGL(hash_probe_kernel<15>, gp, dim3(256), 0, st, a); break;
   }
+  hipLaunchKernelGGL(hash_open_kernel, dim3((unsigned)n_frames), dim3(256), 0, st, a);
   *d_unres_out = a.unres;
   return hipGetLastError();
 }
@@ -1903,9 +2216,9 @@ static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, c
 static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tree, int nt, const float* qry, int nq,
                                     float radius, float r2, unsigned long long* d_best, void* ws, int n_frames,
                                     size_t tree_stride, size_t qry_stride, size_t best_stride, const int* d_n1 = nullptr,
-                                    const int* d_n2 = nullptr, const int* d_unres = nullptr) {
+                                    const int* d_n2 = nullptr, const int* d_unres = nullptr, int* d_todo = nullptr, const int* d_open_list = nullptr) {
   a.tree = tree; a.qry = qry; a.nt = nt; a.nq = nq;
-  a.d_n1 = d_n1; a.d_n2 = d_n2; a.unres = d_unres;
+  a.d_n1 = d_n1; a.d_n2 = d_n2; a.unres = d_unres; a.todo = nullptr; a.open_div = 0; a.open_list = nullptr;
   a.ws = static_cast<char*>(ws);
   if (d_n1) { const int cap = nt > nq ? nt : nq; a.w = cell_ws_layout(cap, cap); }   // ragged: either set may play either role
   else a.w = cell_ws_layout(nt, nq);
@@ -1916,6 +2229,21 @@ static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tr
   a.rs_offsets = nullptr; a.rs_indices = nullptr; a.rs_capacity = 0;
   const unsigned Z = (unsigned)n_frames;
   hipLaunchKernelGGL(cell_bounds_kernel, dim3(Z), dim3(1024), 0, st, a);
+  if (d_unres && d_todo && d_open_list) {
+    // frames with few open queries: the tree streamed past them; the sorted search below then sees todo[] instead of unres[]
+    static const int open_div = [] { const char* e = getenv("VO_MATCH_OPEN_DIV"); return e ? atoi(e) : OPEN_DIV_DEFAULT; }();
+    a.todo = d_todo; a.open_div = open_div; a.open_list = d_open_list;
+    const int big = d_n1 ? (nt > nq ? nt : nq) : nt;
+    // ~4 workgroups per CU over the call, so that the staging round trip at a workgroup's start is a small part of it
+    const int runs = (big + 63) / 64;
+    int tblocks = (4 * 256 + n_frames - 1) / n_frames;
+    const int tb_max = (runs + OPEN_SCAN_WAVES - 1) / OPEN_SCAN_WAVES;
+    tblocks = tblocks > tb_max ? tb_max : tblocks;
+    const int runs_per_wave = (runs + tblocks * OPEN_SCAN_WAVES - 1) / (tblocks * OPEN_SCAN_WAVES);
+    hipLaunchKernelGGL(open_collect_kernel, dim3(Z), dim3(OPEN_THREADS), 0, st, a);
+    hipLaunchKernelGGL(open_scan_kernel, dim3(xcd_grid(tblocks, n_frames)), dim3(OPEN_SCAN_THREADS), 0, st, a, tblocks, runs_per_wave);
+    a.unres = d_todo;
+  }
   hipLaunchKernelGGL(cell_place_kernel, dim3(xcd_grid(a.tb + a.qb, n_frames)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(cell_offsets_kernel, dim3(2, 1, Z), dim3(HCPAD), 0, st, a);
   hipLaunchKernelGGL(cell_fine_kernel, dim3(xcd_grid(HCOARSE / FG, n_frames)), dim3(256), 0, st, a);
@@ -1925,10 +2253,10 @@ static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tr
 static hipError_t launch_match_cells(hipStream_t st, const float* tree, int nt, const float* qry, int nq,
                                      float radius, float r2, unsigned long long* d_best, void* ws, int n_frames,
                                      size_t tree_stride, size_t qry_stride, size_t best_stride, const int* d_n1 = nullptr,
-                                     const int* d_n2 = nullptr, const int* d_unres = nullptr) {
+                                     const int* d_n2 = nullptr, const int* d_unres = nullptr, int* d_todo = nullptr, const int* d_open_list = nullptr) {
   CellArgs a;
   hipError_t e = launch_cells_sort(st, a, tree, nt, qry, nq, radius, r2, d_best, ws, n_frames, tree_stride, qry_stride,
-                                   best_stride, d_n1, d_n2, d_unres);
+                                   best_stride, d_n1, d_n2, d_unres, d_todo, d_open_list);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(cell_search_kernel<0>, dim3(xcd_grid(HNC * CS_STRIPS, n_frames)), dim3(CS_THREADS), 0, st, a);
   return hipGetLastError();
@@ -1976,7 +2304,8 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
       }
       // the cell-hash search with per-frame sizes and roles (workspace laid out for max(n1, n2) in both roles)
       hipError_t ec = launch_match_cells(st, d_a1, n1, d_a2, n2, radius, r2, d_best, ws, n_frames, a1_stride, a2_stride,
-                                         (size_t)q, d_n1, d_n2, d_unres);
+                                         (size_t)q, d_n1, d_n2, d_unres, d_unres ? d_unres + n_frames : nullptr,
+                                         d_unres ? reinterpret_cast<const int*>(static_cast<char*>(d_prune_ws) + hash_head_bytes(n_frames)) : nullptr);
       if (ec != hipSuccess) return ec;
     } else if (q > 0) {
       hipLaunchKernelGGL(match_init_kernel, dim3((q + 255) / 256, 1, (unsigned)n_frames), dim3(256), 0, st, d_best, q, r2, (size_t)q);
@@ -2013,7 +2342,8 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
   }
   if (nq > 0 && nt > 0 && d_prune_ws && variant == 3) {
     hipError_t ep = launch_match_cells(st, tree, nt, qry, nq, radius, r2, d_best, ws, n_frames, ts, qs,
-                                       best_stride, nullptr, nullptr, d_unres);
+                                       best_stride, nullptr, nullptr, d_unres, d_unres ? d_unres + n_frames : nullptr,
+                                       d_unres ? reinterpret_cast<const int*>(static_cast<char*>(d_prune_ws) + hash_head_bytes(n_frames)) : nullptr);
     if (ep != hipSuccess) return ep;
   } else if (nq > 0 && nt > 0 && d_prune_ws) {
     hipError_t ep = launch_match_pruned(st, tree, nt, qry, nq, radius, r2, d_best, ws, n_cu, n_frames, ts, qs,
