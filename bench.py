@@ -476,6 +476,26 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
     ctx.synchronize()
     match_ms = e0.elapsed_time(e1) / 3
     assert int(bp.counts()[0].min()) == args.points
+    # ... and when a share of every frame's queries has NO bitwise copy in the tree (new landmarks of a tracking frame: the
+    # exact-duplicate pass leaves them open; up to nq / 16 of them per frame have the tree streamed past them, more go to the
+    # sorted search): the synthetic pairs of this leg have none, so the stage's time above is its best case
+    by_share = None
+    if dist is None and (frames, args.points) == (200, 50000):
+        by_share = {"0": match_ms}
+        done = 0.0
+        for share in (0.01, 0.05, 0.25):
+            bp.perturb_cur_app(share - done, seed=int(share * 1000))     # (rows drawn anew: the shares add up, a few rows twice)
+            done = share
+            bp.match_only(); ctx.synchronize()
+            e0.record(stream)
+            for _ in range(3):
+                bp.match_only()
+            e1.record(stream)
+            ctx.synchronize()
+            by_share[f"{share:g}"] = e0.elapsed_time(e1) / 3
+            assert int(bp.counts()[0].min()) > 0.99 * args.points       # (displaced by sigma 0.005: still inside the radius 0.1)
+        by_share["note"] = ("matcher stage alone, ms per 200 x 50k frames, by the share of every frame's queries displaced so that "
+                            "they have no bitwise copy in the tree (still matched: by the search)")
     bp.close()
     alg = _frame_alg_bytes(args.points, args.iters) * frames
     gbs = alg / sec / 1e9
@@ -483,6 +503,7 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
             "frames_per_sec": frames * world / (ms * 1e-3), "us_per_frame_per_gpu": ms * 1e3 / frames, "pose_err_vs_gt": err,
             "seeds": f"4000+p, p = {frames * rank}..{frames * rank + frames - 1} on this rank",
             "matcher_ms_per_batch": match_ms,
+            "matcher_ms_by_open_share": by_share,
             "matcher_roofline": _matcher_roofline(frames, args.points, match_ms * 1e-3)
             if (frames, args.points) == (200, 50000) else None,
             "roofline": {"bound": "hbm", "scope": "whole frame (all stages of one vo_frames_batch_dev call)", "achieved": gbs,

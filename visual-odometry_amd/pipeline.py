@@ -241,6 +241,21 @@ class BatchPipeline:
                                                          C.c_void_p(b.cur_app), C.c_int(b.n_cur), None, C.c_float(b.radius),
                                                          C.c_void_p(b.matches), C.c_void_p(b.counts)))
 
+    def perturb_cur_app(self, share: float, seed: int = 0, sigma: float = 0.005):
+        """Measurement helper: a share of every frame's current appearances (rows drawn at random) displaced by N(0, sigma) per
+        component, in device memory -- still within the radius of their landmark, but no bitwise copy of it any more: queries
+        the exact-duplicate pass of the matcher leaves open.  Applied to the arrays as they are (shares add up over calls)."""
+        n, F = self.n_cur, self.F
+        d = self._in[1]
+        a = np.zeros((F, n, 10), np.float32)
+        self.ctx.d2h(a, d)
+        rng = np.random.default_rng(seed)
+        k = int(share * n)
+        for f in range(F):
+            idx = rng.choice(n, k, replace=False)
+            a[f, idx] += rng.normal(0, sigma, (k, 10)).astype(np.float32)
+        self.ctx.h2d(d, a)
+
     def counts(self):
         raw = np.zeros(3 * self.F, np.int32)
         self.ctx.d2h(raw, self.d_counts)
