@@ -24,7 +24,11 @@ def appearance_sets(n, kind):
     elif kind == 1: base = np.concatenate([rng.normal(0.3, 0.01, (max(n, 1) // 2 + 1, 10)), rng.uniform(-1, 1, (max(n, 1), 10))])[: max(n, 1)]
     else: base = rng.uniform(-1, 1, (max(n // 7, 1), 10))[rng.integers(0, max(n // 7, 1), max(n, 1))]
     x = base[:n].astype(np.float32)
-    y = (x[rng.permutation(n)].astype(np.float64) + (0 if kind == 2 else rng.normal(0, 1e-3, (n, 10)))).astype(np.float32)
+    # a share of the copies displaced (no bitwise copy any more: the exact-duplicate pass leaves them open; few of them per frame
+    # have the tree streamed past them, many go to the sorted search)
+    share = float(rng.choice([0.0, 0.01, 0.04, 0.2, 1.0]))
+    noise = rng.normal(0, 1e-3, (n, 10)) * (rng.uniform(0, 1, (n, 1)) < share)
+    y = (x[rng.permutation(n)].astype(np.float64) + (0 if kind == 2 else noise)).astype(np.float32)
     extra = rng.uniform(-1, 1, (int(rng.integers(0, 1 + n // 5 + 3)), 10)).astype(np.float32)
     return (np.concatenate([x, extra]), y) if rng.integers(0, 2) else (x, np.concatenate([y, extra]))
 
