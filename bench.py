@@ -329,14 +329,15 @@ def _valu_roofline(kernels, seconds, scope, pick=max):
                     "i.e. a practical ceiling of 53-80 % of it"}
 
 
-MATCHER_CHAIN = ("vo::hash_rows_kernel", "vo::hash_table_kernel<14>", "vo::hash_probe_kernel<14>", "vo::cell_bounds_kernel",
+MATCHER_CHAIN = ("vo::hash_rows_kernel", "vo::hash_table_kernel<14>", "vo::hash_probe_kernel<14>", "vo::hash_open_kernel",
+                 "vo::cell_bounds_kernel", "vo::open_collect_kernel", "vo::open_scan_kernel",
                  "vo::cell_place_kernel", "vo::cell_offsets_kernel", "vo::cell_fine_kernel", "vo::cell_search_kernel<0>",
                  "vo::match_count_kernel", "vo::match_scatter_kernel")
 
 
 def _matcher_roofline(frames, points, seconds):
     """The matcher stage of the batched call since round 4: row hashes, hash tables in LDS, one lookup per query (match.hip
-    "hash-first"); the cell-hash kernels behind it only touch frames with open queries (none in this workload).  It streams
+    "hash-first"); the kernels behind it (open-query route, cell-hash search) only touch frames with open queries (none in this workload).  It streams
     every row once and gathers one tree row per query: HBM-side algorithmic bytes over time, the counter traffic of its
     kernels beside it, and -- SURVEY 8(d) asked for the matcher's VALU share -- the executed VALU stream as before."""
     alg = FRAME_ALG_BYTES["match"] * (points / 50000.0) * frames
