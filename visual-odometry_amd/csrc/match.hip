@@ -1514,7 +1514,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_THREADS * CS_WG_PER_CU / 256) void c
 //     comparing the two rows, so the table holds one entry per distinct row -- the lowest index, which is the tie rule of this
 //     library's matcher), then stores the finished part as one contiguous image.  No global atomics (level 1's comment above:
 //     a global atomic per point is 64 scattered memory-side requests per wave).
-//   * a safe query reads ONE 8-byte word -- home slot and its neighbour -- of the part its hash selects (a first version
+//   * a safe query reads ONE 16-byte window -- the home slot and the three behind it -- of the part its hash selects (a first version
 //     cut the tree by position and looked into every slice's table: 8 scattered loads per query at ~200 G scattered
 //     lane-loads/s chip-wide made the lookup 0.64 ms per 200 x 50k frames), fetches the row of an entry whose tag agrees
 //     and compares all ten floats: equal -> key (distance 0, that entry's index).  With radius^2 > 0 the key is FINAL: no tree
@@ -1585,7 +1585,7 @@ __device__ __forceinline__ unsigned row_hash(const Row10& r) {
   return x;
 }
 __device__ __forceinline__ unsigned hj_part(unsigned h, int log2p) { return log2p ? h >> (32 - log2p) : 0u; }
-// home slot (even: the lookup reads it and its neighbour as one 8-byte word) and tag of a hash
+// home slot (even: the lookup's 16-byte window from it is 8-byte aligned) and tag of a hash
 template <int LOG2S> __device__ __forceinline__ unsigned hj_home(unsigned h) { return h & ((1u << LOG2S) - 2u); }
 template <int LOG2S> __device__ __forceinline__ unsigned hj_tag(unsigned h, int ib) { return (h >> LOG2S) & ((1u << (31 - ib)) - 1u); }
 
@@ -1738,7 +1738,7 @@ __global__ __launch_bounds__(HJ_THREADS) void hash_table_kernel(HashArgs a) {
 // with one query per lane, 297 with two, 360 with four (fewer waves) -- the kernel is not short of requests in flight, it
 // runs at the rate the XCD's L2 answers scattered line requests (2.8 per query: 0.3 for its row, 1 table word, 1.5 for the
 // candidate's 40-byte row; 1.0 GB of HBM traffic per call, 3.6 TB/s).  So one query per lane.
-// Fast path: the home slot and its neighbour (one 8-byte word) either end the chain (an empty slot) or name a candidate
+// Fast path: the home slot and the three behind it (one 16-byte load) either end the chain (an empty slot) or name a candidate
 // whose row settles it; everything else -- a longer chain, a tag that agrees on a different row -- walks the chain in full.
 #ifndef VO_HJ_Q
 #define VO_HJ_Q 1
