@@ -1954,22 +1954,28 @@ __global__ __launch_bounds__(OPEN_THREADS) void open_collect_kernel(CellArgs a) 
   int qi[OPEN_PER_THREAD], c2[OPEN_PER_THREAD], c0lo[OPEN_PER_THREAD], c1lo[OPEN_PER_THREAD], w0[OPEN_PER_THREAD], w1[OPEN_PER_THREAD];
   int rank[OPEN_PER_THREAD][9];
   unsigned word[OPEN_PER_THREAD];
+  // (three phases, each over all of the thread's queries, so that their round trips overlap: indices, rows, then cells and ranks)
 #pragma unroll
   for (int u = 0; u < OPEN_PER_THREAD; ++u) {
     const int k = tid + u * OPEN_THREADS;
-    qi[u] = 0; c2[u] = 0; c0lo[u] = 0; c1lo[u] = 0; w0[u] = -1; w1[u] = -1; word[u] = 0;      // (w0 < 0: no query here)
+    qi[u] = list[k < m ? k : 0];
+    qi[u] = (unsigned)qi[u] < (unsigned)nq ? qi[u] : 0;    // (always inside: the lookup wrote it; never an address from an unchecked word)
+  }
+  float v10[OPEN_PER_THREAD][10];
+#pragma unroll
+  for (int u = 0; u < OPEN_PER_THREAD; ++u) load10(qry + 10 * (size_t)qi[u], v10[u]);
+#pragma unroll
+  for (int u = 0; u < OPEN_PER_THREAD; ++u) {
+    const int k = tid + u * OPEN_THREADS;
+    c2[u] = 0; c0lo[u] = 0; c1lo[u] = 0; w0[u] = -1; w1[u] = -1; word[u] = 0;      // (w0 < 0: no query here)
     if (k < m) {
-      qi[u] = list[k];
-      qi[u] = (unsigned)qi[u] < (unsigned)nq ? qi[u] : 0;    // (always inside: the lookup wrote it; never an address from an unchecked word)
-      float v10[10];
-      load10(qry + 10 * (size_t)qi[u], v10);
-      const float x0 = pick10(v10, cp.dim[0]), x1 = pick10(v10, cp.dim[1]);
+      const float x0 = pick10(v10[u], cp.dim[0]), x1 = pick10(v10[u], cp.dim[1]);
       c0lo[u] = cell_of(x0 - cp.R, cp.lo[0], cp.scale[0], cp.nc[0]);
       c1lo[u] = cell_of(x1 - cp.R, cp.lo[1], cp.scale[1], cp.nc[1]);
       w0[u] = cell_of(x0 + cp.R, cp.lo[0], cp.scale[0], cp.nc[0]) - c0lo[u];
       w1[u] = cell_of(x1 + cp.R, cp.lo[1], cp.scale[1], cp.nc[1]) - c1lo[u];
-      c2[u] = cell_of(pick10(v10, cp.dim[2]), cp.lo[2], cp.scale[2], cp.nc[2]);
-      word[u] = filter_word(v10[0], v10[1], v10[2], v10[3], cp);
+      c2[u] = cell_of(pick10(v10[u], cp.dim[2]), cp.lo[2], cp.scale[2], cp.nc[2]);
+      word[u] = filter_word(v10[u][0], v10[u][1], v10[u][2], v10[u][3], cp);
     }
 #pragma unroll
     for (int i0 = 0; i0 < 3; ++i0)
