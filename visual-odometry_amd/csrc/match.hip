@@ -705,55 +705,61 @@ struct CellParams {
   int T;                   // SAD threshold
 };
 
-// s_lo / s_hi: per-component bounds in LDS (10 each); s_tmp: 16 floats of LDS scratch.  Indexed dynamically, hence in LDS:
-// private arrays would live in scratch memory.
-__device__ void make_cell_params(const float* s_lo, const float* s_hi, float* s_tmp, float radius, CellParams* out) {
-  float* span = s_tmp;                                   // [10]
-  for (int k = 0; k < 10; ++k) {
-    const float sp = s_hi[k] - s_lo[k];
-    span[k] = (sp < INFINITY) ? sp : -1.f;               // empty / infinite / NaN ranges rank last
+// The grid of a frame from the per-component bounds of its sample: called by ONE WHOLE WAVE, lane k < 10 bringing the bounds of
+// component k (the other lanes anything).  Everything is computed in every lane from values read across lanes -- the same
+// choices, in the same order, as a scalar loop over the components would make (the four largest spans, ties to the lower
+// component; the four largest among components 4..9 when none of them is flatter than half its counterpart) without one lane
+// walking LDS arrays.
+__device__ void make_cell_params_wave(float lo_k, float hi_k, float radius, CellParams* out) {
+  const int lane = threadIdx.x & 63;
+  const float sp0 = hi_k - lo_k;
+  const float span = (lane < 10 && sp0 < INFINITY) ? sp0 : -1.f;      // empty / infinite / NaN ranges rank last
+  // this component's place among all ten, and among components 4..9: descending span, ties to the lower index
+  int rank_all = 0, rank_tail = 0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const float si = __shfl(span, i);
+    const bool before = si > span || (si == span && i < lane);
+    rank_all += before ? 1 : 0;
+    rank_tail += (i >= 4 && before) ? 1 : 0;
   }
-  auto top4 = [&](int k0, int* o) {                      // indices of the four largest spans in [k0, 10), descending
-    unsigned used = 0;
-    for (int j = 0; j < HK; ++j) {
-      int best = -1;
-      for (int k = k0; k < 10; ++k)
-        if (!((used >> k) & 1u) && (best < 0 || span[k] > span[best])) best = k;
-      used |= 1u << best;
-      o[j] = best;
-    }
-  };
   int all4[HK], tail4[HK];
-  top4(0, all4);
-  top4(4, tail4);
   bool tail_ok = true;
 #pragma unroll
-  for (int j = 0; j < HK; ++j) tail_ok = tail_ok && span[tail4[j]] >= 0.5f * span[all4[j]];
+  for (int j = 0; j < HK; ++j) {
+    all4[j] = __ffsll((unsigned long long)__ballot(lane < 10 && rank_all == j)) - 1;
+    tail4[j] = __ffsll((unsigned long long)__ballot(lane >= 4 && lane < 10 && rank_tail == j)) - 1;
+    tail_ok = tail_ok && __shfl(span, tail4[j]) >= 0.5f * __shfl(span, all4[j]);
+  }
   CellParams cp;
   cp.R = radius * 1.001f;
 #pragma unroll
   for (int j = 0; j < HK; ++j) {
     const int k = tail_ok ? tail4[j] : all4[j];
-    const float sp = span[k];
+    const float sp = __shfl(span, k);
     int nc = 1;
     if (sp > 0.f && cp.R > 0.f) {
       const float f = sp / cp.R;
       nc = f >= (float)HNC ? HNC : (int)f;
       if (nc < 1) nc = 1;
     }
-    cp.dim[j] = k; cp.lo[j] = s_lo[k]; cp.nc[j] = nc;
+    cp.dim[j] = k; cp.lo[j] = __shfl(lo_k, k); cp.nc[j] = nc;
     cp.scale[j] = sp > 0.f ? (float)nc / sp : 0.f;       // cell width sp / nc >= R
   }
   // filter words: one scale for components 0..3 (the L1 bound needs a common unit), from their largest finite spread
   float wide = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { cp.qlo[k] = span[k] >= 0.f ? s_lo[k] : 0.f; wide = span[k] > wide ? span[k] : wide; }
+  for (int k = 0; k < 4; ++k) {
+    const float sk = __shfl(span, k);
+    cp.qlo[k] = sk >= 0.f ? __shfl(lo_k, k) : 0.f;
+    wide = sk > wide ? sk : wide;
+  }
   cp.qscale = wide > 0.f ? 255.f / wide : 0.f;
   {
     const float t = 2.f * cp.R * cp.qscale;              // NaN / inf / huge -> every word passes (1020 is the largest SAD)
     cp.T = (t >= 0.f && t < 1000.f) ? (int)t + 7 : 1020;
   }
-  *out = cp;
+  if (lane == 0) *out = cp;
 }
 
 __device__ __forceinline__ unsigned quant8(float x, float lo, float scale) {
@@ -912,20 +918,36 @@ __global__ __launch_bounds__(1024) void cell_bounds_kernel(CellArgs a) {
   const float* tree; const float* qry; int nt, nq;
   cell_sets(a, f, tree, qry, nt, nq);
   __shared__ float s_lo[16][10], s_hi[16][10];
-  __shared__ float s_flo[10], s_fhi[10], s_tmp[16];
   float lo[10], hi[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
   const int st_t = (nt + CELL_SAMPLE - 1) / CELL_SAMPLE, st_q = (nq + CELL_SAMPLE - 1) / CELL_SAMPLE;
   const int ns_t = st_t ? (nt + st_t - 1) / st_t : 0, ns_q = st_q ? (nq + st_q - 1) / st_q : 0;
-  for (int i = threadIdx.x; i < ns_t + ns_q; i += 1024) {
-    const float* row = i < ns_t ? tree + 10 * (size_t)i * st_t : qry + 10 * (size_t)(i - ns_t) * st_q;
-    const float2* p = reinterpret_cast<const float2*>(row);
+  // <= 2 CELL_SAMPLE rows over 1024 threads: all of a thread's rows requested before the first is used
+  constexpr int TRIPS = 2 * CELL_SAMPLE / 1024;
+  // A row as 16 + 16 + 8 bytes (8-byte aligned: the hardware takes a 16-byte load at any dword).  What bounds this kernel is
+  // the LINES it touches: 4096 sampled rows of 40 bytes per frame, each in a 128-byte line of its own (or two) -- 140 MB per
+  // 200 x 50k frames, 25 of its 30 us at the memory's rate.  (Requesting all rows at once, wider loads and the grid parameters
+  // computed across a wave instead of by one lane: 32.8 -> 30.2 us together.)
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+  typedef float f2u __attribute__((ext_vector_type(2), aligned(8)));
+  f4u va[TRIPS], vb[TRIPS];
+  f2u vc[TRIPS];
+  bool live[TRIPS];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const float2 v = p[k];
-      lo[2 * k] = fminf(lo[2 * k], v.x); hi[2 * k] = fmaxf(hi[2 * k], v.x);          // fmin/fmax drop NaNs
-      lo[2 * k + 1] = fminf(lo[2 * k + 1], v.y); hi[2 * k + 1] = fmaxf(hi[2 * k + 1], v.y);
+  for (int t = 0; t < TRIPS; ++t) {
+    const int i = threadIdx.x + t * 1024;
+    live[t] = i < ns_t + ns_q;
+    const int ic = live[t] ? i : 0;                        // (ns_t + ns_q > 0 whenever a frame gets here; row 0 of a set is valid)
+    const float* row = (ic < ns_t || ns_q == 0) ? tree + 10 * (size_t)(ns_t ? ic : 0) * st_t : qry + 10 * (size_t)(ic - ns_t) * st_q;
+    va[t] = *reinterpret_cast<const f4u*>(row); vb[t] = *reinterpret_cast<const f4u*>(row + 4); vc[t] = *reinterpret_cast<const f2u*>(row + 8);
+  }
+#pragma unroll
+  for (int t = 0; t < TRIPS; ++t) {
+    if (live[t]) {
+      const float r[10] = {va[t].x, va[t].y, va[t].z, va[t].w, vb[t].x, vb[t].y, vb[t].z, vb[t].w, vc[t].x, vc[t].y};
+#pragma unroll
+      for (int k = 0; k < 10; ++k) { lo[k] = fminf(lo[k], r[k]); hi[k] = fmaxf(hi[k], r[k]); }          // fmin/fmax drop NaNs
     }
   }
 #pragma unroll
@@ -939,16 +961,13 @@ __global__ __launch_bounds__(1024) void cell_bounds_kernel(CellArgs a) {
 #pragma unroll
     for (int k = 0; k < 10; ++k) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
   __syncthreads();
-  if (threadIdx.x < 10) {                                 // one component per thread over the 16 waves
-    const int k = threadIdx.x;
+  if (threadIdx.x < 64) {                                 // wave 0: lane k < 10 takes component k over the 16 waves, then the grid
+    const int k = threadIdx.x < 10 ? threadIdx.x : 0;
     float l = INFINITY, h = -INFINITY;
 #pragma unroll
     for (int w = 0; w < 16; ++w) { l = fminf(l, s_lo[w][k]); h = fmaxf(h, s_hi[w][k]); }
-    s_flo[k] = l; s_fhi[k] = h;
+    make_cell_params_wave(l, h, a.radius, reinterpret_cast<CellParams*>(a.ws + f * a.ws_stride + a.w.cp));
   }
-  __syncthreads();
-  if (threadIdx.x == 0)
-    make_cell_params(s_flo, s_fhi, s_tmp, a.radius, reinterpret_cast<CellParams*>(a.ws + f * a.ws_stride + a.w.cp));
 }
 
 // level 1: one pass.  a.tb workgroups per frame take the tree's slices, a.qb the queries'.  A workgroup reads its <= 1792
