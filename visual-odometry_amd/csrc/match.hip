@@ -925,10 +925,10 @@ __global__ __launch_bounds__(1024) void cell_bounds_kernel(CellArgs a) {
   const int ns_t = st_t ? (nt + st_t - 1) / st_t : 0, ns_q = st_q ? (nq + st_q - 1) / st_q : 0;
   // <= 2 CELL_SAMPLE rows over 1024 threads: all of a thread's rows requested before the first is used
   constexpr int TRIPS = 2 * CELL_SAMPLE / 1024;
-  // A row as 16 + 16 + 8 bytes (8-byte aligned: the hardware takes a 16-byte load at any dword).  What bounds this kernel is
-  // the LINES it touches: 4096 sampled rows of 40 bytes per frame, each in a 128-byte line of its own (or two) -- 140 MB per
-  // 200 x 50k frames, 25 of its 30 us at the memory's rate.  (Requesting all rows at once, wider loads and the grid parameters
-  // computed across a wave instead of by one lane: 32.8 -> 30.2 us together.)
+  // A row as 16 + 16 + 8 bytes (8-byte aligned: the hardware takes a 16-byte load at any dword).  4096 sampled rows per frame,
+  // each in a line of its own: 21 MB fetched per 200 x 50k frames (FETCH_SIZE), 13 us in a counter pass -- 30 under the kernel
+  // tracer, which is what requesting all rows at once, wider loads and the grid parameters computed across a wave instead of
+  // by one lane were measured against (32.8 -> 30.2 us together).
   typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
   typedef float f2u __attribute__((ext_vector_type(2), aligned(8)));
   f4u va[TRIPS], vb[TRIPS];
