@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--strong-pairs", type=int, default=1600,
                     help="frame pairs of the strong-scaling config-4 leg, sharded over the ranks (0: skip)")
     ap.add_argument("--strong-per-call", type=int, default=1600, help="frames per vo_frames_batch_dev call in that leg")
+    ap.add_argument("--open-shares", type=str, default="0.01,0.05,0.25",
+                    help="matcher stage of the 200-frame batch timed again with these shares of every frame's queries displaced "
+                         "(no bitwise copy in the tree); empty: skip (the counter passes of tools/collect_profiles.sh do)")
     ap.add_argument("--gen-workers", type=int, default=None, help="host processes generating the config-4 pairs (default: CPU share, <= 16)")
     return ap.parse_args()
 
@@ -487,10 +490,11 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
     # exact-duplicate pass leaves them open; up to nq / 16 of them per frame have the tree streamed past them, more go to the
     # sorted search): the synthetic pairs of this leg have none, so the stage's time above is its best case
     by_share = None
-    if dist is None and (frames, args.points) == (200, 50000):
+    shares = sorted(float(x) for x in args.open_shares.split(",") if x.strip())
+    if dist is None and (frames, args.points) == (200, 50000) and shares:
         by_share = {"0": match_ms}
         done = 0.0
-        for share in (0.01, 0.05, 0.25):
+        for share in shares:
             bp.perturb_cur_app(share - done, seed=int(share * 1000))     # (rows drawn anew: the shares add up, a few rows twice)
             done = share
             bp.match_only(); ctx.synchronize()

@@ -64,7 +64,7 @@ if call:
     call["note"] = ("sum over the kernels of one vo_frames_batch_dev call (200 frames x 50k); FETCH_SIZE doubled for the "
                     "batched solver (16-B/lane streaming loads), counted as reported for the rest (mixed widths: uncalibrated)")
 json.dump({"batched_frames_call": call, "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 5 "
-                      "--warmup 1 --legs frame,batched --frame-steps 3 --strong-pairs 0 --gen-workers 1   (one pass per counter; tools/collect_profiles.sh)",
+                      "--warmup 1 --legs frame,batched --frame-steps 3 --strong-pairs 0 --open-shares "" --gen-workers 1   (one pass per counter; tools/collect_profiles.sh)",
            "units": "FETCH_SIZE / WRITE_SIZE are KB.  gfx950: FETCH_SIZE counts exactly half the bytes of wide (16 B/lane) "
                     "coalesced streaming reads (MI355X_MICROARCH.md, HBM) -> doubled where wide_16B_loads is true; other "
                     "access widths are uncalibrated and reported as counted",
@@ -73,7 +73,7 @@ json.dump({"batched_frames_call": call, "command": "rocprofv3 --kernel-trace --p
 vf = glob.glob(f"{src}/VALU/*/*counter_collection.csv")
 if vf:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(vf[0])):
+    for r in csv.DictReader(open(max(vf, key=os.path.getmtime))):       # (the latest run's file, like newest())
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if not name.startswith("vo::"):
             continue
