@@ -1749,7 +1749,10 @@ __global__ __launch_bounds__(HJ_THREADS) void hash_table_kernel(HashArgs a) {
   const bool drop = filled > a.qcap || s_ovf != 0;
   uint4* dst = reinterpret_cast<uint4*>(a.tables + f * a.tables_stride + ((size_t)part << LOG2S));
   const uint4 none = make_uint4(HJ_EMPTY, HJ_EMPTY, HJ_EMPTY, HJ_EMPTY);
-  for (unsigned k = tid; k < S / 4; k += HJ_THREADS) dst[k] = drop ? none : reinterpret_cast<const uint4*>(s_tab)[k];
+  // (two loops: a select between the constant and the LDS word made the compiler park the constant in scratch memory and fetch
+  // either through a flat load, waiting for it in every pass)
+  if (drop) { for (unsigned k = tid; k < S / 4; k += HJ_THREADS) dst[k] = none; }
+  else { for (unsigned k = tid; k < S / 4; k += HJ_THREADS) dst[k] = reinterpret_cast<const uint4*>(s_tab)[k]; }
 }
 
 // step 3: the lookup, in query order.  A query's chain is three dependent round trips -- its row, its table word, the
