@@ -470,7 +470,9 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
     bp = vo.BatchPipeline(ctx, gen, n_iters=args.iters, poses_ptr=poses_t.data_ptr(), n_frames=frames, upload_block=50)
     bp.run()
     ctx.synchronize()
-    sec, all_poses = _timed_batches(torch, ctx, bp, poses_t, dist, vdist, 3)
+    # ten calls between the barriers: the bracket itself (barrier, synchronize, the host waking up) is ~0.3 ms -- over three calls
+    # of 2.6 ms it read as 0.13 ms per call (event time 2.56 against 2.69 ms wall)
+    sec, all_poses = _timed_batches(torch, ctx, bp, poses_t, dist, vdist, 10)
     if dist is not None:
         assert all_poses.shape == (world * frames, 16)
         assert torch.equal(all_poses[rank * frames:(rank + 1) * frames], poses_t)
@@ -493,6 +495,12 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
     shares = sorted(float(x) for x in args.open_shares.split(",") if x.strip())
     if dist is None and (frames, args.points) == (200, 50000) and shares:
         by_share = {"0": match_ms}
+        e0.record(stream)
+        for _ in range(3):
+            bp.run()
+        e1.record(stream)
+        ctx.synchronize()
+        call_by_share = {"0": e0.elapsed_time(e1) / 3}        # (event time like the rest of this table: ms_per_batch above is wall time with the step's barriers)
         done = 0.0
         for share in shares:
             bp.perturb_cur_app(share - done, seed=int(share * 1000))     # (rows drawn anew: the shares add up, a few rows twice)
@@ -505,8 +513,16 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
             ctx.synchronize()
             by_share[f"{share:g}"] = e0.elapsed_time(e1) / 3
             assert int(bp.counts()[0].min()) > 0.99 * args.points       # (displaced by sigma 0.005: still inside the radius 0.1)
+            bp.run(); ctx.synchronize()                                 # ... and the whole call on the same frames
+            e0.record(stream)
+            for _ in range(3):
+                bp.run()
+            e1.record(stream)
+            ctx.synchronize()
+            call_by_share[f"{share:g}"] = e0.elapsed_time(e1) / 3
         by_share["note"] = ("matcher stage alone, ms per 200 x 50k frames, by the share of every frame's queries displaced so that "
                             "they have no bitwise copy in the tree (still matched: by the search)")
+        by_share["whole_call_ms"] = call_by_share
     bp.close()
     alg = _frame_alg_bytes(args.points, args.iters) * frames
     gbs = alg / sec / 1e9
@@ -544,7 +560,7 @@ def frame_throughput_strong(vo, torch, ctx, stream, args, dist=None, vdist=None,
     t_setup = time.perf_counter() - t0
     bp.run()
     ctx.synchronize()
-    sec, all_poses = _timed_batches(torch, ctx, bp, poses_t, dist, vdist, 2)
+    sec, all_poses = _timed_batches(torch, ctx, bp, poses_t, dist, vdist, 4)
     if dist is not None:
         assert all_poses.shape == (world * blk, 16)
         r0, r1 = plan.own_rows()
