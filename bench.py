@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--batch-pairs", type=int, default=200, help="problems of the batched-solver leg (0: skip)")
-    ap.add_argument("--frame-steps", type=int, default=30, help="frames of the whole-frame leg (0: skip)")
+    ap.add_argument("--frame-steps", type=int, default=100, help="frames of the whole-frame leg (0: skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU-baseline leg (0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="headline measurement only")
     ap.add_argument("--legs", default=None,
