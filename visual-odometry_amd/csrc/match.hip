@@ -293,7 +293,10 @@ __device__ BucketParams make_bucket_params(const unsigned* __restrict__ mm, floa
 //   place   : every workgroup ranks its points inside a bin with LDS atomics
 //             and writes 48-B records (10 components, original index, bucket)
 // The order inside a bucket is arbitrary; nothing downstream depends on it.
-constexpr int SORT_BLOCKS = 32;
+#ifndef VO_SORT_BLOCKS
+#define VO_SORT_BLOCKS 32
+#endif
+constexpr int SORT_BLOCKS = VO_SORT_BLOCKS;          // (one 50k frame's matcher: 16 / 24 / 32 / 64 / 128 workgroups -> 88 / 80 / 76 / 92 / 131 us)
 
 __device__ __forceinline__ void sort_slice(int nt, int nq, int& lo, int& hi) {
   const int total = nt + nq;
