@@ -246,3 +246,32 @@ def test_few_open_queries_have_the_tree_streamed_past_them(vo, o32):
     for k in range(len(a1)):
         assert np.array_equal(got[k], o32.match(a1[k], a2[k])), k
     c3.close(); c5.close()
+
+
+def test_frames_without_copies_skip_the_pass(vo, o32):
+    """hash_rows_kernel looks for eight sampled queries of a frame (positions k * (nq >> 3)) while the tree streams past; a
+    frame in which none is found builds no table and looks nothing up.  Whatever it decides, the pairs are the search's: data
+    without any copy; copies only at positions the sample does not look at (the pass is skipped although it would have found
+    them); a copy only at a sampled position; fewer than eight queries; the same in one ragged batch, either image the tree."""
+    rng = np.random.default_rng(61)
+    c3, c5 = _ctxs(vo, (3, 5))
+    n = 6000
+    tree = rng.uniform(-1, 1, (n, 10)).astype(np.float32)
+    near = (tree[rng.permutation(n)][:5200] + rng.normal(0, 0.004, (5200, 10))).astype(np.float32)     # no bitwise copy anywhere
+    sampled = np.arange(8) * (5200 >> 3)
+    only_unsampled = near.copy()
+    rest = np.setdiff1d(np.arange(5200), sampled)
+    only_unsampled[rest[:3000]] = tree[rng.permutation(n)[:3000]]                                      # copies, none at a sampled position
+    only_sampled = near.copy(); only_sampled[sampled[3]] = tree[77]
+    tiny = tree[[5, 9, 11, 200, 4000]].copy(); tiny[1] += np.float32(0.003)
+    cases = [(tree, near), (tree, only_unsampled), (tree, only_sampled), (tree, tiny), (tree[:40], tree[:40][::-1].copy())]
+    for a, b in cases:
+        exp = o32.match(a, b)
+        for c in (c3, c5):
+            assert np.array_equal(vo.compute_correspondences_images(a, b, ctx=c), exp)
+            assert np.array_equal(vo.compute_correspondences_images(b, a, ctx=c), o32.match(b, a))
+    a1 = [c[k % 2] for k, c in enumerate(cases)]; a2 = [c[1 - k % 2] for k, c in enumerate(cases)]
+    got = vo.match_batch_ragged(c5, a1, a2)
+    for k in range(len(cases)):
+        assert np.array_equal(got[k], o32.match(a1[k], a2[k])), k
+    c3.close(); c5.close()
