@@ -993,7 +993,14 @@ static int match_variant(const vo_ctx* c, int nt, int nq, int n_frames) {
     if (m == 3 && !cells_ok) m = 2;
     return (hash && match_hash_supported(nt, n_frames)) ? m + 2 : m;
   }
-  if ((double)nt * (double)nq < 4.0e6) return 1;
+  // the full scan: below ~4 M candidate pairs per frame whatever the frame count, and -- a call of one or a few frames, whose
+  // sorted searches are a chain of ~8 small launches (45 us) -- up to 1e8 pairs in the whole call: one frame of up to ~10 000 x
+  // 10 000 points (measured, one frame, full scan against the sorted searches: 5000: 30 / 46 us, 8500: 36 / 48, 10 000: 42 / 49,
+  // 12 000: 60 / 49; tools/match_sizes.py)
+  {
+    const double pairs = (double)nt * (double)nq;
+    if (pairs < 4.0e6 || pairs * (double)(n_frames > 0 ? n_frames : 1) < 1.0e8) return 1;
+  }
   static const int forced = [] { const char* e = getenv("VO_MATCH_AUTO"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 3) ? v : 0; }();
   if (forced) return with_hash((forced == 3 && !cells_ok) ? 2 : forced, nt, n_frames);
   return with_hash((n_frames >= 8 && cells_ok) ? 3 : 2, nt, n_frames);
