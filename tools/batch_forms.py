@@ -13,7 +13,8 @@ N = int(os.environ.get("N", "50000")); ITERS = 50
 fp = vo.synth.frame_pair(N, seed=2000)
 corr = np.stack([fp["gt_matches"][:, 1], fp["gt_matches"][:, 0]], 1).astype(np.int32)
 K = np.ascontiguousarray(fp["K"].T.reshape(-1), np.float32)
-for FORM, P in [(f, p) for f in (1, 2, 0) for p in (1, 2, 4, 8, 16, 32, 48, 64, 96, 128, 200)]:
+PS = [int(x) for x in os.environ.get("PS", "1,2,4,8,16,32,48,64,96,128,200").split(",")]
+for FORM, P in [(f, p) for f in (1, 2, 0) for p in PS]:
     form = {1: "launch per round ", 2: "one WG per problem", 0: "auto              "}[FORM]
     assert ctx.lib.vo_picp_batch_set_form(ctx.h, FORM) == 0
     d_world = ctx.to_device(np.tile(fp["model"], (P, 1))); d_meas = ctx.to_device(np.tile(fp["cur_pts"], (P, 1)))
