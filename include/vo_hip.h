@@ -138,14 +138,23 @@ int vo_picp_set_kernel_threshold(vo_picp *s, float thr);        /* picp_solver.h
 int vo_picp_get_kernel_threshold(vo_picp *s, float *thr);       /* picp_solver.h:33 */
 /* oneRound(correspondences, keep_outliers) (picp_solver.cpp:98-112):
  * pairs = (measurement index, world index).  Enqueues one Gauss-Newton
- * iteration and returns without waiting; the pose/statistics getters are the
- * synchronisation points.  Like the reference (picp_solver.cpp:62) every call
- * honours the array it is given: the pairs are compared IN FULL with the copy
- * already on the GPU (memcmp, ~15 us per 50k pairs) and uploaded again when
- * anything differs, so editing the vector in place between two rounds is seen.
- * As in the reference it cannot fail on "too few inliers" (min_num_inliers is
- * 0 with no setter). */
+ * iteration -- ONE kernel launch -- and returns without waiting; the
+ * pose/statistics getters are the synchronisation points, and the first of
+ * them after a run of calls enqueues the launch that finishes the last round
+ * (its 6x6 solve, H, b, statistics): a loop of oneRound calls followed by
+ * camera(), as vo_complete.cpp:163-168, costs one launch per call plus one.
+ * Like the reference (picp_solver.cpp:62) every call honours the array it is
+ * given: the pairs are compared IN FULL (memcmp) with the host copy of what is
+ * on the GPU and uploaded again when anything differs, so editing the vector in
+ * place between two rounds is seen.  When the array has the length of the
+ * packed one the round is enqueued first and the comparison runs while the GPU
+ * works; a difference then repeats that round on the new pairs (it had written
+ * nothing a repeat does not overwrite).  As in the reference it cannot fail on
+ * "too few inliers" (min_num_inliers is 0 with no setter). */
 int vo_picp_one_round(vo_picp *s, const int32_t *pairs, int n_pairs, int keep_outliers);
+/* Bookkeeping of the above (any pointer may be NULL): rounds enqueued whose finishing launch is still to come, calls
+ * enqueued ahead of their comparison since the handle was made, and how many of those had to be repeated. */
+int vo_picp_chain_info(vo_picp *s, int *open_rounds, unsigned long long *speculative, unsigned long long *repeated);
 /* n_iters x oneRound with no host round trip in between */
 int vo_picp_solve(vo_picp *s, const int32_t *pairs, int n_pairs, int keep_outliers, int n_iters);
 /* Explicit form of the same, for callers that iterate on one fixed set: hand the pairs over once
@@ -178,7 +187,8 @@ int vo_picp_solve_dev(vo_picp *s, const int32_t *d_pairs, int n_pairs, const int
 int vo_picp_get_pose(vo_picp *s, float T[16]);                  /* camera(), picp_solver.h:41 */
 int vo_picp_get_pose_dev(vo_picp *s, float *d_T16);             /* async copy on the stream */
 /* device address of the solver's own 4x4 pose (column-major), valid for the life of the
- * handle and rewritten by every solve: lets a consumer kernel read the result in place */
+ * handle and rewritten by every solve: lets a consumer kernel read the result in place
+ * (rounds of vo_picp_one_round reach it with the next getter call -- this one included) */
 int vo_picp_pose_dev_ptr(vo_picp *s, const float **d_T16);
 int vo_picp_get_stats(vo_picp *s, float *chi_inliers, float *chi_outliers, int *num_inliers); /* :44-50 */
 /* H (6x6 col-major, damping included, as _H after oneRound) and b of the last round */

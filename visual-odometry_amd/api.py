@@ -260,6 +260,13 @@ class PICPSolver:
         _chk(self.lib.vo_picp_graph_info(self.h, C.byref(u), C.byref(n), C.byref(f)))
         return u.value, n.value, f.value
 
+    def chainInfo(self):
+        """(rounds whose finishing launch is still to come, oneRound calls enqueued ahead of their comparison, how many
+        of those were repeated): vo_picp_chain_info"""
+        o, a, b = C.c_int(), C.c_ulonglong(), C.c_ulonglong()
+        _chk(self.lib.vo_picp_chain_info(self.h, C.byref(o), C.byref(a), C.byref(b)))
+        return o.value, a.value, b.value
+
     def setCorrespondences(self, correspondences):
         p = _i32pairs(correspondences)
         _chk(self.lib.vo_picp_set_correspondences(self.h, _ptr(p), C.c_int(len(p))))

@@ -162,6 +162,11 @@ struct vo_picp {
   int grid = 1;
   const float* pending_T0 = nullptr;   // device 4x4 to load as the pose by the next pack launch
   int zeroed_for_grid = -1;   // grid the (zero-padded) partial buffers were last cleared for
+  // Rounds enqueued since the state (pose[0], T16, H, b, statistics) was last complete: vo_picp_one_round enqueues ONE
+  // launch per call and leaves the finishing launch to whoever needs the state next (a getter, a setter, a multi-round
+  // solve): picp_flush.  0 = the state is complete.
+  int chain_len = 0;
+  unsigned long long spec_rounds = 0, spec_redone = 0;   // one_round calls enqueued before their comparison / found different
   int use_graph = 1;
   int graph_failures = 0;     // captures that failed (the handle then stays on plain launches): vo_picp_graph_info
   std::map<std::tuple<int, int, const void*, size_t, const void*, int>, hipGraphExec_t> graphs;
@@ -169,6 +174,18 @@ struct vo_picp {
 
 static int set_device(vo_ctx* ctx) {
   VO_HIP_CHECK(hipSetDevice(ctx->device));
+  return VO_OK;
+}
+
+// the finishing launch of the rounds vo_picp_one_round has enqueued so far (vo_picp::chain_len), if any
+static int picp_flush(vo_picp* s) {
+  if (s->chain_len == 0) return VO_OK;
+  vo_ctx* c = s->ctx;
+  if (c->capturing)
+    return fail(VO_ERR_NOT_READY, "vo_picp: rounds of vo_picp_one_round are still open (read the pose or the statistics once before the capture)");
+  PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
+  VO_HIP_CHECK(launch_picp_finish(c->stream, s->d_params, s->d_state, pk, s->partials.as<float>(), s->grid, s->chain_len));
+  s->chain_len = 0;
   return VO_OK;
 }
 
@@ -504,6 +521,7 @@ int vo_picp_set_pose(vo_picp* s, const float T[16]) {
   for (int i = 0; i < 9; ++i) pose[i] = P.R[i];
   for (int i = 0; i < 3; ++i) pose[9 + i] = P.t[i];
   s->pending_T0 = nullptr;
+  if (int r = picp_flush(s)) return r;     // open rounds first: H, b and the statistics stay those of the last round
   VO_HIP_CHECK(hipMemcpyAsync(s->d_state->pose[0], pose, sizeof(pose), hipMemcpyHostToDevice,
                               s->ctx->stream));
   VO_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));   // `pose` is a stack buffer
@@ -583,7 +601,12 @@ static int picp_prepare(vo_picp* s, const int32_t* d_pairs, int n_pairs, const i
   if (!s->packed_valid) {
     const size_t cap = ((size_t)(n_pairs > 0 ? n_pairs : 1) + 3) & ~(size_t)3;
     VO_HIP_CHECK(s->packed.ensure(sizeof(float) * 5 * cap, c->stream));
-    s->grid = picp_grid_for(n_pairs, c->n_cu);
+    {
+      // open rounds read the partial rows of their predecessor at the chain's grid: another grid closes the chain first
+      const int g = picp_grid_for(n_pairs, c->n_cu);
+      if (g != s->grid) { if (int r = picp_flush(s)) return r; }
+      s->grid = g;
+    }
     {
       // two buffers of round_up(grid,256) rows; rows >= grid are never written and must read as zero
       const size_t rows = ((size_t)s->grid + 255) & ~(size_t)255;
@@ -608,8 +631,23 @@ static int picp_prepare(vo_picp* s, const int32_t* d_pairs, int n_pairs, const i
   return VO_OK;
 }
 
-static int picp_enqueue(vo_picp* s, int n_iters) {
+static bool picp_chainable(const vo_picp* s) { return !s->exact && !s->ctx->capturing && picp_rounds_chain(s->grid); }
+
+// one round of the open chain; `count` = false: a speculative launch the caller may have to repeat (vo_picp_solve)
+static int picp_enqueue_chain_round(vo_picp* s, bool count) {
   vo_ctx* c = s->ctx;
+  PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
+  VO_HIP_CHECK(launch_picp_chain_round(c->stream, s->d_params, s->d_state, pk, s->partials.as<float>(), s->grid, s->chain_len,
+                                       is_pinhole(s->hp.cam.K), s->hp.keep_outliers != 0));
+  if (count) ++s->chain_len;
+  return VO_OK;
+}
+
+// lazy: a single round may stay open (no finishing launch) -- host entry points only, whose getters close it
+static int picp_enqueue(vo_picp* s, int n_iters, bool lazy = false) {
+  vo_ctx* c = s->ctx;
+  if (lazy && n_iters == 1 && picp_chainable(s)) return picp_enqueue_chain_round(s, true);
+  if (n_iters > 0) { if (int r = picp_flush(s)) return r; }
   PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
   float* partials = s->partials.as<float>();
   const bool pinhole = is_pinhole(s->hp.cam.K), keep = s->hp.keep_outliers != 0;
@@ -667,6 +705,7 @@ int vo_picp_solve_dev(vo_picp* s, const int32_t* d_pairs, int n_pairs, const int
   VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || d_pairs), "bad pairs");
   VO_REQUIRE(n_iters >= 0, "negative n_iters");
   if (int r = set_device(s->ctx)) return r;
+  if (int r = picp_flush(s)) return r;     // rounds left open by vo_picp_one_round: closed before this solve's launches
   // device pairs may have been rewritten in place by the producer: always re-pack
   s->packed_valid = false;
   s->shadow_valid = false;
@@ -699,12 +738,26 @@ int vo_picp_solve(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_outlie
   VO_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || pairs), "bad pairs");
   VO_REQUIRE(n_iters >= 0, "negative n_iters");
   if (int r = set_device(s->ctx)) return r;
+  // ONE round on an array that is probably the one already packed -- the reference's own loop, vo_complete.cpp:163-164:
+  // a hundred oneRound calls on one vector -- is enqueued BEFORE the comparison, which then runs while the GPU works.
+  // Should the array differ after all, the new pairs are uploaded and packed and the SAME round is enqueued again: the
+  // speculative launch has written nothing but the partial rows and the pose slot of its own round index (from the state
+  // its predecessor left, which it does not touch), and the repeat overwrites both.
+  const size_t words = 2 * (size_t)n_pairs;
+  if (n_iters == 1 && s->packed_valid && s->shadow_valid && s->shadow.size() == words && s->have_points &&
+      s->hp.keep_outliers == (keep_outliers ? 1 : 0) && !s->params_dirty && picp_chainable(s)) {
+    if (int r = picp_prepare(s, s->pairs_own.as<int32_t>(), n_pairs, nullptr, keep_outliers)) return r;   // (a pending pose only)
+    if (int r = picp_enqueue_chain_round(s, false)) return r;
+    ++s->spec_rounds;
+    if (words == 0 || memcmp(s->shadow.data(), pairs, sizeof(int32_t) * words) == 0) { ++s->chain_len; s->set_n = n_pairs; return VO_OK; }
+    ++s->spec_redone;
+  }
   if (int r = picp_take_pairs(s, pairs, n_pairs)) return r;
   // pairs_own / shadow now hold THIS array: a later vo_picp_rounds continues on it (not on a stale count from an earlier
   // vo_picp_set_correspondences, which would re-pack a mix of both arrays once set_points invalidated the packing)
   s->set_n = n_pairs;
   if (int r = picp_prepare(s, s->pairs_own.as<int32_t>(), n_pairs, nullptr, keep_outliers)) return r;
-  return picp_enqueue(s, n_iters);
+  return picp_enqueue(s, n_iters, true);
 }
 
 int vo_picp_one_round(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_outliers) {
@@ -732,7 +785,7 @@ int vo_picp_rounds(vo_picp* s, int keep_outliers, int n_iters) {
     return fail(VO_ERR_NOT_READY, "vo_picp_rounds: vo_picp_set_correspondences has not been called");
   if (int r = set_device(s->ctx)) return r;
   if (int r = picp_prepare(s, s->pairs_own.as<int32_t>(), s->set_n, nullptr, keep_outliers)) return r;
-  return picp_enqueue(s, n_iters);
+  return picp_enqueue(s, n_iters, true);
 }
 
 int vo_picp_graph_info(vo_picp* s, int* use_graph, int* n_graphs, int* n_failures) {
@@ -743,14 +796,27 @@ int vo_picp_graph_info(vo_picp* s, int* use_graph, int* n_graphs, int* n_failure
   return VO_OK;
 }
 
+int vo_picp_chain_info(vo_picp* s, int* open_rounds, unsigned long long* speculative, unsigned long long* repeated) {
+  VO_REQUIRE(s, "null argument");
+  if (open_rounds) *open_rounds = s->chain_len;
+  if (speculative) *speculative = s->spec_rounds;
+  if (repeated) *repeated = s->spec_redone;
+  return VO_OK;
+}
+
 int vo_picp_set_exact(vo_picp* s, int on) {
   VO_REQUIRE(s, "null argument");
   VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
+  if ((on ? 1 : 0) != s->exact) {          // open rounds belong to the arithmetic they were enqueued in
+    if (int r = set_device(s->ctx)) return r;
+    if (int r = picp_flush(s)) return r;
+  }
   s->exact = on ? 1 : 0;
   return VO_OK;
 }
 
 static int picp_read_state(vo_picp* s, PicpState* h) {
+  if (int r = picp_flush(s)) return r;
   VO_HIP_CHECK(hipMemcpyAsync(h, s->d_state, sizeof(PicpState), hipMemcpyDeviceToHost, s->ctx->stream));
   VO_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));
   if (h->n_bad > 0)
@@ -776,6 +842,7 @@ int vo_picp_set_pose_dev(vo_picp* s, const float* d_T16) {
   VO_REQUIRE(s && d_T16, "null argument");
   VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   // consumed by the next solve: folded into its gather launch (or a 12-thread launch of its own)
+  if (s->chain_len) { if (int r = set_device(s->ctx)) return r; if (int r = picp_flush(s)) return r; }
   s->pending_T0 = d_T16;
   return VO_OK;
 }
@@ -783,6 +850,7 @@ int vo_picp_set_pose_dev(vo_picp* s, const float* d_T16) {
 int vo_picp_pose_dev_ptr(vo_picp* s, const float** d_T16) {
   VO_REQUIRE(s && d_T16, "null argument");
   VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
+  if (s->chain_len) { if (int r = set_device(s->ctx)) return r; if (int r = picp_flush(s)) return r; }
   *d_T16 = s->d_state->T16;
   return VO_OK;
 }
@@ -803,6 +871,7 @@ int vo_picp_get_pose_dev(vo_picp* s, float* d_T16) {
   VO_REQUIRE(s && d_T16, "null argument");
   VO_REQUIRE(ctx_alive(s->ctx, s->ctx_id), "the context this solver was made on has been destroyed");
   if (int r = set_device(s->ctx)) return r;
+  if (int r = picp_flush(s)) return r;
   hipLaunchKernelGGL(pose12_to_T16_kernel, dim3(1), dim3(64), 0, s->ctx->stream, s->d_state->pose[0], d_T16);
   VO_HIP_CHECK(hipGetLastError());
   return VO_OK;
@@ -824,6 +893,7 @@ int vo_picp_get_stats(vo_picp* s, float* chi_in, float* chi_out, int* n_in) {
 #ifdef VO_STAMPS
 // diagnostic build only: copies the s_memtime stamps of the last solve (128 rounds x 8 stamps)
 int vo_debug_get_stamps(vo_picp* s, unsigned long long* out) {
+  if (int r = picp_flush(s)) return r;
   PicpState h;
   VO_HIP_CHECK(hipMemcpyAsync(&h, s->d_state, sizeof(PicpState), hipMemcpyDeviceToHost, s->ctx->stream));
   VO_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));

@@ -612,6 +612,38 @@ static void launch_rounds_t(hipStream_t st, const PicpParams* d_params, PicpStat
                      d_state, pk.base, pk.cap, d_partials, n_iters, grid);
 }
 
+// ---- a chain of rounds without its finishing launch (vo_picp_one_round, capi.hip) ------------------------------------
+// The reference's own loop (vo_complete.cpp:163-164) calls oneRound a hundred times and reads the camera afterwards.  Round
+// `it` of a chain is ONE launch: it derives its pose from the partial rows of round it - 1 (it = 0: from the finished state)
+// exactly as the rounds inside launch_picp_rounds do; the FINISH launch -- the last solve, H, b, statistics, T16 -- is
+// enqueued by launch_picp_finish when somebody needs the state.  Same kernels, same order: the same bits as one
+// launch_picp_rounds call of as many rounds.
+bool picp_rounds_chain(int grid) { return !(grid == 1 && picp_small_enabled()); }
+
+hipError_t launch_picp_chain_round(hipStream_t st, const PicpParams* d_params, PicpState* d_state, PackedCorr pk,
+                                   float* d_partials, int grid, int it, bool pinhole, bool keep_outliers) {
+  const dim3 g(grid), b(PICP_BLOCK);
+#define VO_CHAIN_LAUNCH(PRE, PH, KP) \
+  hipLaunchKernelGGL((picp_round_kernel<PRE, false, PH, KP>), g, b, 0, st, d_params, d_state, pk.base, pk.cap, d_partials, it, grid)
+  if (it > 0) {
+    if (pinhole) { if (keep_outliers) VO_CHAIN_LAUNCH(true, true, true); else VO_CHAIN_LAUNCH(true, true, false); }
+    else { if (keep_outliers) VO_CHAIN_LAUNCH(true, false, true); else VO_CHAIN_LAUNCH(true, false, false); }
+  } else {
+    if (pinhole) { if (keep_outliers) VO_CHAIN_LAUNCH(false, true, true); else VO_CHAIN_LAUNCH(false, true, false); }
+    else { if (keep_outliers) VO_CHAIN_LAUNCH(false, false, true); else VO_CHAIN_LAUNCH(false, false, false); }
+  }
+#undef VO_CHAIN_LAUNCH
+  return hipGetLastError();
+}
+
+// closes a chain of `n_rounds` rounds (the state is then what launch_picp_rounds(n_rounds) leaves)
+hipError_t launch_picp_finish(hipStream_t st, const PicpParams* d_params, PicpState* d_state, PackedCorr pk,
+                              float* d_partials, int grid, int n_rounds) {
+  hipLaunchKernelGGL((picp_round_kernel<true, true, false, false>), dim3(1), dim3(PICP_BLOCK), 0, st, d_params, d_state,
+                     pk.base, pk.cap, d_partials, n_rounds, grid);
+  return hipGetLastError();
+}
+
 hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpState* d_state,
                               PackedCorr pk, float* d_partials, int grid, int n_iters, bool pinhole,
                               bool keep_outliers) {

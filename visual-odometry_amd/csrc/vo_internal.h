@@ -80,6 +80,15 @@ hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpSt
 
 int picp_grid_for(int n_corr, int n_cu);
 
+// A chain of rounds whose finishing launch is deferred (vo_picp_one_round): round `it` is one launch; launch_picp_finish
+// closes a chain of n_rounds.  picp_rounds_chain(grid): false when launch_picp_rounds runs this size as ONE launch anyway
+// (a single workgroup: picp_small_kernel), which leaves nothing to defer.
+bool picp_rounds_chain(int grid);
+hipError_t launch_picp_chain_round(hipStream_t st, const PicpParams* d_params, PicpState* d_state, PackedCorr pk,
+                                   float* d_partials, int grid, int it, bool pinhole, bool keep_outliers);
+hipError_t launch_picp_finish(hipStream_t st, const PicpParams* d_params, PicpState* d_state, PackedCorr pk,
+                              float* d_partials, int grid, int n_rounds);
+
 // Reference-order solver (bit-identical to the reference's scalar arithmetic): n_iters rounds in one launch of one
 // workgroup; reads the packed correspondences and P->n_corr, leaves pose / T16 / H / b / statistics in *d_state.
 hipError_t launch_picp_exact(hipStream_t st, const PicpParams* d_params, PicpState* d_state, PackedCorr pk,
