@@ -112,15 +112,34 @@ int main(int argc, char** argv) {
     const double solve_us = us(t0, t1);
     verify("solve");
 
+    // (4) the explicit hand-over: pairs given once, rounds with no comparison at all (what a call costs without it)
+    check(vo_picp_set_correspondences(solver.handle(), pair_data(corr), n), "vo_picp_set_correspondences");
+    double rcalls_us = 0;
+    auto rounds_step = [&](bool timed) {
+      check(vo_picp_set_pose(solver.handle(), I.data()), "vo_picp_set_pose");
+      const auto a = clk::now();
+      for (int i = 0; i < rounds; ++i) check(vo_picp_rounds(solver.handle(), 0, 1), "vo_picp_rounds");
+      const auto b = clk::now();
+      (void)solver.camera();
+      if (timed) rcalls_us += us(a, b);
+    };
+    for (int s = 0; s < warmup; ++s) rounds_step(false);
+    t0 = clk::now();
+    for (int s = 0; s < steps; ++s) rounds_step(true);
+    t1 = clk::now();
+    const double rounds_us = us(t0, t1);
+    verify("rounds_call");
+
     const double iters = (double)steps * rounds;
     std::printf("{\"points\": %d, \"rounds_per_step\": %d, \"steps\": %d, \"warmup\": %d, "
                 "\"loop\": {\"iters_per_sec\": %.1f, \"us_per_round\": %.3f, \"host_us_per_call\": %.3f, \"ms_per_step\": %.4f}, "
                 "\"with_init\": {\"iters_per_sec\": %.1f, \"us_per_round\": %.3f, \"ms_per_step\": %.4f}, "
                 "\"solve_call\": {\"iters_per_sec\": %.1f, \"us_per_round\": %.3f, \"ms_per_step\": %.4f}, "
+                "\"rounds_call\": {\"iters_per_sec\": %.1f, \"us_per_round\": %.3f, \"host_us_per_call\": %.3f}, "
                 "\"speculative_calls\": %llu, \"repeated_calls\": %llu, \"ok\": %s}\n",
                 n, rounds, steps, warmup, iters / loop_us * 1e6, loop_us / iters, calls_us / iters, loop_us / steps * 1e-3,
                 iters / init_us * 1e6, init_us / iters, init_us / steps * 1e-3, iters / solve_us * 1e6, solve_us / iters,
-                solve_us / steps * 1e-3, spec, redone, ok ? "true" : "false");
+                solve_us / steps * 1e-3, iters / rounds_us * 1e6, rounds_us / iters, rcalls_us / iters, spec, redone, ok ? "true" : "false");
     return ok ? 0 : 1;
   } catch (const vo::Error& e) {
     std::fprintf(stderr, "one_round_rate: %s\n", e.what());

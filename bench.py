@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU-baseline leg (0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="headline measurement only")
     ap.add_argument("--legs", default=None,
-                    help="extra legs to run (comma list of frame,batched,sequence,cpu); default: all four on one "
+                    help="extra legs to run (comma list of frame,batched,sequence,cpu,api); default: all five on one "
                          "GPU, only `frame` (the sharded config-4 leg) when several ranks run")
     ap.add_argument("--seq-frames", type=int, default=200, help="frames of the sequence leg (config 3)")
     ap.add_argument("--seq-points", type=int, default=50000, help="landmarks in view per frame in the sequence leg")
@@ -102,7 +102,7 @@ def main():
     rank, local_rank, world = vdist.env_rank_world()
     # host processes that generate the synthetic pairs of the config-4 legs: forked now, while this process is
     # still clean (no torch, no HIP call)
-    want_legs = set() if args.no_extras else set((args.legs or ("frame,batched,sequence,cpu" if world == 1 else "frame")).split(","))
+    want_legs = set() if args.no_extras else set((args.legs or ("frame,batched,sequence,cpu,api" if world == 1 else "frame")).split(","))
     if "frame" in want_legs and args.frame_steps > 0:
         _PairGen.start_pool(world, args.gen_workers)
     import torch
@@ -212,7 +212,7 @@ def main():
 
     # the rank-0-only legs (batched solver sweep, serial sequence, CPU baseline) would keep the other ranks
     # spinning in the final barrier: with several ranks only the sharded leg runs unless asked for explicitly
-    default_legs = "frame,batched,sequence,cpu" if world == 1 else "frame"
+    default_legs = "frame,batched,sequence,cpu,api" if world == 1 else "frame"
     legs = set() if args.no_extras else set((args.legs or default_legs).split(","))
     if "frame" in legs and args.frame_steps > 0:           # every rank: config 4 (sharded pairs + pose gather)
         with torch.cuda.stream(stream):
@@ -226,6 +226,8 @@ def main():
             if args.frame_steps > 0 and "frame" in legs:
                 out["frame"] = frame_leg(torch, ctx, stream, pipe, fp, args, vo)
                 out["exact_mode"] = exact_leg(torch, ctx, stream, pipe, fp, args)
+            if "api" in legs:
+                out["api_one_round"] = api_leg(vo, ctx, pipe, fp, args, value)
             if args.batch_pairs > 0 and "batched" in legs:
                 out["batched"] = batched_leg(torch, vo, ctx, stream, args)
             if args.seq_frames >= 3 and "sequence" in legs:
@@ -607,6 +609,74 @@ def exact_leg(torch, ctx, stream, pipe, fp, args):
             "note": "reference-order arithmetic (terms unfused, H / b / chi summed sequentially in correspondence order, Eigen's "
                     "LDLT, double sin/cos): bit-identical to the float32 CPU restatement; floor = one dependent v_add_f32 "
                     "(7.5 cycles) per correspondence and round"}
+
+
+def api_leg(vo, ctx, pipe, fp, args, headline):
+    """The reference's own call pattern (vo_complete.cpp:161-168): `iters` x oneRound(host pairs), then camera().
+    Here through the C ABI the reference would bind: per step vo_picp_set_pose(identity),
+    `iters` x vo_picp_one_round on the SAME host array of 50k pairs (compared in full on every call), vo_picp_get_pose.
+    `ctypes`: this process (every call pays Python's foreign-call overhead); `cpp`: apps/one_round_rate, the same loop on
+    vo::PICPSolver::oneRound from C++ (a child process on the same GPU, run after this one's work has drained)."""
+    import subprocess
+    lib = ctx.lib
+    pairs = np.ascontiguousarray(pipe.fetch("join"))
+    n = len(pairs)
+    s = vo.PICPSolver(ctx)
+    s.setKernelThreshold(10000.0)
+    s.init(vo.Camera(fp["rows"], fp["cols"], fp["z_near"], fp["z_far"], fp["K"], np.eye(4), ctx=ctx), fp["model"], fp["cur_pts"])
+    ident = np.ascontiguousarray(np.eye(4, dtype=np.float32))
+    T = np.zeros(16, np.float32)
+    one_round, set_pose, get_pose = lib.vo_picp_one_round, lib.vo_picp_set_pose, lib.vo_picp_get_pose
+    a_h, a_p, a_n, a_k = s.h, C.c_void_p(pairs.ctypes.data), C.c_int(n), C.c_int(0)
+    a_i, a_T = C.c_void_p(ident.ctypes.data), C.c_void_p(T.ctypes.data)
+
+    def step():
+        rc = set_pose(a_h, a_i)
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            rc |= one_round(a_h, a_p, a_n, a_k)
+        t1 = time.perf_counter()
+        rc |= get_pose(a_h, a_T)
+        _chk(lib, rc)
+        return t1 - t0
+
+    steps = max(20, min(args.steps, 200))
+    for _ in range(20):
+        step()
+    calls = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        calls += step()
+    dt = time.perf_counter() - t0
+    err = float(np.abs(T.reshape(4, 4).T - fp["X_gt"]).max())
+    assert err < 1e-3 and s.numInliers() == n, (err, s.numInliers())
+    open_rounds, spec, redone = s.chainInfo()
+    s.close()
+    out = {"what": f"per step: vo_picp_set_pose(identity), {args.iters} x vo_picp_one_round(host array of {n} pairs), vo_picp_get_pose "
+                   "-- the reference's loop vo_complete.cpp:161-168; one kernel launch per call, the pairs compared in full on "
+                   "every call while the round runs",
+           "ctypes": {"iters_per_sec": steps * args.iters / dt, "us_per_round": dt * 1e6 / (steps * args.iters),
+                      "host_us_per_call": calls * 1e6 / (steps * args.iters), "steps": steps, "pose_err_vs_gt": err,
+                      "speculative_calls": spec, "repeated_calls": redone},
+           "headline_iters_per_sec": headline}
+    exe = os.path.join(ROOT, "apps", "bin", "one_round_rate")
+    try:
+        if not os.path.exists(exe):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "apps"), "-s", "bin/one_round_rate"], check=True, timeout=300)
+        ctx.synchronize()
+        r = subprocess.run([exe, str(args.points), str(args.iters), str(steps), "20"], capture_output=True, text=True, timeout=300)
+        cpp = json.loads(r.stdout.strip().splitlines()[-1])
+        cpp["returncode"] = r.returncode
+        out["cpp"] = cpp
+        out["iters_per_sec"] = cpp["loop"]["iters_per_sec"]
+        out["host_us_per_call"] = cpp["loop"]["host_us_per_call"]
+        out["vs_headline"] = cpp["loop"]["iters_per_sec"] / headline
+    except Exception as e:      # (the C++ driver is an extra: the ctypes figures stand on their own)
+        out["cpp"] = {"error": repr(e)}
+        out["iters_per_sec"] = out["ctypes"]["iters_per_sec"]
+        out["host_us_per_call"] = out["ctypes"]["host_us_per_call"]
+        out["vs_headline"] = out["iters_per_sec"] / headline
+    return out
 
 
 def frame_leg(torch, ctx, stream, pipe, fp, args, vo_mod=None):
