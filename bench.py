@@ -34,8 +34,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
+from tools import stamp as _stamp  # noqa: E402   (which sources a file under profiles/ was taken on)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_SUSTAINED_GBS = 6300.0     # MI355X_MICROARCH.md: what HBM sustains (float4 copy; 6.0-6.1 TB/s for a 1.2 GB in-order sweep)
 BYTES_PER_CORR_ITER = 20       # world xyz 12 B + measurement uv 8 B
 
 
@@ -59,7 +61,7 @@ def parse():
     ap.add_argument("--strong-pairs", type=int, default=1600,
                     help="frame pairs of the strong-scaling config-4 leg, sharded over the ranks (0: skip)")
     ap.add_argument("--strong-per-call", type=int, default=1600, help="frames per vo_frames_batch_dev call in that leg")
-    ap.add_argument("--open-shares", type=str, default="0.01,0.05,0.25",
+    ap.add_argument("--open-shares", type=str, default="0.01,0.05,0.25,1.0",
                     help="matcher stage of the 200-frame batch timed again with these shares of every frame's queries displaced "
                          "(no bitwise copy in the tree); empty: skip (the counter passes of tools/collect_profiles.sh do)")
     ap.add_argument("--gen-workers", type=int, default=None, help="host processes generating the config-4 pairs (default: CPU share, <= 16)")
@@ -187,6 +189,7 @@ def main():
     out = {
         **({"rehearsal": "VO_BENCH_SHARE_GPU=1: all ranks on ONE GPU, gloo collectives -- not a scaling measurement"} if share_gpu else {}),
         "metric": "PICP iterations/sec @50k pts",
+        "evidence_stamp": _stamp.current(),
         "value": value, "unit": "iter/s", "n_gpus": world, "ranks_seen": (dist.get_world_size() if dist is not None else 1),
         "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM_STEPS,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -257,6 +260,27 @@ def _relate_exact_and_cpu(out):
         ex["vs_cpu_baseline"] = ex["iters_per_sec"] / cpu["value"]
 
 
+_CSRC_SHA = None
+
+
+def _evidence_note(path):
+    """how a committed evidence file relates to the tree this run executes: its stamp (tools/stamp.py) against the hash of
+    the kernel sources at hand"""
+    global _CSRC_SHA
+    if _CSRC_SHA is None:
+        _CSRC_SHA = _stamp.csrc_sha()
+    if not path:
+        return "no file"
+    state, st = _stamp.status(path, _CSRC_SHA)
+    name = os.path.basename(path)
+    if state == "current":
+        return f"{name}: taken at commit {st.get('commit')} on the kernel sources of this run (csrc_sha {_CSRC_SHA})"
+    if state == "stale":
+        return (f"{name}: STALE -- taken at commit {st.get('commit')} (csrc_sha {st.get('csrc_sha')}), the kernel sources of this run "
+                f"hash to {_CSRC_SHA}")
+    return f"{name}: unstamped (collected before round 5 introduced stamps); this run's csrc_sha is {_CSRC_SHA}"
+
+
 def _pmc_file():
     """the newest committed PMC summary (profiles/rNN_pmc_fetch_write*.json)"""
     import glob
@@ -267,12 +291,14 @@ def _pmc_file():
 def _headline_stamps(launch_us):
     """In-kernel phase split of the headline round (profiles/r04_headline_stamps.json: s_memtime stamps of workgroup 0 over
     1470 rounds of the timed geometry, VO_STAMPS build) beside this run's launch_us."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_headline_stamps.json")
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_headline_stamps.json")))
     try:
+        path = files[-1]
         st = json.load(open(path))
     except Exception:
         return None
-    return {"source": "profiles/r04_headline_stamps.json", "rounds": st["rounds"],
+    return {"source": "profiles/" + os.path.basename(path), "evidence": _evidence_note(path), "rounds": st["rounds"],
             "in_kernel_us": st["in_kernel_us_mean"], "kernel_boundary_us": st["kernel_boundary_us_mean"],
             "round_to_round_us": st["round_to_round_us_mean"],
             "round_to_round_over_this_runs_launch_us": st["round_to_round_us_mean"] / launch_us,
@@ -293,7 +319,7 @@ def _pmc_traffic(kernel, grid_threads):
     wide = k.get("wide_16B_loads", False)
     b = (2.0 * fetch_kb if wide else fetch_kb) * 1024.0 + write_kb * 1024.0
     return b, ("FETCH_SIZE x2 (gfx950 counts half of 16-B/lane coalesced reads) + WRITE_SIZE" if wide else
-               "FETCH_SIZE + WRITE_SIZE as reported (4-B/lane loads: uncalibrated width)") + ", from " + os.path.basename(path)
+               "FETCH_SIZE + WRITE_SIZE as reported (4-B/lane loads: uncalibrated width)") + ", from " + _evidence_note(path)
 
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 (vector)
@@ -374,7 +400,7 @@ def _pmc_frames_call():
     """HBM bytes of one whole vo_frames_batch_dev call (200 x 50k), summed over its kernels, from the same summary"""
     try:
         c = json.load(open(_pmc_file()))["batched_frames_call"]
-        return c["bytes_corrected"], c["note"] + ", from " + os.path.basename(_pmc_file())
+        return c["bytes_corrected"], c["note"] + ", from " + _evidence_note(_pmc_file())
     except (OSError, KeyError, ValueError, TypeError):
         return None, "no committed PMC summary of the batched call"
 
@@ -505,7 +531,10 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
         call_by_share = {"0": e0.elapsed_time(e1) / 3}        # (event time like the rest of this table: ms_per_batch above is wall time with the step's barriers)
         done = 0.0
         for share in shares:
-            bp.perturb_cur_app(share - done, seed=int(share * 1000))     # (rows drawn anew: the shares add up, a few rows twice)
+            if share >= 1.0:
+                bp.perturb_cur_app(1.0, seed=1000)                       # every row: no bitwise copy left in any frame
+            else:
+                bp.perturb_cur_app(share - done, seed=int(share * 1000))     # (rows drawn anew: the shares add up, a few rows twice)
             done = share
             bp.match_only(); ctx.synchronize()
             e0.record(stream)
@@ -526,6 +555,21 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
                             "they have no bitwise copy in the tree (still matched: by the search)")
         by_share["whole_call_ms"] = call_by_share
     bp.close()
+    without = None
+    if by_share is not None and "1" in by_share:
+        # descriptors recomputed per frame: no query is a bitwise copy, every one is answered by the nearest-neighbour search
+        m_alg = FRAME_ALG_BYTES["match"] * frames
+        without = {"frames_per_sec": frames / (by_share["whole_call_ms"]["1"] * 1e-3), "ms_per_call_event_time": by_share["whole_call_ms"]["1"],
+                   "matcher_ms": by_share["1"],
+                   "matcher_roofline": {"bound": "hbm", "scope": f"matcher stage of {frames} frames, no bitwise copies: grid bounds, "
+                                        "level 1 / offsets / level 2 of the cell sort, cell-hash search, compaction", "achieved":
+                                        m_alg / (by_share["1"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": m_alg / (by_share["1"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "algorithmic_bytes_per_call": m_alg, "traffic": None,
+                                        "traffic_note": "counter passes of this variant: tools/pmc_match.sh with OPENS=1.0 (profiles/)"},
+                   "note": "every current descriptor displaced by N(0, 0.005) per component (all still matched, by the search): "
+                           "what a front end that recomputes descriptors per frame gets; the headline frames_per_sec is for "
+                           "descriptors copied bit for bit, as the reference's data and SURVEY 8(d)'s generator have them"}
     alg = _frame_alg_bytes(args.points, args.iters) * frames
     gbs = alg / sec / 1e9
     return {"frames_per_gpu": frames, "n_gpus": world, "frames_total": frames * world, "ms_per_batch": ms, "scaling": "weak",
@@ -533,6 +577,8 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
             "seeds": f"4000+p, p = {frames * rank}..{frames * rank + frames - 1} on this rank",
             "matcher_ms_per_batch": match_ms,
             "matcher_ms_by_open_share": by_share,
+            "frames_per_sec_without_copies": without["frames_per_sec"] if without else None,
+            "without_copies": without,
             "matcher_roofline": _matcher_roofline(frames, args.points, match_ms * 1e-3)
             if (frames, args.points) == (200, 50000) else None,
             "roofline": {"bound": "hbm", "scope": "whole frame (all stages of one vo_frames_batch_dev call)", "achieved": gbs,
@@ -810,17 +856,26 @@ def batched_leg(torch, vo, ctx, stream, args):
     out = _batched_run(torch, vo, ctx, stream, args, args.batch_pairs)
     if args.batch_pairs == 200:
         out["chip_full"] = []
-        for P in (256, 512):
+        for P in (256, 512, 2048):
             r = _batched_run(torch, vo, ctx, stream, args, P)
+            ws = r["working_set_MB"] * 1e6
+            tb = r["frac_traffic"] * HBM_PEAK_GBS / 1e3
             out["chip_full"].append({"pairs": P, "kernel_ms": r["kernel_ms"], "iters_per_sec": r["iters_per_sec"],
                                      "achieved_GBs": r["roofline"]["achieved"], "frac": r["roofline"]["frac"],
                                      "frac_algorithmic": r["frac_algorithmic"], "frac_traffic": r["frac_traffic"],
+                                     "traffic_TBs": tb, "frac_traffic_of_sustained_6.3TBs": tb * 1e3 / HBM_SUSTAINED_GBS,
                                      "working_set_MB": r["working_set_MB"],
-                                     "working_set_fits_infinity_cache": r["working_set_fits_infinity_cache"]})
-        past = [c for c in out["chip_full"] if not c["working_set_fits_infinity_cache"]]
-        if past:      # the point to read as an HBM fraction: its working set cannot live in the Infinity Cache
-            out["hbm_point"] = dict(past[-1], note="working set beyond the 256 MiB Infinity Cache: frac_traffic of this point is "
-                                                    "HBM traffic over time over 8 TB/s (DRAM-destined requests: profiles/r04_pmc_dram.txt)")
+                                     "working_set_fits_infinity_cache": r["working_set_fits_infinity_cache"],
+                                     "served_by": ("Infinity Cache" if ws < 256 * 2 ** 20 else
+                                                   "Infinity-Cache-assisted (working set < 8 x the 256 MiB cache)" if ws < 8 * 256 * 2 ** 20
+                                                   else "HBM")})
+        past = [c for c in out["chip_full"] if c["served_by"] == "HBM"]
+        if past:      # the one point to read as an HBM fraction: 2 GiB of packed correspondences swept 50 times, 8 x the Infinity Cache
+            out["hbm_point"] = dict(past[-1], note="working set 8 x the 256 MiB Infinity Cache, swept in order once per round: the cache "
+                                                    "cannot hold a line until its next use, so frac_traffic (bytes that leave the LDS, over "
+                                                    "time) is HBM traffic -- quoted against the 8.0 TB/s specification (frac_traffic) and "
+                                                    "against the 6.3 TB/s the guide measures as sustained (frac_traffic_of_sustained_6.3TBs). "
+                                                    "The 256- and 512-problem points are Infinity-Cache-assisted and are not HBM figures.")
         # a few problems per call: the launch-per-round form (problem = grid dimension) against one workgroup per problem
         out["few_problems"] = []
         for P in (4, 16):

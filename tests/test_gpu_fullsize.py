@@ -54,6 +54,46 @@ def test_batched_frames_200x50k(vo, ctx, o32):
     bp.close()
 
 
+def test_batched_frames_200x50k_without_bitwise_copies(vo, ctx, o32):
+    """The same call when NO current descriptor is a bitwise copy of its landmark's (a front end that recomputes descriptors
+    per frame): current rows = reference rows + N(0, 0.01^2) per component, so every query is answered by the nearest-neighbour
+    SEARCH (vo_complete.cpp:12-49, brute_force_search.h:22-41) and none by the exact-duplicate pass.  All 200 frames against
+    the generator's permutation, three of them against the oracle's kd-tree matcher and through the rest of the frame."""
+    rng = np.random.default_rng(77)
+    distinct = []
+    for p in range(8):
+        fp = dict(vo.synth.frame_pair(N, seed=4000 + p))
+        fp["cur_app"] = (fp["cur_app"] + rng.normal(0.0, 0.01, fp["cur_app"].shape)).astype(np.float32)
+        assert not (fp["cur_app"][fp["gt_matches"][:, 1]] == fp["ref_app"][fp["gt_matches"][:, 0]]).all(axis=1).any()
+        distinct.append(fp)
+    fps = [distinct[i % 8] for i in range(F)]
+    bp = vo.BatchPipeline(ctx, lambda lo, hi: fps[lo:hi], n_iters=10, n_frames=F, upload_block=40)
+    for mode in (0, 3, 5):                                  # automatic, the search alone, exact-duplicate pass + search
+        assert ctx.lib.vo_match_set_mode(ctx.h, mode) == 0
+        try:
+            bp.match_only()
+            ctx.synchronize()
+        finally:
+            assert ctx.lib.vo_match_set_mode(ctx.h, 0) == 0
+        assert np.all(bp.counts()[0] == N)
+        for f in range(F):
+            assert np.array_equal(bp.fetch("match", f), fps[f]["gt_matches"]), (mode, f)
+    bp.run()
+    ctx.synchronize()
+    c, T, st = bp.counts(), bp.poses(), bp.stats()
+    assert np.all(c[0] == N) and np.all(c[1] == N) and np.all(st[:, 2] == N)
+    for f in (0, 101, 199):
+        fp = fps[f]
+        m = bp.fetch("match", f)
+        m_o = o32.match_kdtree(fp["ref_app"], fp["cur_app"])
+        assert np.array_equal(m, m_o)
+        assert np.array_equal(bp.fetch("join", f), o32.join(m_o, fp["model_pairs"], linear=True))
+        xyz, pairs, app = bp.fetch("tri_xyz", f), bp.fetch("tri_pairs", f), bp.fetch("tri_app", f)
+        xo, po, ao = o32.triangulate(fp["K"], T[f], m_o, fp["ref_pts"], fp["cur_pts"], fp["cur_app"])
+        assert np.array_equal(pairs, po) and np.array_equal(app, ao) and np.array_equal(xyz, xo)
+    bp.close()
+
+
 @pytest.mark.parametrize("n,f", [(6000, 12), (N, 24)])
 def test_batched_frames_reference_order_form(vo, ctx, o32, n, f):
     """the same call with the solver stage in reference-order arithmetic (vo_picp_batch_set_form(3)): poses and
