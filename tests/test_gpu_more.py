@@ -479,3 +479,46 @@ def test_device_arrays_off_an_8_byte_boundary_are_refused(vo, ctx):
     finally:
         for p in (d_a, d_out, d_cnt):
             ctx.free(p)
+
+
+def test_single_pass_compaction_equals_the_default(vo, ctx):
+    """VO_ONE_PASS=1 (geom.hip: chained scan with decoupled look-back -- built in round 5, measured slower, kept opt-in):
+    matcher output, join (+ the solver's gather), triangulation of a batched call and of single-frame calls, bit for bit
+    what the count / scan / scatter form writes, survivors in the reference's order (utils.cpp:97-99,126-128)."""
+    import os
+    rng = np.random.default_rng(5)
+    batch = []
+    for p in range(9):                        # equal sizes (a batch needs them); the gaps are planted afterwards
+        fp = dict(vo.synth.frame_pair(9000, seed=5100 + p))
+        n = len(fp["cur_app"])
+        fp["cur_app"] = fp["cur_app"].copy(); fp["model_pairs"] = fp["model_pairs"].copy()
+        lost = rng.choice(n, n // 10, replace=False)
+        fp["cur_app"][lost] = rng.uniform(-1, 1, (len(lost), 10)).astype(np.float32)       # queries without a match
+        if p % 2:   # no bitwise copies at all: every key goes through the search and the matcher's own compaction
+            fp["cur_app"] = (fp["cur_app"] + rng.normal(0, 0.003, fp["cur_app"].shape)).astype(np.float32)
+        fp["model_pairs"][rng.choice(len(fp["model_pairs"]), len(fp["model_pairs"]) // 5, replace=False), 0] = -1   # no partner
+        batch.append(fp)
+    singles = [vo.synth.frame_pair(7000, seed=5200 + p, drop=0.1, distractors=50, model_drop=0.2) for p in range(3)]
+    res = {}
+    for one_pass in ("0", "1"):
+        os.environ["VO_ONE_PASS"] = one_pass
+        try:
+            out = []
+            bp = vo.BatchPipeline(ctx, batch, n_iters=4)
+            bp.run(); ctx.synchronize()
+            c = bp.counts()
+            assert np.all(c[0] < 9000) and np.all(c[1] < c[0]) and np.all(c[2] > 0) and np.all(c[2] <= c[0])
+            out.append((c.tobytes(), bp.poses().tobytes()))
+            for f in range(len(batch)):
+                out.append(tuple(bp.fetch(w, f).tobytes() for w in ("match", "join", "tri_xyz", "tri_pairs", "tri_app")))
+            bp.close()
+            for fp in singles:
+                m = vo.compute_correspondences_images(fp["ref_app"], fp["cur_app"], ctx=ctx)
+                j = vo.extract_correspondences_world(m, fp["model_pairs"], ctx=ctx)
+                xyz, pairs, app = vo.triangulate_points(fp["K"], fp["X_gt"], m, fp["ref_pts"], fp["cur_pts"], fp["cur_app"], ctx=ctx)
+                assert 0 < len(xyz) <= len(m) and 0 < len(j) < len(m)
+                out.append((m.tobytes(), j.tobytes(), xyz.tobytes(), pairs.tobytes(), app.tobytes()))
+            res[one_pass] = out
+        finally:
+            os.environ.pop("VO_ONE_PASS", None)
+    assert res["0"] == res["1"]

@@ -15,13 +15,34 @@
 // than writing and re-reading 12-44 B per item.
 #include <limits.h>
 
+#include <stdlib.h>
+
 #include "vo_internal.h"
+#include "chain_scan.h"
 
 namespace vo {
 
 constexpr int CB = 256;  // items per compaction workgroup
 
-size_t compaction_scratch_ints(int n) { return (size_t)((n + CB - 1) / CB) + 16; }
+// per frame: the chain state of the single-pass compactions (chain_scan.h: 8-byte words) -- which also covers the
+// per-workgroup counts of the count / scan / scatter form (4-byte) -- plus 64 bytes
+size_t compaction_scratch_ints(int n) { return 2 * chain_words((n + CB - 1) / CB) + 16; }
+static inline size_t chain_stride(int n) { return compaction_scratch_ints(n) / 2; }     // 8-byte words per frame
+
+// The compactions run as count / scan / scatter (two visits of every item, a scan launch in between).  VO_ONE_PASS=1 in the
+// environment (read at every launch: a test flips it inside one process) selects the single-pass form instead -- a chained
+// scan with decoupled look-back, chain_scan.h -- which round 5 built to spare the second visit and MEASURED SLOWER on this
+// path: per 200 x 50k frames the triangulation takes 335-394 us against 297 (count 111 + scatter 186), the join with the
+// solver's gather 247-295 against 222, the whole call 2.57-2.97 ms against 2.54-2.56 (1, 2, 4, 8, 12, 16 rows of 256 items per
+// workgroup: 3.57 / 2.97 / 2.68 / 2.57 / 2.61 / 2.64 ms; same box, tools/ab_frames.sh).  Why: the two-pass kernels already
+// move their ACTUAL bytes (algorithmic + the 24 B per item they hand from pass to pass) at 5.2 TB/s, so a perfect single
+// pass could save 19 % of their time at most; and a chained workgroup holds its slot through three memory-side round trips
+// (ticket, published count, look-back: agent-scope atomics, the only hand-off that is correct across XCDs) with nothing in
+// flight, which costs more memory-level parallelism than the second visit costs bytes.  DESIGN.md section 8.
+static bool two_pass() {
+  const char* e = getenv("VO_ONE_PASS");
+  return !(e && e[0] == '1');
+}
 
 // exclusive rank of `flag` inside a 256-thread workgroup; total = survivors
 __device__ __forceinline__ int block_rank(bool flag, int* s_wave, int& total) {
@@ -274,6 +295,8 @@ struct TriArgs {
   // batched use: strides in pairs / points per frame (0 for a single frame); nb workgroups for each of n_frames frames
   size_t pairs_stride, p1_stride, p2_stride, out_stride, counts_stride;
   int nb, n_frames;
+  unsigned long long* chain;        // single-pass form: [n_frames][chain_stride] status words (zeroed before the launch)
+  size_t chain_stride;
 };
 
 // shifts every per-frame pointer of `a` to frame f
@@ -289,8 +312,8 @@ __device__ __forceinline__ TriArgs tri_frame(TriArgs a, int frame) {
   if (a.out_pairs) a.out_pairs += 2 * f * a.out_stride;
   if (a.out_app) a.out_app += 10 * f * a.out_stride;
   a.counts += f * a.counts_stride;
-  a.tmp_xyz += 3 * f * (size_t)a.n_max;
-  a.tmp_ok += f * (size_t)((a.n_max + 63) / 64);
+  if (a.tmp_xyz) { a.tmp_xyz += 3 * f * (size_t)a.n_max; a.tmp_ok += f * (size_t)((a.n_max + 63) / 64); }
+  a.chain += f * a.chain_stride;
   return a;
 }
 
@@ -382,6 +405,122 @@ __global__ __launch_bounds__(CB) void tri_scatter_kernel(TriArgs a0) {
   }
 }
 
+// ---- single-pass compaction: several rows of CB items per workgroup ----------------------------------------------------
+// A workgroup of the single-pass kernels owns a CHUNK of OP_ITEMS rows of CB consecutive items (thread t takes item
+// t of every row: coalesced), because what a chained scan adds to a workgroup's life -- the ticket, the published count,
+// the look-back: three memory-side round trips -- is per workgroup, and these kernels are bound by the number of
+// workgroups in flight, not by bytes (one row per workgroup, 196 chunks per 50k frame: 857 us per 200 frames where
+// count + scatter took 297).  Eight rows: 25 chunks per frame, one look-back window, eight independent gathers per lane.
+#ifndef VO_OP_ITEMS
+#define VO_OP_ITEMS 8
+#endif
+constexpr int OP_ITEMS = VO_OP_ITEMS;
+constexpr int OP_CHUNK = CB * OP_ITEMS;
+
+// ranks of a chunk: item (row j, thread t) with flag ok[j] gets the number of flagged items in front of it in item
+// order (rows before j, then threads before t).  s_cnt: OP_ITEMS * (CB / 64) ints.  One barrier.
+__device__ __forceinline__ void chunk_rank(const bool ok[OP_ITEMS], int* s_cnt, int rank[OP_ITEMS], int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int before[OP_ITEMS];
+#pragma unroll
+  for (int j = 0; j < OP_ITEMS; ++j) {
+    const unsigned long long m = __ballot(ok[j]);
+    before[j] = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_cnt[j * (CB / 64) + wave] = __popcll(m);
+  }
+  __syncthreads();
+  int run = 0;
+#pragma unroll
+  for (int j = 0; j < OP_ITEMS; ++j) {
+#pragma unroll
+    for (int w = 0; w < CB / 64; ++w) {
+      if (w == wave) rank[j] = run + before[j];
+      run += s_cnt[j * (CB / 64) + w];
+    }
+  }
+  total = run;
+}
+
+// The triangulation in ONE pass (chain_scan.h): triangulate, rank inside the chunk, learn the chunk's offset from its
+// predecessors' published counts, write.  No point is stored for a second pass, no pair is read twice; the appearance
+// rows of the survivors are requested BEFORE the look-back (their addresses do not depend on the offset) and stored after it.
+__global__ __launch_bounds__(CB) void tri_onepass_kernel(TriArgs a0, int* d_n_out) {
+  const FrameBlock fb = frame_block(a0.nb, a0.n_frames);       // the frame (and with it the XCD); the chunk is the ticket
+  if (!fb.live) return;
+  const TriArgs a = tri_frame(a0, fb.f);
+  __shared__ TriConst s_c;
+  __shared__ int s_cnt[OP_ITEMS * (CB / 64)];
+  __shared__ int s_src[OP_CHUNK];
+  __shared__ int s_b, s_excl;
+  if (threadIdx.x == 0) s_b = chain_take_ticket(a.chain);
+  tri_setup(a, &s_c);                                          // (its barrier publishes s_b too)
+  const int b = s_b;
+  const int n = clamp_count(a.d_n, a.n_max);
+  bool ok[OP_ITEMS];
+  int i2[OP_ITEMS], rank[OP_ITEMS];
+  float p[OP_ITEMS][3];
+#pragma unroll
+  for (int j = 0; j < OP_ITEMS; ++j) {
+    const int k = b * OP_CHUNK + j * CB + threadIdx.x;
+    ok[j] = false; i2[j] = 0; p[j][0] = p[j][1] = p[j][2] = 0.f;
+    if (k < n) ok[j] = tri_eval(a, s_c, k, i2[j], p[j]);
+  }
+  int total;
+  chunk_rank(ok, s_cnt, rank, total);
+#pragma unroll
+  for (int j = 0; j < OP_ITEMS; ++j) if (ok[j]) s_src[rank[j]] = i2[j];
+  __syncthreads();
+  constexpr int PIECES = 5;                                    // 8-byte pieces of a 40-byte appearance row
+  float2 piece[PIECES * OP_ITEMS];
+  const bool with_app = a.out_app && a.app2;
+#ifndef VO_TRI_LATE_APP
+  if (with_app) {
+    const float2* app = reinterpret_cast<const float2*>(a.app2);
+#pragma unroll
+    for (int q = 0; q < PIECES * OP_ITEMS; ++q) {
+      const int j = threadIdx.x + q * CB;
+      // (clamped, unconditional: a predicated load makes the compiler wait for all of them at the first use)
+      const int jj = j < PIECES * total ? j : 0;
+      const int pt = jj / PIECES;
+      piece[q] = total > 0 ? app[PIECES * (size_t)s_src[pt] + (jj - PIECES * pt)] : make_float2(0.f, 0.f);
+    }
+  }
+#endif
+  if (threadIdx.x < 64) {
+    const int e = chain_lookback(a.chain, b, total);
+    if (threadIdx.x == 0) s_excl = e;
+  }
+  __syncthreads();
+  const int excl = s_excl;
+  if (excl < 0) return;                                        // the look-back gave up (chain word 1 is set): nothing is written
+#pragma unroll
+  for (int j = 0; j < OP_ITEMS; ++j) {
+    if (ok[j]) {
+      const size_t dst = (size_t)excl + rank[j];
+      a.out_xyz[3 * dst] = p[j][0]; a.out_xyz[3 * dst + 1] = p[j][1]; a.out_xyz[3 * dst + 2] = p[j][2];
+      if (a.out_pairs) reinterpret_cast<int2*>(a.out_pairs)[dst] = make_int2(i2[j], (int)dst);     // utils.cpp:97
+    }
+  }
+  if (with_app) {                                                                              // utils.cpp:127
+    float2* o = reinterpret_cast<float2*>(a.out_app) + PIECES * (size_t)excl;
+#ifdef VO_TRI_LATE_APP
+    const float2* app = reinterpret_cast<const float2*>(a.app2);
+    for (int j = threadIdx.x; j < PIECES * total; j += CB) {
+      const int pt = j / PIECES;
+      o[j] = app[PIECES * (size_t)s_src[pt] + (j - PIECES * pt)];
+    }
+    (void)piece;
+#else
+#pragma unroll
+    for (int q = 0; q < PIECES * OP_ITEMS; ++q) {
+      const int j = threadIdx.x + q * CB;
+      if (j < PIECES * total) o[j] = piece[q];
+    }
+#endif
+  }
+  if (b == a.nb - 1 && threadIdx.x == 0) d_n_out[fb.f] = excl + total;
+}
+
 __global__ __launch_bounds__(CB) void tri_small_kernel(TriArgs a0, int* d_n_out) {
   const int f = blockIdx.x;
   const TriArgs a = tri_frame(a0, f);
@@ -446,7 +585,10 @@ hipError_t launch_triangulate_batch(hipStream_t st, const float K[9], const Pose
   a.p1 = d_p1; a.n1 = n1; a.p2 = d_p2; a.n2 = n2; a.app2 = d_app2;
   a.out_xyz = d_out_xyz; a.out_pairs = d_out_pairs; a.out_app = d_out_app;
   a.counts = d_scratch;
-  {
+  a.tmp_ok = nullptr; a.tmp_xyz = nullptr;
+  a.chain = reinterpret_cast<unsigned long long*>(d_scratch);
+  a.chain_stride = chain_stride(n);
+  if (two_pass()) {
     size_t off = sizeof(int) * compaction_scratch_ints(n) * (size_t)n_frames;   // triangulate_scratch_bytes
     off = (off + 15) & ~(size_t)15;
     char* t = reinterpret_cast<char*>(d_scratch) + off;
@@ -461,6 +603,14 @@ hipError_t launch_triangulate_batch(hipStream_t st, const float K[9], const Pose
   a.nb = nb; a.n_frames = n_frames;
   if (n <= SMALL_N) {
     hipLaunchKernelGGL(tri_small_kernel, dim3(n_frames), dim3(CB), 0, st, a, d_n_out);
+    return hipGetLastError();
+  }
+  if (nb == 0) return hipMemsetAsync(d_n_out, 0, sizeof(int) * (size_t)n_frames, st);
+  if (!two_pass()) {
+    hipError_t e = hipMemsetAsync(d_scratch, 0, sizeof(int) * compaction_scratch_ints(n) * (size_t)n_frames, st);
+    if (e != hipSuccess) return e;
+    a.nb = (n + OP_CHUNK - 1) / OP_CHUNK;                       // chunks of OP_ITEMS rows
+    hipLaunchKernelGGL(tri_onepass_kernel, frame_grid(a.nb, n_frames), dim3(CB), 0, st, a, d_n_out);
     return hipGetLastError();
   }
   if (nb > 0) hipLaunchKernelGGL(tri_count_kernel, frame_grid(nb, n_frames), dim3(CB), 0, st, a);
@@ -510,6 +660,8 @@ struct JoinArgs {
   int nb, n_frames;                                             // workgroups per frame, frames
   int* tmp_w;                                                   // [n_frames][n_max]: what the counting pass looked up ...
   unsigned long long* tmp_ok;                                   // [n_frames][(n_max + 63) / 64]: ... and whether there was a partner
+  unsigned long long* chain;                                    // single-pass form: [n_frames][chain_stride] status words
+  size_t chain_stride;
 };
 // the writing pass with the solver's gather folded in: BatchArgs by value beside the join's own arguments
 struct JoinSink { BatchArgs b; };
@@ -522,8 +674,8 @@ __device__ __forceinline__ JoinArgs join_frame(JoinArgs a, int frame) {
   a.table += f * (size_t)a.n_ref;
   a.out += 2 * f * a.out_stride;
   a.counts += f * a.counts_stride;
-  a.tmp_w += f * (size_t)a.n_max;
-  a.tmp_ok += f * (size_t)((a.n_max + 63) / 64);
+  if (a.tmp_w) { a.tmp_w += f * (size_t)a.n_max; a.tmp_ok += f * (size_t)((a.n_max + 63) / 64); }
+  if (a.chain) a.chain += f * a.chain_stride;
   return a;
 }
 
@@ -587,6 +739,59 @@ __device__ __forceinline__ void join_scatter_body(const JoinArgs& a0, const Batc
 __global__ __launch_bounds__(CB) void join_scatter_kernel(JoinArgs a0) { join_scatter_body<false>(a0, nullptr); }
 __global__ __launch_bounds__(CB) void join_scatter_pack_kernel(JoinArgs a0, JoinSink s) { join_scatter_body<true>(a0, &s.b); }
 
+// The join in ONE pass (chain_scan.h): look the partner up, rank, learn the offset from the predecessors' counts, write
+// the pair -- and, with a sink, the solver's packed correspondence, whose point and pixel are requested before the
+// look-back (their addresses come from the pair, not from the slot).
+template <bool SINK>
+__device__ __forceinline__ void join_onepass_body(const JoinArgs& a0, const BatchArgs* sink, int* d_n_out) {
+  const FrameBlock fb = frame_block(a0.nb, a0.n_frames);
+  if (!fb.live) return;
+  const JoinArgs a = join_frame(a0, fb.f);
+  __shared__ int s_cnt[OP_ITEMS * (CB / 64)];
+  __shared__ int s_b, s_excl;
+  if (threadIdx.x == 0) s_b = chain_take_ticket(a.chain);
+  __syncthreads();
+  const int b = s_b;
+  const int n = clamp_count(a.d_n, a.n_max);
+  bool ok[OP_ITEMS];
+  int c[OP_ITEMS], w[OP_ITEMS], rank[OP_ITEMS];
+#pragma unroll
+  for (int j = 0; j < OP_ITEMS; ++j) {
+    const int i = b * OP_CHUNK + j * CB + threadIdx.x;
+    ok[j] = false; c[j] = 0; w[j] = 0;
+    if (i < n) ok[j] = join_eval(a, i, c[j], w[j]);
+  }
+  PackedItem it[OP_ITEMS];
+  if (SINK) {
+    const Pose Xw = batch_pack_pose(*sink, fb.f);
+#pragma unroll
+    for (int j = 0; j < OP_ITEMS; ++j) {
+      it[j] = PackedItem{0.f, 0.f, 0.f, 0.f, 0.f};
+      if (ok[j]) it[j] = batch_pack_load(*sink, fb.f, Xw, c[j], w[j]);
+    }
+  }
+  int total;
+  chunk_rank(ok, s_cnt, rank, total);
+  if (threadIdx.x < 64) {
+    const int e = chain_lookback(a.chain, b, total);
+    if (threadIdx.x == 0) s_excl = e;
+  }
+  __syncthreads();
+  const int excl = s_excl;
+  if (excl < 0) return;
+#pragma unroll
+  for (int j = 0; j < OP_ITEMS; ++j) {
+    if (ok[j]) {
+      const size_t dst = (size_t)excl + rank[j];
+      reinterpret_cast<int2*>(a.out)[dst] = make_int2(c[j], w[j]);        // vo_complete.cpp:59
+      if (SINK && dst < sink->cap) batch_pack_store(*sink, fb.f, dst, it[j]);     // a pair beyond the solver's capacity is not packed
+    }
+  }
+  if (b == a.nb - 1 && threadIdx.x == 0) d_n_out[fb.f] = excl + total;
+}
+__global__ __launch_bounds__(CB) void join_onepass_kernel(JoinArgs a0, int* d_n_out) { join_onepass_body<false>(a0, nullptr, d_n_out); }
+__global__ __launch_bounds__(CB) void join_onepass_pack_kernel(JoinArgs a0, JoinSink s, int* d_n_out) { join_onepass_body<true>(a0, &s.b, d_n_out); }
+
 bool join_fuses_gather(int n_img, int n_world, int n_ref) { return !(n_img <= SMALL_N && n_ref <= SMALL_N && n_world <= 8 * SMALL_N) && n_img > 0; }
 
 __global__ __launch_bounds__(CB) void join_small_kernel(JoinArgs a0, int n_world_max, const int* d_n_world, int* d_n_out) {
@@ -637,7 +842,7 @@ hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, co
   hipError_t e = hipSuccess;
   if (n_img <= SMALL_N && n_ref <= SMALL_N && n_world <= 8 * SMALL_N) {
     JoinArgs a{d_img, n_img, d_n_img, d_world, n_ref, d_table, d_out, d_scratch,
-               batched ? img_stride : 0, batched ? world_stride : 0, batched ? out_stride : 0, 0, 0, n_frames, nullptr, nullptr};
+               batched ? img_stride : 0, batched ? world_stride : 0, batched ? out_stride : 0, 0, 0, n_frames, nullptr, nullptr, nullptr, 0};
     hipLaunchKernelGGL(join_small_kernel, dim3(n_frames), dim3(CB), 0, st, a, n_world, d_n_world, d_n_out);
     return hipGetLastError();
   }
@@ -654,7 +859,21 @@ hipError_t launch_join_batch(hipStream_t st, const int32_t* d_img, int n_img, co
   const int nb = (n_img + CB - 1) / CB;
   JoinArgs a{d_img, n_img, d_n_img, d_world, n_ref, d_table, d_out, d_scratch,
              batched ? img_stride : 0, batched ? world_stride : 0, batched ? out_stride : 0,
-             batched ? compaction_scratch_ints(n_img) : 0, nb, n_frames, nullptr, nullptr};
+             batched ? compaction_scratch_ints(n_img) : 0, nb, n_frames, nullptr, nullptr,
+             reinterpret_cast<unsigned long long*>(d_scratch), chain_stride(n_img)};
+  if (nb == 0) return hipMemsetAsync(d_n_out, 0, sizeof(int) * (size_t)n_frames, st);
+  if (!two_pass()) {
+    e = hipMemsetAsync(d_scratch, 0, sizeof(int) * compaction_scratch_ints(n_img) * (size_t)n_frames, st);
+    if (e != hipSuccess) return e;
+    a.nb = (n_img + OP_CHUNK - 1) / OP_CHUNK;                   // chunks of OP_ITEMS rows
+    if (sink) {
+      JoinSink js; js.b = *sink;
+      hipLaunchKernelGGL(join_onepass_pack_kernel, frame_grid(a.nb, n_frames), dim3(CB), 0, st, a, js, d_n_out);
+    } else {
+      hipLaunchKernelGGL(join_onepass_kernel, frame_grid(a.nb, n_frames), dim3(CB), 0, st, a, d_n_out);
+    }
+    return hipGetLastError();
+  }
   {
     size_t off = (sizeof(int) * compaction_scratch_ints(n_img) * (size_t)n_frames + 15) & ~(size_t)15;      // join_scratch_bytes
     char* t = reinterpret_cast<char*>(d_scratch) + off;
@@ -748,6 +967,52 @@ __global__ __launch_bounds__(CB) void match_scatter_kernel(MatchOutArgs a) {
   }
 }
 
+// the same in one pass (chain_scan.h); a frame whose queries all found their copy (unres == 0) has its pairs in place
+__global__ __launch_bounds__(CB) void match_onepass_kernel(MatchOutArgs a, int* d_n_out, unsigned long long* chain, size_t chain_stride) {
+  __shared__ int s_cnt[OP_ITEMS * (CB / 64)];
+  __shared__ int s_b, s_excl;
+  int nq, tree_is_1;
+  match_out_frame(a, nq, tree_is_1);
+  if (a.unres && a.unres[blockIdx.y] == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) d_n_out[blockIdx.y] = nq;
+    return;
+  }
+  chain += blockIdx.y * chain_stride;
+  if (threadIdx.x == 0) s_b = chain_take_ticket(chain);
+  __syncthreads();
+  const int b = s_b;
+  const unsigned long long* best = a.best + blockIdx.y * a.best_stride;
+  int32_t* out = a.out + 2 * blockIdx.y * a.out_stride;
+  bool ok[OP_ITEMS];
+  unsigned idx[OP_ITEMS];
+  int rank[OP_ITEMS];
+#pragma unroll
+  for (int j = 0; j < OP_ITEMS; ++j) {
+    const int q = b * OP_CHUNK + j * CB + threadIdx.x;
+    idx[j] = 0xffffffffu;
+    if (q < nq) idx[j] = (unsigned)(best[q] & 0xffffffffull);
+    ok[j] = idx[j] != 0xffffffffu;
+  }
+  int total;
+  chunk_rank(ok, s_cnt, rank, total);
+  if (threadIdx.x < 64) {
+    const int e = chain_lookback(chain, b, total);
+    if (threadIdx.x == 0) s_excl = e;
+  }
+  __syncthreads();
+  const int excl = s_excl;
+  if (excl < 0) return;
+#pragma unroll
+  for (int j = 0; j < OP_ITEMS; ++j) {
+    if (ok[j]) {
+      const int q = b * OP_CHUNK + j * CB + threadIdx.x;
+      const size_t dst = (size_t)excl + rank[j];
+      reinterpret_cast<int2*>(out)[dst] = tree_is_1 ? make_int2((int)idx[j], q) : make_int2(q, (int)idx[j]);
+    }
+  }
+  if (b == (int)gridDim.x - 1 && threadIdx.x == 0) d_n_out[blockIdx.y] = excl + total;
+}
+
 __global__ __launch_bounds__(CB) void match_compact_small_kernel(MatchOutArgs a, int* d_n_out) {
   __shared__ int s_wave[CB / 64];
   const unsigned long long* best = a.best + blockIdx.y * a.best_stride;
@@ -781,6 +1046,14 @@ hipError_t launch_match_compact(hipStream_t st, const unsigned long long* d_best
   MatchOutArgs a{d_best, nq, tree_is_1, d_out, d_scratch, best_stride, n_frames > 1 ? out_stride : 0, cs, d_n1, d_n2, cap1, cap2, d_unres};
   if (nq <= SMALL_N) {
     hipLaunchKernelGGL(match_compact_small_kernel, dim3(1, n_frames), dim3(CB), 0, st, a, d_n_out);
+    return hipGetLastError();
+  }
+  if (nb == 0) return hipMemsetAsync(d_n_out, 0, sizeof(int) * (size_t)n_frames, st);
+  if (!two_pass()) {
+    hipError_t e0 = hipMemsetAsync(d_scratch, 0, sizeof(int) * compaction_scratch_ints(nq) * (size_t)(n_frames > 1 ? n_frames : 1), st);
+    if (e0 != hipSuccess) return e0;
+    hipLaunchKernelGGL(match_onepass_kernel, dim3((nq + OP_CHUNK - 1) / OP_CHUNK, n_frames), dim3(CB), 0, st, a, d_n_out,
+                       reinterpret_cast<unsigned long long*>(d_scratch), chain_stride(nq));
     return hipGetLastError();
   }
   if (nb > 0) hipLaunchKernelGGL(match_count_kernel, dim3(nb, n_frames), dim3(CB), 0, st, a);

@@ -127,19 +127,27 @@ hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a);
 #if defined(__HIPCC__)
 // What the gather does for correspondence i of problem p: (measurement m, world point w) -> packed x, y, z, u, v; an index
 // outside its array leaves the marker and is counted (picp_batch_pack_kernel and the join's writing pass share this).
-__device__ __forceinline__ void batch_pack_item(const BatchArgs& a, int p, const Pose& Xw, size_t i, int m, int w) {
+// in two halves, so that a caller can request the point and the pixel before it knows the slot they go to
+struct PackedItem { float x, y, z, u, v; };
+__device__ __forceinline__ PackedItem batch_pack_load(const BatchArgs& a, int p, const Pose& Xw, int m, int w) {
   const float* world = a.world + 3 * (size_t)p * a.world_stride;
   const float* meas = a.meas + 2 * (size_t)p * a.meas_stride;
-  float* dst = a.packed + (size_t)p * 5 * a.cap;
-  float x = __int_as_float((int)VO_DROPPED_BITS), y = 0.f, z = 0.f, u = 0.f, v = 0.f;
+  PackedItem it{__int_as_float((int)VO_DROPPED_BITS), 0.f, 0.f, 0.f, 0.f};
   if (m >= 0 && m < a.n_meas && w >= 0 && w < a.n_world) {
-    x = world[3 * (size_t)w]; y = world[3 * (size_t)w + 1]; z = world[3 * (size_t)w + 2];
-    if (a.X_world) { const float px = x, py = y, pz = z; pose_apply(Xw, px, py, pz, x, y, z); }   // PointCloud.h:80, as transform_batch_kernel
-    u = meas[2 * (size_t)m]; v = meas[2 * (size_t)m + 1];
+    it.x = world[3 * (size_t)w]; it.y = world[3 * (size_t)w + 1]; it.z = world[3 * (size_t)w + 2];
+    if (a.X_world) { const float px = it.x, py = it.y, pz = it.z; pose_apply(Xw, px, py, pz, it.x, it.y, it.z); }   // PointCloud.h:80, as transform_batch_kernel
+    it.u = meas[2 * (size_t)m]; it.v = meas[2 * (size_t)m + 1];
   } else if (a.n_bad) {
     atomicAdd(&a.n_bad[p], 1);        // dropped (marker) and counted: reported in stats_out[4p + 3]
   }
-  dst[i] = x; dst[a.cap + i] = y; dst[2 * a.cap + i] = z; dst[3 * a.cap + i] = u; dst[4 * a.cap + i] = v;
+  return it;
+}
+__device__ __forceinline__ void batch_pack_store(const BatchArgs& a, int p, size_t i, const PackedItem& it) {
+  float* dst = a.packed + (size_t)p * 5 * a.cap;
+  dst[i] = it.x; dst[a.cap + i] = it.y; dst[2 * a.cap + i] = it.z; dst[3 * a.cap + i] = it.u; dst[4 * a.cap + i] = it.v;
+}
+__device__ __forceinline__ void batch_pack_item(const BatchArgs& a, int p, const Pose& Xw, size_t i, int m, int w) {
+  batch_pack_store(a, p, i, batch_pack_load(a, p, Xw, m, w));
 }
 __device__ __forceinline__ Pose batch_pack_pose(const BatchArgs& a, int p) {
   Pose Xw;
