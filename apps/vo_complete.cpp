@@ -5,11 +5,12 @@
 // map_appearances.txt, trajectory_est_complete.txt, trajectory_est_data.txt.
 //   usage: vo_complete <data dir> [output dir] [rounds=100] [--resident [--match-up-front]] [--exact]
 // --resident: the same sequence through vo::DeviceSequence -- all measurement files are read and uploaded first, the
-// whole frame chain runs on the GPU without a host round trip per frame, the map is built afterwards from the
-// per-frame clouds.  Same outputs.
+// whole frame chain runs on the GPU without a host round trip per frame, the map upkeep included (vo_map_*: the
+// reference's upsert as a hash table of first occurrences in device memory).  Same outputs.
 // --exact: the solver in reference-order arithmetic (PICPSolver::setExact): every pose of the chain is then
 // bit-identical to the reference's float32 arithmetic given the same first relative pose.
-// Also written: poses_raw.txt, one camera pose per line (row-major 4x4, %.9g = exact float32 round trip).
+// Also written: poses_raw.txt, one camera pose per line (row-major 4x4, %.9g = exact float32 round trip), and map_raw.txt,
+// one map entry per line (x y z a0..a9, %.9g).
 #include <cstdio>
 #include <iostream>
 
@@ -22,6 +23,17 @@ static void write_poses_raw(const std::string& file, const IsometryVector& traje
   if (!f) return;
   for (const auto& X : trajectory) {
     for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) std::fprintf(f, "%.9g ", X(r, c));
+    std::fprintf(f, "\n");
+  }
+  std::fclose(f);
+}
+
+static void write_map_raw(const std::string& file, const PointCloudVector<3>& map) {
+  std::FILE* f = std::fopen(file.c_str(), "w");
+  if (!f) return;
+  for (size_t i = 0; i < map.size(); ++i) {
+    for (int k = 0; k < 3; ++k) std::fprintf(f, "%.9g ", map.points()[i][k]);
+    for (int k = 0; k < 10; ++k) std::fprintf(f, "%.9g ", map.appearances()[i].v[k]);
     std::fprintf(f, "\n");
   }
   std::fclose(f);
@@ -50,22 +62,18 @@ static int run_resident(const std::string& path, const std::string& out, int rou
   DeviceSequence seq(cam, frames, rounds);
   seq.setExact(exact);
   seq.setMatchUpFront(up_front);              // all consecutive pairs in one batched matcher call before the chain
+  seq.setKeepMap(true);                       // map.update / history inside the chain, on the device (vo_complete.cpp:145-147,175-176)
   seq.run();
   const IsometryVector trajectory = seq.trajectory();          // waits for the chain
-  // map upkeep afterwards, in frame order (vo_complete.cpp:145-147,175-176,181)
-  PointCloudVector<3> map;
-  map.update(seq.cloud(1));
-  Isometry3f history = trajectory[1].inverse();
   for (int t = 2; t < seq.frames(); ++t) {
     int n_match, n_join, n_tri;
     seq.counts(t, n_match, n_join, n_tri);
     const Isometry3f& X = trajectory[(size_t)t];
     std::printf("%s: %d matches, %d model correspondences, t = % .5f % .5f % .5f\n", names[(size_t)t].c_str(), n_match, n_join,
                 X(0, 3), X(1, 3), X(2, 3));
-    map.update(history * seq.cloud(t));
-    history = history * X.inverse();
   }
-  map = H * map;
+  const PointCloudVector<3> map = seq.map(&H);                 // map = H * map (vo_complete.cpp:183)
+  write_map_raw(out + "map_raw.txt", map);
   write_eigen_vectors_to_file(out + "map.txt", map.points());
   write_eigen_vectors_to_file(out + "map_appearances.txt", map.appearances());
   save_trajectory(out + "trajectory_est_complete.txt", trajectory, H);
@@ -157,6 +165,7 @@ int main(int argc, char* argv[]) {
       reference_pc = current_pc;
     }
     map = H * map;
+    write_map_raw(out + "map_raw.txt", map);
     write_eigen_vectors_to_file(out + "map.txt", map.points());
     write_eigen_vectors_to_file(out + "map_appearances.txt", map.appearances());
     save_trajectory(out + "trajectory_est_complete.txt", trajectory, H);

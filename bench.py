@@ -784,8 +784,8 @@ def sequence_leg(vo, ctx, args):
     t0 = time.perf_counter()
     seq = vo.synth.sequence(seed=3000, n_frames=args.seq_frames, n_visible=args.seq_points)
     t_gen = time.perf_counter() - t0
-    def timed(overlap, prematch=False):
-        sp = vo.SequencePipeline(ctx, seq, n_iters=args.seq_iters, overlap_match=overlap, prematch=prematch)
+    def timed(overlap, prematch=False, keep_map=False):
+        sp = vo.SequencePipeline(ctx, seq, n_iters=args.seq_iters, overlap_match=overlap, prematch=prematch, keep_map=keep_map)
         sp.run(); ctx.synchronize()                  # warm-up pass: sizes every workspace, builds the solver graph
         t0 = time.perf_counter()
         sp.start(); ctx.synchronize()
@@ -795,6 +795,8 @@ def sequence_leg(vo, ctx, args):
         ctx.synchronize()
         t2 = time.perf_counter()
         res = [sp.trajectory(), sp.counts(), t1 - t0, t2 - t1, sp.F]
+        if keep_map:
+            res.append(len(sp.map))
         if prematch:                                  # the one batched matcher call on its own
             ctx.synchronize(); t3 = time.perf_counter()
             sp.match_all(); ctx.synchronize()
@@ -807,6 +809,10 @@ def sequence_leg(vo, ctx, args):
     assert np.array_equal(traj, traj2) and np.array_equal(counts, counts2), "overlapped matcher changed the result"
     traj3, counts3, init3, chain3, _, match_all_s = timed(False, prematch=True)
     assert np.array_equal(traj, traj3) and np.array_equal(counts, counts3), "matching up front changed the result"
+    # the loop body as the reference has it: map.update(history * triangulated_pc) and the history step inside the chain
+    # (vo_complete.cpp:175-176), on the device
+    traj4, counts4, init4, chain4, _, map_entries = timed(False, keep_map=True)
+    assert np.array_equal(traj, traj4) and np.array_equal(counts, counts4), "the map upkeep changed the chain"
     m = _sequence_metrics(vo, seq, traj)
     n = [len(f["pts"]) for f in seq["frames"]]
     return {"frames": F, "points_per_frame": {"min": int(min(n)), "max": int(max(n))}, "landmarks": len(seq["world_xyz"]),
@@ -814,6 +820,11 @@ def sequence_leg(vo, ctx, args):
             "chain_ms": chain_s * 1e3, "frames_per_sec": (F - 2) / chain_s,
             "ms_per_frame": chain_s * 1e3 / (F - 2),
             "picp_iters_per_sec": (F - 2) * args.seq_iters / chain_s,
+            "with_map": {"frames_per_sec": (F - 2) / chain4, "ms_per_frame": chain4 * 1e3 / (F - 2), "chain_ms": chain4 * 1e3,
+                         "map_entries": map_entries, "map_update_ms_per_frame": (chain4 - chain_s) * 1e3 / (F - 2),
+                         "note": "the same chain with the loop body's map upkeep inside it, on the device: map.update(history * "
+                                 "triangulated_pc) keyed by exact appearance equality (PointCloud.h:52-66) + history = history * "
+                                 "pose^-1 (vo_complete.cpp:175-176); frames_per_sec above is the chain without it"},
             "frames_per_sec_matcher_on_second_stream": (F - 2) / chain2,
             "matched_up_front": {"frames_per_sec": (F - 2) / (chain3 + match_all_s), "chain_ms": chain3 * 1e3,
                                  "match_all_ms": match_all_s * 1e3, "init_ms": init3 * 1e3,

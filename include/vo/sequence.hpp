@@ -4,9 +4,11 @@
 // vo_estimate_transform (the only host round trip) and triangulated; every later frame is
 //     match -> join -> X_curr * model -> n x oneRound from the identity -> triangulate
 // chained through device-side counts and the solver's device-side pose -- no host synchronisation per frame.
-// The triangulated cloud of every frame stays on the device until cloud(t) fetches it (the map upkeep,
-// PointCloudVector::update, is host code and runs afterwards).  Results are bit-identical to driving the same
-// kernels frame by frame through Camera / PICPSolver / triangulate_points.
+// The triangulated cloud of every frame stays on the device until cloud(t) fetches it.  setKeepMap(true): the map upkeep
+// of the loop body -- map.update(history * triangulated_pc), history = history * pose^-1 (vo_complete.cpp:145-147,
+// 175-176; PointCloud.h:52-66) -- runs on the device too, inside the chain (vo_map_*: a hash table of first
+// occurrences instead of the reference's O(N M) scan; same entries in the same order); map() fetches it.  Results are
+// bit-identical to driving the same kernels frame by frame through Camera / PICPSolver / triangulate_points.
 // setMatchUpFront(true): the matcher needs the appearances alone, so all F-1 consecutive pairs are matched by ONE
 // vo_match_appearances_batch_dev call before the chain starts (frames of different sizes; the appearances are held as
 // [F][capacity][10], so the pairs (t-1, t) are two views of one array; more than 65535 pairs go in several calls); same
@@ -61,6 +63,7 @@ class DeviceSequence {
     check(vo_picp_pose_dev_ptr(solver_, &d_pose_), "vo_picp_pose_dev_ptr");
   }
   ~DeviceSequence() {
+    if (map_) vo_map_destroy(map_);
     if (solver_) vo_picp_destroy(solver_);
     for (void* d : owned_) vo_dev_free(ctx_, d);
   }
@@ -70,6 +73,16 @@ class DeviceSequence {
   int frames() const { return F_; }
   //! reference-order arithmetic for every solve of the chain (vo_picp_set_exact)
   void setExact(bool on) { check(vo_picp_set_exact(solver_, on ? 1 : 0), "vo_picp_set_exact"); }
+  //! keep the map inside the chain (vo_complete.cpp:145-147,175-176), on the device; capacity: entries to make room for up
+  //! front (default: every point of the sequence could be a new landmark, up to 8 frames' worth -- the map grows beyond)
+  void setKeepMap(bool on, size_t capacity = 0) {
+    if (ran_) throw Error(VO_ERR_INVALID_ARG, "DeviceSequence: setKeepMap after run()");
+    if (on && !map_) {
+      const size_t cap = capacity ? capacity : std::min(off_.back(), 8 * cap_);
+      check(vo_map_create(ctx_, (int)std::min<size_t>(cap, 0x3fffffff), &map_), "vo_map_create");
+    }
+    keep_map_ = on;
+  }
   //! match every consecutive pair in one batched call at the start of run() instead of one call per frame inside the chain
   void setMatchUpFront(bool on) {
     if (ran_) throw Error(VO_ERR_INVALID_ARG, "DeviceSequence: the matching mode cannot change after run()");
@@ -118,6 +131,12 @@ class DeviceSequence {
     const Isometry3f I = Isometry3f::Identity();
     check(vo_memcpy_h2d(ctx_, d_traj_, I.data(), 64), "DeviceSequence::run");
     check(vo_memcpy_h2d(ctx_, d_traj_ + 16, X0_.data(), 64), "DeviceSequence::run");
+    if (keep_map_) {                                             // vo_complete.cpp:145-146
+      check(vo_map_clear(map_), "vo_map_clear");
+      map_update(1, nullptr);
+      check(vo_map_history_reset_dev(map_, d_traj_ + 16), "vo_map_history_reset_dev");
+      check(vo_map_history_dev_ptr(map_, &d_history_), "vo_map_history_dev_ptr");
+    }
     // every later frame: vo_complete.cpp:150-179
     for (int t = 2; t < F_; ++t) {
       const int nq = (int)std::min(n(t - 1), n(t)), nq_prev = (int)std::min(n(t - 2), n(t - 1));
@@ -132,7 +151,23 @@ class DeviceSequence {
       check(vo_picp_solve_dev(solver_, d_j_, (int)cap_, cnt(t, 1), 0, rounds_), "vo_picp_solve_dev");
       check(vo_picp_get_pose_dev(solver_, d_traj_ + 16 * (size_t)t), "vo_picp_get_pose_dev");
       triangulate(t, nullptr);
+      if (keep_map_) {                                           // vo_complete.cpp:175-176
+        map_update(t, d_history_);
+        check(vo_map_history_step_dev(map_, d_pose_), "vo_map_history_step_dev");
+      }
     }
+  }
+
+  //! the map (setKeepMap): entries in the order the reference's update leaves them; H (or null): map = H * map first
+  //! (vo_complete.cpp:183; applied once, in place).  Waits for the chain.
+  PointCloudVector<3> map(const Isometry3f* H = nullptr) {
+    if (!keep_map_ || !map_) throw Error(VO_ERR_NOT_READY, "DeviceSequence::map: setKeepMap(true) before run()");
+    if (H) check(vo_map_transform(map_, H->data()), "vo_map_transform");
+    int k = 0;
+    check(vo_map_size(map_, &k), "vo_map_size");
+    PointCloudVector<3> pc((size_t)k);
+    if (k) check(vo_map_read(map_, pc.points()[0].data(), pc.appearances()[0].data(), k, &k), "vo_map_read");
+    return pc;
   }
 
   //! poses of the trajectory (identity, X_1, X_2, ...); waits for the chain
@@ -196,6 +231,10 @@ class DeviceSequence {
     check(vo_match_appearances_dev(ctx_, app_of(t - 1), (int)n(t - 1), app_of(t), (int)n(t), 0.1f, d_m_, cnt(t, 0)),
           "vo_match_appearances_dev");
   }
+  void map_update(int t, const float* d_T16) {
+    const int nq = (int)std::min(n(t - 1), n(t));
+    check(vo_map_update_dev(map_, xyz_of(t), d_tapp_ + 10 * cap_ * (size_t)t, nq, cnt(t, 2), d_T16), "vo_map_update_dev");
+  }
   void triangulate(int t, const float* X_host) {
     const int nq = (int)std::min(n(t - 1), n(t));
     check(vo_triangulate_dev(ctx_, cam_.cameraMatrix().data(), X_host, X_host ? nullptr : d_pose_, m_of(t), nq, cnt(t, 0),
@@ -211,6 +250,9 @@ class DeviceSequence {
   Vector2fVector first_[2];
   Isometry3f X0_ = Isometry3f::Identity();
   vo_picp* solver_ = nullptr;
+  vo_map* map_ = nullptr;
+  bool keep_map_ = false;
+  const float* d_history_ = nullptr;
   const float* d_pose_ = nullptr;
   float *d_pts_ = nullptr, *d_app_ = nullptr, *d_model_t_ = nullptr, *d_xyz_ = nullptr, *d_tapp_ = nullptr, *d_traj_ = nullptr,
         *d_ident_ = nullptr;

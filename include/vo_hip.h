@@ -390,6 +390,39 @@ int vo_match_appearances_batch_dev(vo_ctx *ctx, int n_frames, const float *d_a1,
                                    const float *d_a2, int cap2, const int *d_n2, float radius, int32_t *d_out_pairs,
                                    int *d_n_out);
 
+/* ---- the map (PointCloud.h:52-66; vo_complete.cpp:145-147,175-176,181-183) ---------------------------------------
+ * PointCloudVector<3> `map` of vo_complete, resident on the GPU.  map.update(cloud) is the reference's upsert keyed by
+ * EXACT equality of the ten appearance floats (operator==: -0 equals +0, a row with a NaN equals nothing, itself
+ * included): for every point of the cloud, in order, the first entry with an equal appearance gets the point, otherwise
+ * the pair is appended (and found by later points of the same cloud).  Equivalent, and what the kernels compute
+ * (map.hip): every class of equal appearances keeps the appearance bits of its first occurrence ever and the point of
+ * its last occurrence so far; new classes are appended in the order of their first occurrence in the cloud; NaN rows
+ * are always appended.  O(cloud) per update through a hash table of first occurrences (the reference: O(cloud x map)).
+ * All calls are enqueued on the context's stream; only vo_map_size / vo_map_read / vo_map_get_history wait.
+ * The arrays grow by themselves (a stream synchronisation and a copy when they do: give vo_map_create the capacity a
+ * run will need to avoid it; growing is refused inside a graph capture). */
+typedef struct vo_map vo_map;
+int vo_map_create(vo_ctx *ctx, int capacity, vo_map **out);
+int vo_map_destroy(vo_map *m);
+int vo_map_clear(vo_map *m);                                   /* empty map, history = identity */
+/* map.update(T * cloud): d_xyz [n_max][3], d_app [n_max][10] (8-byte aligned), *d_n_rows (or NULL) <= n_max rows are
+ * live, d_T16 (or NULL: identity) a column-major 4x4 in device memory applied to every point -- `history *
+ * triangulated_pc` of vo_complete.cpp:175 with d_T16 = vo_map_history_dev_ptr() -- as PointCloud.h:77-82 does. */
+int vo_map_update_dev(vo_map *m, const float *d_xyz, const float *d_app, int n_max, const int *d_n_rows, const float *d_T16);
+int vo_map_update(vo_map *m, const float *xyz, const float *app, int n, const float T16[16] /* or NULL */);   /* host arrays */
+/* the `history` isometry of vo_complete, kept on the device: reset = X^-1 (vo_complete.cpp:146), step = history * X^-1
+ * (:176), both from a pose in device memory (e.g. vo_picp_pose_dev_ptr), in the reference's float arithmetic */
+int vo_map_history_reset_dev(vo_map *m, const float *d_X16);
+int vo_map_history_step_dev(vo_map *m, const float *d_X16);
+int vo_map_history_dev_ptr(vo_map *m, const float **d_T16);
+int vo_map_get_history(vo_map *m, float T16[16]);
+int vo_map_transform(vo_map *m, const float T16[16]);           /* map = H * map (vo_complete.cpp:183), in place */
+int vo_map_size(vo_map *m, int *n);
+/* copies min(size, capacity) entries to the host (either array may be NULL); *n_out = size */
+int vo_map_read(vo_map *m, float *xyz, float *app, int capacity, int *n_out);
+/* the arrays in device memory (entries [0, *d_size)); they move when the map grows */
+int vo_map_dev_ptrs(vo_map *m, const float **d_xyz, const float **d_app, const int **d_size);
+
 #ifdef __cplusplus
 }
 #endif

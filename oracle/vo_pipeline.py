@@ -133,20 +133,69 @@ def iso_inv(T):
     return X
 
 
+def _dot3_32(a0, b0, a1, b1, a2, b2):
+    """a 3-term inner product in float32 as Eigen 3.4 sums it (fixed size, not vectorised): x0 + (x1 + x2)"""
+    f = np.float32
+    return f(f(f(a0) * f(b0)) + f(f(f(a1) * f(b1)) + f(f(a2) * f(b2))))
+
+
+def iso_inv32(T):
+    """Isometry3f::inverse() in float32: R^T, -(R^T t) (vo_complete.cpp:146,176)"""
+    T = np.asarray(T, np.float32)
+    X = np.eye(4, dtype=np.float32)
+    X[:3, :3] = T[:3, :3].T
+    for r in range(3):
+        X[r, 3] = -_dot3_32(X[r, 0], T[0, 3], X[r, 1], T[1, 3], X[r, 2], T[2, 3])
+    return X
+
+
+def iso_mul32(A, B):
+    """Isometry3f * Isometry3f in float32: R = Ra Rb, t = Ra tb + ta (vo_complete.cpp:176)"""
+    A = np.asarray(A, np.float32); B = np.asarray(B, np.float32)
+    C = np.eye(4, dtype=np.float32)
+    for c in range(3):
+        for r in range(3):
+            C[r, c] = _dot3_32(A[r, 0], B[0, c], A[r, 1], B[1, c], A[r, 2], B[2, c])
+    for r in range(3):
+        C[r, 3] = np.float32(_dot3_32(A[r, 0], B[0, 3], A[r, 1], B[1, 3], A[r, 2], B[2, 3]) + np.float32(A[r, 3]))
+    return C
+
+
 class Map:
-    """PointCloudVector::update (PointCloud.h:52-66)"""
+    """PointCloudVector::update (PointCloud.h:52-66): for every point of the cloud, in order, the first entry whose
+    appearance compares equal -- operator== on ten floats: -0 equals +0, a row with a NaN equals nothing -- gets the
+    point, otherwise the pair is appended.  The dictionary holds the first entry of every class, keyed by the bytes of the
+    row with -0 turned into +0 (x + 0.0); NaN rows are appended without a key.  literal_update() below is the double
+    loop itself, for the tests that pin this shortcut."""
 
     def __init__(self):
         self.pts, self.app, self.idx = [], [], {}
 
     def update(self, pts, app):
         for p, a in zip(pts, app):
-            k = a.tobytes()
+            a = np.asarray(a, np.float32)
+            if np.isnan(a).any():
+                self.pts.append(p); self.app.append(a)
+                continue
+            k = (a + np.float32(0.0)).tobytes()
             if k in self.idx:
                 self.pts[self.idx[k]] = p
             else:
                 self.idx[k] = len(self.pts)
                 self.pts.append(p); self.app.append(a)
+
+
+def literal_update(map_pts, map_app, pts, app):
+    """the reference's loops as written (PointCloud.h:52-66), on Python lists of float32 arrays; O(N M)"""
+    for p, a in zip(pts, app):
+        found = False
+        for j in range(len(map_app)):
+            if bool(np.all(map_app[j] == a)):          # Eigen's operator==: every component compares equal
+                map_pts[j] = p
+                found = True
+                break
+        if not found:
+            map_pts.append(p); map_app.append(a)
 
 
 def id_correspondences(ids_ref, ids_cur):
@@ -187,7 +236,7 @@ def run_sequence(frames, K, rows, cols, zn, zf, rounds=100, o: Oracle | None = N
     m = Map()
     if keep_map:
         m.update(tri, tri_app)
-    history = iso_inv(X.astype(np.float64)).astype(np.float32)
+    history = iso_inv32(X)                                       # Isometry3f arithmetic, like the reference (vo_complete.cpp:146)
     X_curr = X
     ref_pts, ref_app = cur_pts, cur_app
     stats, tri_counts = [], [len(tri)]
@@ -204,7 +253,7 @@ def run_sequence(frames, K, rows, cols, zn, zf, rounds=100, o: Oracle | None = N
         tri_counts.append(len(tri))
         if keep_map:
             m.update(o.transform_points(history, tri) if len(tri) else tri, tri_app)
-        history = (history.astype(np.float64) @ iso_inv(X_curr.astype(np.float64))).astype(np.float32)
+        history = iso_mul32(history, iso_inv32(X_curr))          # vo_complete.cpp:176
         ref_pts, ref_app = cur_pts, cur_app
     return dict(trajectory=traj, stats=stats, tri_counts=tri_counts, map=m)
 

@@ -265,6 +265,13 @@ def test_example_data_chain_is_bit_identical_to_ref32(tmp_path, o32):
     assert np.array_equal(np.array(counts, dtype=int), np.array(res["stats"], dtype=int))
     ref = np.array(res["trajectory"], dtype=np.float32)
     assert np.array_equal(poses, ref)
+    # the map the loop body keeps (vo_complete.cpp:145-147,175-176,183): map_raw.txt = map.txt + map_appearances.txt at full
+    # precision, every entry in order, bit for bit -- host upkeep (PointCloudVector::update behind the facade) here ...
+    want_map = np.concatenate([res["map"], res["map_app"]], axis=1).astype(np.float32)
+
+    def map_of(d):
+        return np.loadtxt(os.path.join(d, "map_raw.txt"), dtype=np.float64).astype(np.float32).reshape(-1, 13)
+    assert len(want_map) > 400 and np.array_equal(map_of(tmp_path), want_map)
     # the epipolar initialisation itself (f-1): host double Jacobi vs the oracle's numpy SVDs
     res0 = vp.run_vo_complete(DATA, rounds=1, o=o32)
     assert np.abs(poses[1] - res0["trajectory"][1]).max() < 2e-5
@@ -273,8 +280,10 @@ def test_example_data_chain_is_bit_identical_to_ref32(tmp_path, o32):
     rdir.mkdir()
     _, poses_r = _run_app(rdir, "--exact", "--resident")
     assert np.array_equal(poses_r, poses)
+    assert np.array_equal(map_of(rdir), want_map)            # ... and the device map inside the chain (vo_map_*) there
     # ... also with all 120 consecutive pairs of the dataset (14..127 points per frame) matched by ONE batched call up front
     udir = tmp_path / "upfront"
     udir.mkdir()
     _, poses_u = _run_app(udir, "--exact", "--resident", "--match-up-front")
     assert np.array_equal(poses_u, poses)
+    assert np.array_equal(map_of(udir), want_map)

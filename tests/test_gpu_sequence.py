@@ -274,3 +274,38 @@ def test_degenerate_sequences_in_the_default_arithmetic(vo, ctx, o32, case):
     if case in ("empty5", "foreign5"):
         assert np.array_equal(tf[5], np.eye(4, dtype=np.float32))            # no correspondence: dx = 0, the pose stays the identity
     assert np.array_equal(np.isnan(tf).any(axis=(1, 2)), np.isnan(te).any(axis=(1, 2)))     # poisoned frames: the same ones
+
+
+def test_device_map_inside_the_chain_equals_the_reference_loop(vo, ctx, o32, seq_run):
+    """keep_map: map.update(history * triangulated_pc) and history = history * pose^-1 (vo_complete.cpp:145-147,175-176)
+    on the device, inside the chain, solver in reference-order arithmetic: the chain is then the oracle's chain bit for bit
+    (tests above), so the map must be the oracle's map -- every entry, in order, point and appearance bits -- and the history
+    isometry the oracle's."""
+    seq, d, res0, P = seq_run
+    sp = vo.SequencePipeline(ctx, seq, n_iters=ROUNDS, exact=True, keep_map=True, map_capacity=64)     # (it has to grow)
+    sp.run()
+    traj = sp.trajectory()
+    pts, app = sp.map.read()
+    hist = sp.map.history()
+    frames = [(f["pts"], f["app"]) for f in seq["frames"]]
+    res = P.run_sequence(frames, seq["K"], seq["rows"], seq["cols"], seq["z_near"], seq["z_far"], rounds=ROUNDS, o=o32, X0=traj[1])
+    assert np.array_equal(np.array(traj), np.array(res["trajectory"], dtype=np.float32))
+    m = res["map"]
+    assert len(pts) == len(m.pts) > 2 * N_VISIBLE
+    assert pts.tobytes() == np.array(m.pts, np.float32).tobytes()
+    assert app.tobytes() == np.array(m.app, np.float32).tobytes()
+    h = P.iso_inv32(traj[1])
+    for X in traj[2:]:
+        h = P.iso_mul32(h, P.iso_inv32(X))
+    assert np.array_equal(hist, h)
+    # running it again on the same object starts from an empty map
+    sp.run()
+    p2, a2 = sp.map.read()
+    assert p2.tobytes() == pts.tobytes() and a2.tobytes() == app.tobytes()
+    sp.close()
+    # the default arithmetic keeps the same entries (the appearances do not depend on the pose)
+    sp = vo.SequencePipeline(ctx, seq, n_iters=ROUNDS, keep_map=True)
+    sp.run()
+    p3, a3 = sp.map.read()
+    sp.close()
+    assert a3.tobytes() == app.tobytes() and np.abs(p3 - pts).max() < 5e-2

@@ -12,6 +12,7 @@ from .api import (  # noqa: F401
     Context,
     Event,
     KdTree,
+    Map,
     PICPSolver,
     VoError,
     compute_correspondences_images,

@@ -308,6 +308,77 @@ class PICPSolver:
         return H.reshape(6, 6).T.copy(), b
 
 
+class Map:
+    """PointCloudVector<3> `map` of vo_complete on the GPU (vo_map_*): update() is PointCloud.h:52-66, the history
+    isometry vo_complete.cpp:145-147,175-176."""
+
+    def __init__(self, ctx: Context | None = None, capacity: int = 0):
+        self.ctx = ctx or default_context()
+        self.lib = self.ctx.lib
+        h = C.c_void_p()
+        _chk(self.lib.vo_map_create(self.ctx.h, C.c_int(capacity), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vo_map_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        _chk(self.lib.vo_map_clear(self.h))
+
+    def update(self, points, appearances, T=None):
+        """map.update(T * cloud) from host arrays"""
+        p = _f32(points, (-1, 3))
+        a = _f32(appearances, (-1, 10))
+        assert len(p) == len(a)
+        _chk(self.lib.vo_map_update(self.h, _ptr(p), _ptr(a), C.c_int(len(p)), _ptr(_colmajor(T, 4)) if T is not None else None))
+
+    def update_dev(self, d_xyz, d_app, n_max, d_n=None, d_T16=None):
+        _chk(self.lib.vo_map_update_dev(self.h, C.c_void_p(d_xyz), C.c_void_p(d_app), C.c_int(n_max),
+                                        C.c_void_p(d_n) if d_n else None, C.c_void_p(d_T16) if d_T16 else None))
+
+    def history_reset_dev(self, d_X16):
+        _chk(self.lib.vo_map_history_reset_dev(self.h, C.c_void_p(d_X16)))
+
+    def history_step_dev(self, d_X16):
+        _chk(self.lib.vo_map_history_step_dev(self.h, C.c_void_p(d_X16)))
+
+    @property
+    def history_dev(self):
+        p = C.c_void_p()
+        _chk(self.lib.vo_map_history_dev_ptr(self.h, C.byref(p)))
+        return p.value
+
+    def history(self):
+        T = np.zeros(16, np.float32)
+        _chk(self.lib.vo_map_get_history(self.h, _ptr(T)))
+        return T.reshape(4, 4).T.copy()
+
+    def transform(self, T):
+        _chk(self.lib.vo_map_transform(self.h, _ptr(_colmajor(T, 4))))
+
+    def __len__(self):
+        n = C.c_int()
+        _chk(self.lib.vo_map_size(self.h, C.byref(n)))
+        return n.value
+
+    def read(self):
+        """(points (n, 3), appearances (n, 10)) in entry order"""
+        n = len(self)
+        p = np.zeros((max(n, 1), 3), np.float32)
+        a = np.zeros((max(n, 1), 10), np.float32)
+        m = C.c_int()
+        _chk(self.lib.vo_map_read(self.h, _ptr(p), _ptr(a), C.c_int(n), C.byref(m)))
+        return p[:n].copy(), a[:n].copy()
+
+
 def triangulate_points(k, X, correspondences, p1_img, p2_img, app2=None, want_pairs=True,
                        ctx: Context | None = None):
     """utils.cpp:51-134.  Returns (triangulated, correspondences_new, appearances)."""

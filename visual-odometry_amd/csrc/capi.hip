@@ -1457,4 +1457,223 @@ int vo_estimate_transform(vo_ctx* c, const float K[9], const int32_t* pairs, int
   return VO_OK;
 }
 
+// ---- the map (PointCloudVector<3>::update + the history chain of vo_complete.cpp:145-147,175-176,183) ---------------------------
+struct vo_map {
+  vo_ctx* ctx = nullptr;
+  unsigned long long ctx_id = 0;
+  MapDev d;
+  DevBuf scratch;
+  float* hist = nullptr;        // [0,16) the history isometry, [16,32) staging of a host isometry (vo_map_update)
+  long long size_ub = 0;        // upper bound of the size known without asking the device
+  DevBuf up_xyz, up_app;        // staging of vo_map_update
+};
+
+static unsigned map_tcap_for(int cap) {
+  unsigned t = 1024;
+  while (t < 2u * (unsigned)cap + 2u * ((unsigned)cap >> 2)) t <<= 1;      // at most 40 % full
+  return t;
+}
+
+static void map_free_arrays(MapDev& d) {
+  if (d.pts) (void)hipFree(d.pts);
+  if (d.app) (void)hipFree(d.app);
+  if (d.table) (void)hipFree(d.table);
+  if (d.last) (void)hipFree(d.last);
+  d.pts = d.app = nullptr; d.table = nullptr; d.last = nullptr;
+}
+
+static int map_alloc_arrays(MapDev& d, int cap) {
+  d.cap = cap; d.tcap = map_tcap_for(cap);
+  VO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d.pts), sizeof(float) * 3 * (size_t)cap));
+  VO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d.app), sizeof(float) * 10 * (size_t)cap));
+  VO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d.table), sizeof(unsigned long long) * (size_t)d.tcap));
+  VO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d.last), sizeof(int) * (size_t)d.tcap));
+  return VO_OK;
+}
+
+// room for n more entries: the bound the host keeps (size_ub grows by a cloud's row count per update) is refreshed from
+// the device only when it would pass the capacity, and the arrays grow only when the true size would
+static int map_reserve(vo_map* m, int n) {
+  vo_ctx* c = m->ctx;
+  if (m->size_ub + n <= m->d.cap) return VO_OK;
+  if (c->capturing) return fail(VO_ERR_NOT_READY, "vo_map: the map would have to grow inside a graph capture (create it with the capacity it will need)");
+  int size = 0;
+  VO_HIP_CHECK(hipMemcpyAsync(&size, m->d.hdr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  m->size_ub = size;
+  if ((long long)size + n <= m->d.cap) return VO_OK;
+  long long want = 2ll * m->d.cap;
+  if (want < (long long)size + n) want = (long long)size + n + ((long long)size + n) / 2;
+  if (want > 0x3fffffffll) return fail(VO_ERR_INVALID_ARG, "vo_map: more than 2^30 entries");
+  MapDev old = m->d;
+  MapDev nd = old;
+  nd.pts = nd.app = nullptr; nd.table = nullptr; nd.last = nullptr;
+  if (int r = map_alloc_arrays(nd, (int)want)) { map_free_arrays(nd); return r; }
+  if (size > 0) {
+    VO_HIP_CHECK(hipMemcpyAsync(nd.pts, old.pts, sizeof(float) * 3 * (size_t)size, hipMemcpyDeviceToDevice, c->stream));
+    VO_HIP_CHECK(hipMemcpyAsync(nd.app, old.app, sizeof(float) * 10 * (size_t)size, hipMemcpyDeviceToDevice, c->stream));
+  }
+  VO_HIP_CHECK(launch_map_rehash(c->stream, nd, size));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  map_free_arrays(old);
+  m->d = nd;
+  return VO_OK;
+}
+
+#define VO_MAP_LIVE(m) \
+  do { VO_REQUIRE(m, "null map"); VO_REQUIRE(ctx_alive((m)->ctx, (m)->ctx_id), "the context this map was made on has been destroyed"); } while (0)
+
+int vo_map_create(vo_ctx* c, int capacity, vo_map** out) {
+  VO_REQUIRE(c && out, "null argument");
+  VO_NOT_CAPTURING(c);
+  VO_REQUIRE(capacity >= 0 && capacity <= 0x3fffffff, "bad capacity");
+  *out = nullptr;
+  if (int r = set_device(c)) return r;
+  vo_map* m = new vo_map();
+  m->ctx = c; m->ctx_id = c->id;
+  const int cap = capacity < 1024 ? 1024 : capacity;
+  int rc = map_alloc_arrays(m->d, cap);
+  if (rc == VO_OK && hipMalloc(reinterpret_cast<void**>(&m->d.hdr), 64) != hipSuccess) rc = fail(VO_ERR_OUT_OF_MEMORY, "vo_map_create: out of device memory");
+  if (rc == VO_OK && hipMalloc(reinterpret_cast<void**>(&m->hist), sizeof(float) * 32) != hipSuccess) rc = fail(VO_ERR_OUT_OF_MEMORY, "vo_map_create: out of device memory");
+  if (rc != VO_OK) { (void)hipGetLastError(); map_free_arrays(m->d); if (m->d.hdr) (void)hipFree(m->d.hdr); if (m->hist) (void)hipFree(m->hist); delete m; return rc; }
+  *out = m;
+  return vo_map_clear(m);
+}
+
+int vo_map_destroy(vo_map* m) {
+  if (!m) return VO_OK;
+  if (ctx_alive(m->ctx, m->ctx_id)) {
+    VO_NOT_CAPTURING(m->ctx);
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+  } else {
+    (void)hipDeviceSynchronize();
+  }
+  map_free_arrays(m->d);
+  if (m->d.hdr) (void)hipFree(m->d.hdr);
+  if (m->hist) (void)hipFree(m->hist);
+  m->scratch.release(); m->up_xyz.release(); m->up_app.release();
+  delete m;
+  return VO_OK;
+}
+
+int vo_map_clear(vo_map* m) {
+  VO_MAP_LIVE(m);
+  vo_ctx* c = m->ctx;
+  VO_NOT_CAPTURING(c);
+  if (int r = set_device(c)) return r;
+  VO_HIP_CHECK(hipMemsetAsync(m->d.hdr, 0, 64, c->stream));
+  VO_HIP_CHECK(launch_map_rehash(c->stream, m->d, 0));
+  const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  VO_HIP_CHECK(hipMemcpyAsync(m->hist, I, sizeof(I), hipMemcpyHostToDevice, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  m->size_ub = 0;
+  return VO_OK;
+}
+
+int vo_map_update_dev(vo_map* m, const float* d_xyz, const float* d_app, int n_max, const int* d_n, const float* d_T16) {
+  VO_MAP_LIVE(m);
+  VO_REQUIRE(n_max >= 0 && (n_max == 0 || (d_xyz && d_app)), "bad cloud");
+  VO_REQUIRE(aligned8(d_app), "device appearance rows must be 8-byte aligned");
+  if (n_max == 0) return VO_OK;
+  vo_ctx* c = m->ctx;
+  if (int r = set_device(c)) return r;
+  if (int r = map_reserve(m, n_max)) return r;
+  VO_HIP_CHECK(m->scratch.ensure(sizeof(int) * map_scratch_ints(n_max), c->stream));
+  VO_HIP_CHECK(launch_map_update(c->stream, m->d, d_xyz, d_app, n_max, d_n, d_T16, m->scratch.as<int>()));
+  m->size_ub += n_max;
+  return VO_OK;
+}
+
+int vo_map_update(vo_map* m, const float* xyz, const float* app, int n, const float T16[16]) {
+  VO_MAP_LIVE(m);
+  VO_NOT_CAPTURING(m->ctx);
+  VO_REQUIRE(n >= 0 && (n == 0 || (xyz && app)), "bad cloud");
+  if (n == 0) return VO_OK;
+  vo_ctx* c = m->ctx;
+  if (int r = set_device(c)) return r;
+  if (int r = upload(c, m->up_xyz, xyz, sizeof(float) * 3 * (size_t)n)) return r;
+  if (int r = upload(c, m->up_app, app, sizeof(float) * 10 * (size_t)n)) return r;
+  if (T16) VO_HIP_CHECK(hipMemcpyAsync(m->hist + 16, T16, sizeof(float) * 16, hipMemcpyHostToDevice, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));          // the host arrays may go away after the call
+  return vo_map_update_dev(m, m->up_xyz.as<float>(), m->up_app.as<float>(), n, nullptr, T16 ? m->hist + 16 : nullptr);
+}
+
+int vo_map_history_reset_dev(vo_map* m, const float* d_X16) {
+  VO_MAP_LIVE(m);
+  VO_REQUIRE(d_X16, "null pose");
+  if (int r = set_device(m->ctx)) return r;
+  VO_HIP_CHECK(launch_map_history(m->ctx->stream, m->hist, d_X16, 1));
+  return VO_OK;
+}
+
+int vo_map_history_step_dev(vo_map* m, const float* d_X16) {
+  VO_MAP_LIVE(m);
+  VO_REQUIRE(d_X16, "null pose");
+  if (int r = set_device(m->ctx)) return r;
+  VO_HIP_CHECK(launch_map_history(m->ctx->stream, m->hist, d_X16, 0));
+  return VO_OK;
+}
+
+int vo_map_history_dev_ptr(vo_map* m, const float** d_T16) {
+  VO_MAP_LIVE(m);
+  VO_REQUIRE(d_T16, "null argument");
+  *d_T16 = m->hist;
+  return VO_OK;
+}
+
+int vo_map_get_history(vo_map* m, float T16[16]) {
+  VO_MAP_LIVE(m);
+  VO_REQUIRE(T16, "null argument");
+  VO_NOT_CAPTURING(m->ctx);
+  if (int r = set_device(m->ctx)) return r;
+  VO_HIP_CHECK(hipMemcpyAsync(T16, m->hist, sizeof(float) * 16, hipMemcpyDeviceToHost, m->ctx->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  return VO_OK;
+}
+
+int vo_map_size(vo_map* m, int* n) {
+  VO_MAP_LIVE(m);
+  VO_REQUIRE(n, "null argument");
+  VO_NOT_CAPTURING(m->ctx);
+  if (int r = set_device(m->ctx)) return r;
+  int h[4] = {0, 0, 0, 0};
+  VO_HIP_CHECK(hipMemcpyAsync(h, m->d.hdr, sizeof(h), hipMemcpyDeviceToHost, m->ctx->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  m->size_ub = h[0];
+  *n = h[0];
+  if (h[3] > 0) return fail(VO_ERR_BAD_INDEX, "vo_map: %d entries were dropped for lack of room", h[3]);
+  return VO_OK;
+}
+
+int vo_map_read(vo_map* m, float* xyz, float* app, int capacity, int* n_out) {
+  VO_MAP_LIVE(m);
+  VO_REQUIRE(capacity >= 0 && n_out, "bad arguments");
+  int n = 0;
+  if (int r = vo_map_size(m, &n)) return r;
+  *n_out = n;
+  const int k = n < capacity ? n : capacity;
+  if (k > 0 && xyz) VO_HIP_CHECK(hipMemcpyAsync(xyz, m->d.pts, sizeof(float) * 3 * (size_t)k, hipMemcpyDeviceToHost, m->ctx->stream));
+  if (k > 0 && app) VO_HIP_CHECK(hipMemcpyAsync(app, m->d.app, sizeof(float) * 10 * (size_t)k, hipMemcpyDeviceToHost, m->ctx->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  return VO_OK;
+}
+
+int vo_map_transform(vo_map* m, const float T16[16]) {
+  VO_MAP_LIVE(m);
+  VO_REQUIRE(T16, "null argument");
+  if (int r = set_device(m->ctx)) return r;
+  const long long bound = m->size_ub < m->d.cap ? m->size_ub : m->d.cap;
+  VO_HIP_CHECK(launch_map_transform(m->ctx->stream, m->d, pose_from_T16(T16), (int)bound));
+  return VO_OK;
+}
+
+int vo_map_dev_ptrs(vo_map* m, const float** d_xyz, const float** d_app, const int** d_size) {
+  VO_MAP_LIVE(m);
+  if (d_xyz) *d_xyz = m->d.pts;
+  if (d_app) *d_app = m->d.app;
+  if (d_size) *d_size = m->d.hdr;
+  return VO_OK;
+}
+
 }  // extern "C"

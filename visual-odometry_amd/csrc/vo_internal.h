@@ -266,4 +266,22 @@ hipError_t launch_match(hipStream_t st, const float* d_a1, int n1, const float* 
                         unsigned long long* d_best /* min(n1,n2) u64 */, int* d_scratch, int n_cu,
                         void* d_prune_ws, int variant);
 
+// ---- the map on the device (map.hip) ------------------------------------------------------------------
+struct MapDev {
+  float* pts = nullptr;                 // [cap][3]
+  float* app = nullptr;                 // [cap][10]
+  unsigned long long* table = nullptr;  // [tcap] open addressing, (tag << 32) | entry
+  int* last = nullptr;                  // [tcap]
+  int* hdr = nullptr;                   // [0] size [1] base of the last update [2] its rows [3] rows dropped for lack of room (never, unless misused)
+  unsigned tcap = 0;                    // a power of two, >= 2 * cap
+  int cap = 0;
+};
+size_t map_scratch_ints(int n_max);
+// PointCloudVector<3>::update(T * cloud) (PointCloud.h:52-66,77-82); d_T16 / d_n may be null; d_scratch: map_scratch_ints(n_max) ints
+hipError_t launch_map_update(hipStream_t st, const MapDev& m, const float* d_xyz, const float* d_app, int n_max, const int* d_n,
+                             const float* d_T16, int* d_scratch);
+hipError_t launch_map_rehash(hipStream_t st, const MapDev& m, int size_bound);      // empties the table, enters entries 0 .. size-1
+hipError_t launch_map_history(hipStream_t st, float* d_hist16, const float* d_X16, int reset);
+hipError_t launch_map_transform(hipStream_t st, const MapDev& m, const Pose& T, int size_bound);
+
 }  // namespace vo

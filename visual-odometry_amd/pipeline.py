@@ -379,12 +379,13 @@ class SequencePipeline:
     (SURVEY 8(d) config 3): all measurement files are uploaded up front; the first pair is matched,
     initialised by vo_estimate_transform (the only host round trip) and triangulated; every later
     frame is match -> join -> X_curr * model -> n_iters x oneRound from the identity -> triangulate,
-    chained through device-side counts and the solver's device-side pose.  Map maintenance
-    (PointCloudVector::update) is host code in the C++ application and not part of this chain."""
+    chained through device-side counts and the solver's device-side pose.  keep_map: the loop body's map upkeep
+    (map.update(history * triangulated_pc), history = history * pose^-1: vo_complete.cpp:145-147,175-176) runs inside
+    the chain too, on the device (vo_map_*)."""
 
     def __init__(self, ctx: Context, seq: dict, n_iters: int = 100, kernel_threshold: float = 10000.0,
                  keep_appearance: bool = False, matches: list | None = None, overlap_match: bool = False, exact: bool = False,
-                 prematch: bool = False):
+                 prematch: bool = False, keep_map: bool = False, map_capacity: int | None = None):
         """prematch: the matcher depends on the appearances alone, so when the whole sequence is on hand -- as it
         is for vo_complete, which reads its measurement files from a directory -- all F-1 consecutive pairs are matched by ONE
         vo_match_appearances_batch_dev call at start() (frames of different sizes, per-frame tree choice as in the single
@@ -440,7 +441,11 @@ class SequencePipeline:
             self.pre_off = np.concatenate([[0], np.cumsum(self.pre_n)]).astype(np.int64)
             self.pre = up(np.concatenate(ms + [np.zeros((1, 2), np.int32)]))
         self.d_tri_xyz, self.d_tri_pairs = a(F * cap * 12), a(F * cap * 8)      # frame t's cloud at slice t
-        self.d_tri_app = a(F * cap * 40) if keep_appearance else 0
+        self.d_tri_app = a(F * cap * 40) if (keep_appearance or keep_map) else 0
+        self.map = None
+        if keep_map:
+            from .api import Map
+            self.map = Map(ctx, int(map_capacity if map_capacity is not None else min(int(self.off[-1]), 8 * cap)))
         self.d_counts = a(3 * F * 4)                                            # [t] = (n_match, n_join, n_tri)
         c0 = np.zeros((F, 3), np.int32)
         if self.pre is not None:
@@ -534,6 +539,10 @@ class SequencePipeline:
         self._release(1)
         self.ctx.h2d(self.d_traj, np.eye(4, dtype=np.float32))
         self.ctx.h2d(self.d_traj + 64, X)
+        if self.map is not None:                          # vo_complete.cpp:145-146
+            self.map.clear()
+            self._map_update(1, None)
+            self.map.history_reset_dev(self.d_traj + 64)
 
     def step(self, t):
         """frame t >= 2 (vo_complete.cpp:150-179); asynchronous"""
@@ -555,7 +564,13 @@ class SequencePipeline:
                                         C.c_int(0), C.c_int(self.n_iters)))
         _chk(self.lib.vo_picp_get_pose_dev(self.solver, C.c_void_p(self.d_traj + 64 * t)))
         self._triangulate(t, None)
+        if self.map is not None:                          # vo_complete.cpp:175-176
+            self._map_update(t, self.map.history_dev)
+            self.map.history_step_dev(self.d_pose)
         self._release(t)
+
+    def _map_update(self, t, d_T16):
+        self.map.update_dev(self._xyz(t).value, self._tapp(t).value, min(self.n[t - 1], self.n[t]), self._cnt(t, 2).value, d_T16)
 
     def start(self):
         """first pair (and, in overlap mode, the matchers of frames 1 and 2 on the second stream)"""
@@ -607,6 +622,9 @@ class SequencePipeline:
         return ci.value, co.value, ni.value
 
     def close(self):
+        if self.map is not None:
+            self.map.close()
+            self.map = None
         if self.solver:
             self.lib.vo_picp_destroy(self.solver)
             self.solver = None
