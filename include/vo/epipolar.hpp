@@ -32,6 +32,31 @@ inline Vector2fVector normalize(const Vector2fVector& p, Matrix3f& T) {
   return ret;
 }
 
+//! back half of estimate_fundamental (epipolar_utils.cpp:127-143) from the 81 entries of A^T A and the two conditioning
+//! matrices: null vector, rank-2 projection, un-normalisation
+inline Matrix3f fundamental_from_normal_matrix(const std::vector<double>& AtA, const Matrix3f& T1, const Matrix3f& T2) {
+  std::vector<double> ev, evec;
+  linalg::jacobi_eigen_sym(9, AtA, ev, evec);
+  linalg::Mat3d Fa;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fa.m[i][j] = evec[(size_t)(3 * i + j) * 9 + 0];   // :128-131
+  linalg::Mat3d U, V; double s[3];
+  linalg::svd3(Fa, U, s, V);
+  linalg::Mat3d D = linalg::Mat3d::zero();
+  D.m[0][0] = s[0]; D.m[1][1] = s[1];                        // rank 2, :135-139
+  const linalg::Mat3d F = U * D * V.transpose();
+  linalg::Mat3d t1, t2;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { t1.m[i][j] = T1(i, j); t2.m[i][j] = T2(i, j); }
+  const linalg::Mat3d Fd = t1.transpose() * F * t2;          // :142
+  Matrix3f out;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out(i, j) = (float)Fd.m[i][j];
+  return out;
+}
+
+//! the conditioning matrix normalize() builds from an image's per-axis maxima (epipolar_utils.cpp:61-63)
+inline Matrix3f conditioning_matrix(float max_x, float max_y) {
+  return Matrix3f::FromRows(1.f / (max_x / 2.f), 0.f, -1.f, 0.f, 1.f / (max_y / 2.f), -1.f, 0.f, 0.f, 1.f);
+}
+
 //! epipolar_utils.cpp:103-144
 inline Matrix3f estimate_fundamental(const IntPairVector& correspondences, const Vector2fVector& p1_img,
                                      const Vector2fVector& p2_img) {
@@ -49,21 +74,7 @@ inline Matrix3f estimate_fundamental(const IntPairVector& correspondences, const
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) row[3 * i + j] = d1[i] * d2[j];     // :124-125
     for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) AtA[(size_t)i * 9 + j] += row[i] * row[j];
   }
-  std::vector<double> ev, evec;
-  linalg::jacobi_eigen_sym(9, AtA, ev, evec);
-  linalg::Mat3d Fa;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fa.m[i][j] = evec[(size_t)(3 * i + j) * 9 + 0];   // :128-131
-  linalg::Mat3d U, V; double s[3];
-  linalg::svd3(Fa, U, s, V);
-  linalg::Mat3d D = linalg::Mat3d::zero();
-  D.m[0][0] = s[0]; D.m[1][1] = s[1];                        // rank 2, :135-139
-  const linalg::Mat3d F = U * D * V.transpose();
-  linalg::Mat3d t1, t2;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { t1.m[i][j] = T1(i, j); t2.m[i][j] = T2(i, j); }
-  const linalg::Mat3d Fd = t1.transpose() * F * t2;          // :142
-  Matrix3f out;
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out(i, j) = (float)Fd.m[i][j];
-  return out;
+  return fundamental_from_normal_matrix(AtA, T1, T2);
 }
 
 //! epipolar_utils.cpp:146-174
@@ -95,26 +106,38 @@ inline IsometryPair essential2transformPair(const Matrix3f& E) {
 //! epipolar_utils.cpp:176-213 with the cheirality count abstracted: count_in_front(X) returns the number of
 //! correspondences that triangulate successfully under the candidate X (the reference calls
 //! triangulate_points v1 and uses its return value, :196-209).  Strict '>' keeps the first best candidate.
-template <class CountInFront>
-inline Isometry3f estimate_transform_with(const Matrix3f k, const IntPairVector& correspondences,
-                                          const Vector2fVector& p1_img, const Vector2fVector& p2_img,
-                                          CountInFront&& count_in_front) {
-  const Matrix3f F = estimate_fundamental(correspondences, p1_img, p2_img);
+//! the four candidates of epipolar_utils.cpp:187-211 in the order the reference tries them: (R1, t), (R1, -t), (R2, t), (R2, -t)
+inline void transform_candidates(const Matrix3f& k, const Matrix3f& F, Isometry3f X[4]) {
   linalg::Mat3d kd, Fd;
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { kd.m[i][j] = k(i, j); Fd.m[i][j] = F(i, j); }
   const linalg::Mat3d Ed = kd.transpose() * Fd * kd;          // :180
   Matrix3f E;
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E(i, j) = (float)Ed.m[i][j];
   const IsometryPair X12 = essential2transformPair(E);
+  for (int cand = 0; cand < 4; ++cand) {
+    X[cand] = cand < 2 ? X12.first : X12.second;
+    if (cand & 1) { X[cand](0, 3) = -X[cand](0, 3); X[cand](1, 3) = -X[cand](1, 3); X[cand](2, 3) = -X[cand](2, 3); }
+  }
+}
+//! the vote: strict '>' keeps the first best candidate, no candidate in front of anything leaves the identity (:184-211)
+inline Isometry3f pick_candidate(const Isometry3f X[4], const int n_in_front_of[4]) {
   int n_in_front = 0;
   Isometry3f X_best = Isometry3f::Identity();
-  for (int cand = 0; cand < 4; ++cand) {                      // :187-211
-    Isometry3f X_test = cand < 2 ? X12.first : X12.second;
-    if (cand & 1) { X_test(0, 3) = -X_test(0, 3); X_test(1, 3) = -X_test(1, 3); X_test(2, 3) = -X_test(2, 3); }
-    const int n_test = count_in_front(X_test);
-    if (n_test > n_in_front) { n_in_front = n_test; X_best = X_test; }
-  }
+  for (int cand = 0; cand < 4; ++cand)
+    if (n_in_front_of[cand] > n_in_front) { n_in_front = n_in_front_of[cand]; X_best = X[cand]; }
   return X_best;
+}
+
+template <class CountInFront>
+inline Isometry3f estimate_transform_with(const Matrix3f k, const IntPairVector& correspondences,
+                                          const Vector2fVector& p1_img, const Vector2fVector& p2_img,
+                                          CountInFront&& count_in_front) {
+  const Matrix3f F = estimate_fundamental(correspondences, p1_img, p2_img);
+  Isometry3f X[4];
+  transform_candidates(k, F, X);
+  int n[4];
+  for (int cand = 0; cand < 4; ++cand) n[cand] = count_in_front(X[cand]);      // :187-211
+  return pick_candidate(X, n);
 }
 
 //! epipolar_utils.cpp:176-213 -- pose of the first camera in the frame of the second

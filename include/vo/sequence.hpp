@@ -45,7 +45,6 @@ class DeviceSequence {
         std::memcpy(&app[10 * cap_ * (size_t)t], f.appearances()[0].data(), sizeof(float) * 10 * f.size());
       }
     }
-    first_[0] = frames[0].points(); first_[1] = frames[1].points();
     d_pts_ = upload(pts); d_app_ = upload(app);
     d_m_ = alloc<int32_t>(2 * cap_); d_j_ = alloc<int32_t>(2 * cap_); d_model_t_ = alloc<float>(3 * cap_);
     d_xyz_ = alloc<float>(3 * cap_ * (size_t)F_); d_pairs_ = alloc<int32_t>(2 * cap_ * (size_t)F_);
@@ -120,13 +119,8 @@ class DeviceSequence {
     }
     // first pair: vo_complete.cpp:121-132
     match(1);
-    int c0 = 0;
-    check(vo_memcpy_d2h(ctx_, &c0, cnt(1, 0), sizeof(int)), "DeviceSequence::run");
-    std::vector<int32_t> pairs(2 * (size_t)std::max(c0, 1));
-    if (c0) check(vo_memcpy_d2h(ctx_, pairs.data(), m_of(1), sizeof(int32_t) * 2 * (size_t)c0), "DeviceSequence::run");
-    check(vo_estimate_transform(ctx_, cam_.cameraMatrix().data(), pairs.data(), c0, first_[0].empty() ? nullptr : first_[0][0].data(),
-                                (int)first_[0].size(), first_[1].empty() ? nullptr : first_[1][0].data(), (int)first_[1].size(),
-                                X0_.data()), "vo_estimate_transform");
+    check(vo_estimate_transform_dev(ctx_, cam_.cameraMatrix().data(), m_of(1), (int)std::min(n(0), n(1)), cnt(1, 0), pts_of(0), (int)n(0),
+                                    pts_of(1), (int)n(1), X0_.data()), "vo_estimate_transform_dev");
     triangulate(1, X0_.data());
     const Isometry3f I = Isometry3f::Identity();
     check(vo_memcpy_h2d(ctx_, d_traj_, I.data(), 64), "DeviceSequence::run");
@@ -247,7 +241,6 @@ class DeviceSequence {
   int F_, rounds_;
   size_t cap_ = 1;
   std::vector<size_t> off_;
-  Vector2fVector first_[2];
   Isometry3f X0_ = Isometry3f::Identity();
   vo_picp* solver_ = nullptr;
   vo_map* map_ = nullptr;

@@ -330,13 +330,20 @@ int vo_triangulate_dev(vo_ctx *ctx, const float K[9], const float X[16], const f
 /* Relative pose of the first camera in the frame of the second from >= 8 image correspondences
  * pairs = (index in p1, index in p2): normalised 8-point fundamental (:103-144, normalisation over
  * ALL n1 / n2 points, :48-65), E = K^T F K, the four (R, +-t) candidates (:146-174) and the
- * cheirality vote, which runs the triangulation kernel once per candidate and keeps the first
- * candidate with the most survivors.  Host linear algebra in double (once per sequence).
+ * cheirality vote -- how many correspondences triangulate under each candidate (the triangulation kernel's per-pair
+ * arithmetic, counted) -- which keeps the first candidate with the most survivors.  Host linear algebra in double.
  * As in the reference t is read off R*E un-normalised (:163-164): |t| is the singular value
  * of E, which is what fixes the scale of a monocular sequence.  Fewer than 8 pairs:
  * VO_ERR_INVALID_ARG (the reference prints and exits, :105-108). */
 int vo_estimate_transform(vo_ctx *ctx, const float K[9], const int32_t *pairs, int n,
                           const float *p1_uv, int n1, const float *p2_uv, int n2, float X_out[16]);
+/* The same from arrays in device memory -- the matcher's pairs and the two images as they lie in HBM; *d_n_pairs (or
+ * NULL) <= n_max pairs are live.  The sums over the correspondences run on the GPU (epi.hip): per-axis maxima of both
+ * images (:50-56), the 45 distinct entries of A^T A in double (:114-126), and the cheirality vote of all four candidates in
+ * one launch; the 9 x 9 eigen-solve and the decomposition of E stay on the host in double.  Two small read-backs;
+ * X_out on the host.  (vo_estimate_transform is this after three uploads.) */
+int vo_estimate_transform_dev(vo_ctx *ctx, const float K[9], const int32_t *d_pairs, int n_max, const int *d_n_pairs,
+                              const float *d_p1_uv, int n1, const float *d_p2_uv, int n2, float X_out[16]);
 
 /* ---- many independent frame pairs at once (throughput form of vo_complete.cpp:156-173) ---- */
 /* For each of n_frames independent frame pairs: match -> join -> X_prev * model -> n_iters rounds

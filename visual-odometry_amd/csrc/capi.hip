@@ -107,6 +107,7 @@ struct vo_ctx {
   PicpParams batch_params_host{};        //   its parameter block as last uploaded, and where
   const PicpParams* batch_params_dev = nullptr;
   DevBuf prune_ws;    // sorted copies / tables of the matcher's sorted variants
+  DevBuf epi_ws;      // maxima, A^T A and vote counts of vo_estimate_transform
   int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan, 3 cell-hash search, 4 / 5 exact-duplicate pass first, then 2 / 3
   int batch_form = 0; // batched solver: 0 auto, 1 one launch per round, 2 one workgroup per problem
   bool capturing = false;
@@ -234,7 +235,7 @@ int vo_ctx_destroy(vo_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   c->scratch.release(); c->best.release(); c->table.release(); c->counts.release();
-  c->batch_pack.release(); c->batch_bad.release(); c->prune_ws.release(); c->batch_states.release(); c->batch_partials.release();
+  c->batch_pack.release(); c->batch_bad.release(); c->prune_ws.release(); c->epi_ws.release(); c->batch_states.release(); c->batch_partials.release();
   for (auto& b : c->in) b.release();
   for (auto& b : c->out) b.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1415,6 +1416,47 @@ int vo_triangulate(vo_ctx* c, const float K[9], const float X[16], const int32_t
 }
 
 // ---- epipolar initialisation (epipolar_utils.cpp:176-213) --------------------------------------
+// Device half first (epi.hip): maxima of both images, the 45 sums of A^T A, one small read-back; then the host's 9 x 9
+// eigen-solve, rank-2 projection and decomposition of E in double (include/vo/epipolar.hpp); then ONE launch that counts,
+// for all four candidates at once, the correspondences that triangulate in front of both cameras; a second read-back.
+int vo_estimate_transform_dev(vo_ctx* c, const float K[9], const int32_t* d_pairs, int n_max, const int* d_n, const float* d_p1,
+                              int n1, const float* d_p2, int n2, float X_out[16]) {
+  VO_REQUIRE(c && K && d_pairs && d_p1 && d_p2 && X_out, "null argument");
+  VO_NOT_CAPTURING(c);
+  VO_REQUIRE(n_max >= 8, "fewer than 8 correspondences");
+  VO_REQUIRE(n1 > 0 && n2 > 0, "empty point set");
+  VO_REQUIRE(aligned8(d_pairs, d_p1, d_p2), "device arrays must be 8-byte aligned");
+  if (int r = set_device(c)) return r;
+  VO_HIP_CHECK(c->epi_ws.ensure(epi_workspace_bytes(), c->stream));
+  VO_HIP_CHECK(launch_epi_front(c->stream, d_pairs, n_max, d_n, d_p1, n1, d_p2, n2, c->epi_ws.p));
+  struct { unsigned maxima[4]; int info[4]; int votes[8]; double ata[45]; } h;
+  static_assert(sizeof(h) == 64 + 45 * sizeof(double), "layout of the epipolar workspace");
+  VO_HIP_CHECK(hipMemcpyAsync(&h, c->epi_ws.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (h.info[1] > 0)
+    return fail(VO_ERR_BAD_INDEX, "vo_estimate_transform: %d pair(s) index outside the point arrays", h.info[1]);
+  if (h.info[0] < 8) return fail(VO_ERR_INVALID_ARG, "vo_estimate_transform: fewer than 8 correspondences (%d)", h.info[0]);
+  std::vector<double> AtA(81, 0.0);
+  for (int i = 0, k = 0; i < 9; ++i)
+    for (int j = i; j < 9; ++j, ++k) AtA[(size_t)i * 9 + j] = AtA[(size_t)j * 9 + i] = h.ata[k];
+  float mx[4];
+  memcpy(mx, h.maxima, sizeof(mx));
+  vo::Matrix3f k;
+  for (int j = 0; j < 9; ++j) k.m[j] = K[j];
+  const vo::Matrix3f F = vo::fundamental_from_normal_matrix(AtA, vo::conditioning_matrix(mx[0], mx[1]), vo::conditioning_matrix(mx[2], mx[3]));
+  vo::Isometry3f X[4];
+  vo::transform_candidates(k, F, X);
+  Pose P[4];
+  for (int q = 0; q < 4; ++q) P[q] = pose_from_T16(X[q].data());
+  VO_HIP_CHECK(launch_epi_vote(c->stream, K, P, d_pairs, n_max, d_n, d_p1, n1, d_p2, n2, c->epi_ws.p));
+  int votes[4] = {0, 0, 0, 0};
+  VO_HIP_CHECK(hipMemcpyAsync(votes, static_cast<char*>(c->epi_ws.p) + 32, sizeof(votes), hipMemcpyDeviceToHost, c->stream));
+  VO_HIP_CHECK(hipStreamSynchronize(c->stream));
+  const vo::Isometry3f best = vo::pick_candidate(X, votes);
+  memcpy(X_out, best.data(), sizeof(float) * 16);
+  return VO_OK;
+}
+
 int vo_estimate_transform(vo_ctx* c, const float K[9], const int32_t* pairs, int n, const float* p1, int n1,
                           const float* p2, int n2, float X_out[16]) {
   VO_REQUIRE(c && K && pairs && p1 && p2 && X_out, "null argument");
@@ -1426,35 +1468,10 @@ int vo_estimate_transform(vo_ctx* c, const float K[9], const int32_t* pairs, int
       return fail(VO_ERR_BAD_INDEX, "vo_estimate_transform: pair %d = (%d,%d) outside the point arrays", i,
                   pairs[2 * i], pairs[2 * i + 1]);
   if (int r = set_device(c)) return r;
-  // device copies once; the four candidates are scored by the triangulation kernel in count-only use
   if (int r = upload(c, c->in[0], pairs, sizeof(int32_t) * 2 * (size_t)n)) return r;
   if (int r = upload(c, c->in[1], p1, sizeof(float) * 2 * (size_t)n1)) return r;
   if (int r = upload(c, c->in[2], p2, sizeof(float) * 2 * (size_t)n2)) return r;
-  VO_HIP_CHECK(c->out[0].ensure(sizeof(float) * 3 * (size_t)n, c->stream));
-  if (int r = ensure_counts(c)) return r;
-  vo::Matrix3f k;
-  for (int j = 0; j < 9; ++j) k.m[j] = K[j];
-  vo::IntPairVector corr((size_t)n);
-  for (int i = 0; i < n; ++i) corr[(size_t)i] = vo::IntPair(pairs[2 * i], pairs[2 * i + 1]);
-  vo::Vector2fVector a((size_t)n1), b((size_t)n2);
-  memcpy((void*)a.data(), p1, sizeof(float) * 2 * (size_t)n1);
-  memcpy((void*)b.data(), p2, sizeof(float) * 2 * (size_t)n2);
-  int rc = VO_OK;
-  const vo::Isometry3f X = vo::estimate_transform_with(k, corr, a, b, [&](const vo::Isometry3f& X_test) {
-    if (rc != VO_OK) return 0;
-    rc = vo_triangulate_dev(c, K, X_test.data(), nullptr, c->in[0].as<int32_t>(), n, nullptr, c->in[1].as<float>(), n1,
-                            c->in[2].as<float>(), n2, nullptr, c->out[0].as<float>(), nullptr, nullptr,
-                            c->counts.as<int>());
-    int h = 0;
-    if (rc == VO_OK && hipMemcpyAsync(&h, c->counts.p, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
-      rc = fail(VO_ERR_HIP, "vo_estimate_transform: count readback failed");
-    if (rc == VO_OK && hipStreamSynchronize(c->stream) != hipSuccess)
-      rc = fail(VO_ERR_HIP, "vo_estimate_transform: stream synchronisation failed");
-    return rc == VO_OK ? h : 0;
-  });
-  if (rc != VO_OK) return rc;
-  memcpy(X_out, X.data(), sizeof(float) * 16);
-  return VO_OK;
+  return vo_estimate_transform_dev(c, K, c->in[0].as<int32_t>(), n, nullptr, c->in[1].as<float>(), n1, c->in[2].as<float>(), n2, X_out);
 }
 
 // ---- the map (PointCloudVector<3>::update + the history chain of vo_complete.cpp:145-147,175-176,183) ---------------------------

@@ -284,4 +284,13 @@ hipError_t launch_map_rehash(hipStream_t st, const MapDev& m, int size_bound);  
 hipError_t launch_map_history(hipStream_t st, float* d_hist16, const float* d_X16, int reset);
 hipError_t launch_map_transform(hipStream_t st, const MapDev& m, const Pose& T, int size_bound);
 
+// ---- epipolar initialisation, device half (epi.hip) ------------------------------------------------------
+size_t epi_workspace_bytes();
+// maxima of both point sets + the 45 sums of A^T A + the number of rows / of pairs with a bad index, into ws:
+// [0,16) four float maxima  [16,32) int info[0] = rows used, info[1] = bad pairs  [32,48) vote counts  [64,424) 45 doubles
+hipError_t launch_epi_front(hipStream_t st, const int32_t* d_pairs, int n_max, const int* d_n, const float* d_p1, int n1,
+                            const float* d_p2, int n2, void* ws);
+hipError_t launch_epi_vote(hipStream_t st, const float K[9], const Pose X[4], const int32_t* d_pairs, int n_max, const int* d_n,
+                           const float* d_p1, int n1, const float* d_p2, int n2, void* ws);
+
 }  // namespace vo

@@ -410,7 +410,6 @@ class SequencePipeline:
         self.off = np.concatenate([[0], np.cumsum(self.n)]).astype(np.int64)
         self.K = _colmajor(seq["K"], 3)
         self.cam = (int(seq["rows"]), int(seq["cols"]), int(seq["z_near"]), int(seq["z_far"]))
-        self._host_pts = [np.ascontiguousarray(f["pts"], np.float32) for f in fr[:2]]
         up, a = ctx.to_device, ctx.alloc
         self.d_pts = up(np.ascontiguousarray(np.concatenate([f["pts"] for f in fr]), np.float32))
         self.d_app = up(np.ascontiguousarray(np.concatenate([f["app"] for f in fr]), np.float32))
@@ -525,15 +524,11 @@ class SequencePipeline:
     def initialise(self):
         """first pair: match, epipolar initialisation (host, once per sequence), triangulate (vo_complete.cpp:121-132)"""
         self._match(1)
-        c = np.zeros(1, np.int32)
-        self.ctx.d2h(c, self._cnt(1, 0).value)
-        pairs = np.zeros((max(int(c[0]), 1), 2), np.int32)
-        if c[0]:
-            self.ctx.d2h(pairs[: c[0]], self._m(1).value)
         X = np.zeros(16, np.float32)
-        _chk(self.lib.vo_estimate_transform(self.ctx.h, _ptr(self.K), _ptr(pairs), C.c_int(int(c[0])),
-                                            _ptr(self._host_pts[0]), C.c_int(self.n[0]), _ptr(self._host_pts[1]),
-                                            C.c_int(self.n[1]), _ptr(X)))
+        # pairs, count and both images as they lie in device memory: no copy of the pairs to the host (vo_estimate_transform_dev)
+        _chk(self.lib.vo_estimate_transform_dev(self.ctx.h, _ptr(self.K), self._m(1), C.c_int(min(self.n[0], self.n[1])),
+                                                self._cnt(1, 0), self._pts(0), C.c_int(self.n[0]), self._pts(1),
+                                                C.c_int(self.n[1]), _ptr(X)))
         self.X0 = X
         self._triangulate(1, X)
         self._release(1)
