@@ -12,6 +12,7 @@
 // Plain C++ over include/vo/*.hpp + vo_hip.h + rccl.h + the HIP runtime API (device count, nothing else).
 #include <cstdio>
 #include <iostream>
+#include <algorithm>
 #include <numeric>
 #include <thread>
 
@@ -92,8 +93,12 @@ void rank_main(int rank, Shared& S) {
       RANK_CHECK(vo_memcpy_h2d(ctx, d_cnt, zeros.data(), zeros.size() * sizeof(int)));
       RANK_CHECK(vo_memcpy_h2d(ctx, d_app, app.data(), app.size() * sizeof(float)));
       RANK_CHECK(vo_memcpy_h2d(ctx, d_n, sizes.data(), sizes.size() * sizeof(int)));
-      if (np > 0)
-        RANK_CHECK(vo_match_appearances_batch_dev(ctx, np, d_app, (int)cap, d_n, d_app + 10 * cap, (int)cap, d_n + 1, 0.1f, d_pairs, d_cnt));
+      // the frame is a grid dimension of the batched matcher: at most 65535 pairs per call (as DeviceSequence::run does)
+      for (int p0 = 0; p0 < np && S.agree->ok(rank); p0 += 65535) {
+        const int k = std::min(65535, np - p0);
+        RANK_CHECK(vo_match_appearances_batch_dev(ctx, k, d_app + 10 * cap * (size_t)p0, (int)cap, d_n + p0, d_app + 10 * cap * (size_t)(p0 + 1), (int)cap,
+                                                  d_n + p0 + 1, 0.1f, d_pairs + 2 * cap * (size_t)p0, d_cnt + p0));
+      }
     }
   }
   if (S.agree->all_ok()) {                                   // nobody enters the collectives unless everybody does
@@ -110,6 +115,9 @@ void rank_main(int rank, Shared& S) {
       NCCL_CHECK(ncclAllGather(d_cnt, g_counts, (size_t)S.blk, ncclInt32, S.comms[(size_t)rank], st));
       NCCL_CHECK(ncclAllGather(d_pairs, g_pairs, 2 * cap * (size_t)S.blk, ncclInt32, S.comms[(size_t)rank], st));
       NCCL_CHECK(ncclGroupEnd());
+      // a rank whose part of the collective failed takes its communicator down, so that the others -- who may already sit
+      // inside the all-gather -- come back with an error instead of waiting for it forever
+      if (!S.agree->ok(rank)) { (void)ncclCommAbort(S.comms[(size_t)rank]); S.comms[(size_t)rank] = nullptr; }   // (abort frees it)
     }
     RANK_CHECK(vo_ctx_synchronize(ctx));
     std::vector<int> cnt((size_t)S.blk, 0);
@@ -202,7 +210,7 @@ int main(int argc, char* argv[]) {
     std::vector<std::thread> th;
     for (int r = 0; r < S.world; ++r) th.emplace_back(rank_main, r, std::ref(S));
     for (auto& t : th) t.join();
-    for (ncclComm_t c : S.comms) ncclCommDestroy(c);
+    for (ncclComm_t c : S.comms) if (c) ncclCommDestroy(c);
     int fail = 0;
     for (int r = 0; r < S.world; ++r)
       if (!agree.errors()[(size_t)r].empty()) { std::fprintf(stderr, "rank %d: %s\n", r, agree.errors()[(size_t)r].c_str()); fail = 2; }

@@ -1057,6 +1057,7 @@ static int with_hash(int v, int nt, int n_frames) {
   const bool on = env < 0 ? n_frames >= 8 : env == 1;
   return (on && (v == 2 || v == 3) && match_hash_supported(nt, n_frames)) ? v + 2 : v;
 }
+static int match_auto_flag(const vo_ctx* c) { return c->match_mode == 0 ? MATCH_VARIANT_AUTO : 0; }
 static int match_variant(const vo_ctx* c, int nt, int nq, int n_frames) {
   const bool cells_ok = match_cells_supported(nt, nq);      // the cell-hash search serves sets of up to 1.8 M points
   if (c->match_mode != 0) {
@@ -1072,7 +1073,8 @@ static int match_variant(const vo_ctx* c, int nt, int nq, int n_frames) {
   // 12 000: 60 / 49; tools/match_sizes.py)
   {
     const double pairs = (double)nt * (double)nq;
-    if (pairs < 4.0e6 || pairs * (double)(n_frames > 0 ? n_frames : 1) < 1.0e8) return 1;
+    // (the 1e8 rule is measured for ONE frame only; calls of 2..7 frames keep the 4 M-pairs-per-frame crossover)
+    if (pairs < 4.0e6 || (n_frames <= 1 && pairs < 1.0e8)) return 1;
   }
   static const int forced = [] { const char* e = getenv("VO_MATCH_AUTO"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 3) ? v : 0; }();
   if (forced) return with_hash((forced == 3 && !cells_ok) ? 2 : forced, nt, n_frames);
@@ -1113,7 +1115,7 @@ int vo_match_appearances_dev(vo_ctx* c, const float* d_a1, int n1, const float* 
   void* ws = nullptr;
   if (nq > 0) if (int r = match_workspace(c, variant, nt, nq, 1, &ws)) return r;
   VO_HIP_CHECK(launch_match(c->stream, d_a1, n1, d_a2, n2, radius, d_out_pairs, d_n_out,
-                            c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, variant));
+                            c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, variant | match_auto_flag(c)));
   return VO_OK;
 }
 
@@ -1162,7 +1164,7 @@ int vo_match_appearances_batch_dev(vo_ctx* c, int n_frames, const float* d_a1, i
   if (q > 0) if (int r = match_workspace(c, variant, nt, d_n1 ? nt : q, n_frames, &ws)) return r;
   VO_HIP_CHECK(launch_match_batch(c->stream, d_a1, cap1, 10 * (size_t)cap1, d_a2, cap2, 10 * (size_t)cap2, radius, d_out_pairs,
                                   (size_t)q, d_n_out, c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, n_frames,
-                                  variant, d_n1, d_n2));
+                                  variant | match_auto_flag(c), d_n1, d_n2));
   return VO_OK;
 }
 
@@ -1208,7 +1210,7 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
   // compute_correspondences_images, all frames                                  vo_complete.cpp:156
   VO_HIP_CHECK(launch_match_batch(c->stream, b->ref_app, b->n_ref, 10 * (size_t)b->n_ref, b->cur_app, b->n_cur,
                                   10 * (size_t)b->n_cur, b->radius, b->matches, (size_t)q, n_match,
-                                  c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, F, variant,
+                                  c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, F, variant | match_auto_flag(c),
                                   sz ? sz->n_ref : nullptr, sz ? sz->n_cur : nullptr));
   // X_curr * triangulated_pc                                                    vo_complete.cpp:159
   // The moved cloud as an output is optional: without it the solver's gather applies X_prev to the points it fetches (the

@@ -1564,7 +1564,9 @@ struct HashArgs {
   int qcap;                   // records a part's queue holds
   int* unres;                 // [n_frames] queries left open (zeroed per call)
   unsigned* sample_mask;      // [n_frames] (zeroed per call) bit k: sample query k of the frame has a bitwise copy in the tree -- a frame
-                              //   with none of its eight samples found skips the tables and the lookup: its queries all go to the search
+                              //   with fewer than sample_min of its HJ_SAMPLES samples found skips the tables and the lookup: its queries all go to the search
+  int sample_min;             // automatic mode: HJ_SAMPLE_MIN (the pass pays while fewer than ~10 % of a frame's queries lack a copy);
+                              //   forced modes 4 / 5: 1 (any copy at all)
   int* open_list;             // [n_frames][OPEN_MAX] their indices when there are at most OPEN_MAX, in no particular order (hash_open_kernel)
   size_t queue_stride;        // uint2 per frame of `queues`; the lookup reuses a frame's queues for its workgroups' open queries:
   int seg_counts;             //   ints [0, seg_counts) the segments (256 HJ_Q per workgroup), behind them one count per workgroup
@@ -1576,6 +1578,13 @@ struct HashArgs {
   int n_frames, log2p, ib, qblocks, hblocks;   // parts = 1 << log2p; ib: index bits of a word (the tag takes the other 31 - ib)
 };
 
+// Sample queries per frame and how many of them must have a bitwise copy in the tree for the frame to take the pass in the
+// automatic mode.  Matcher stage per 200 x 50k frames by share of queries WITHOUT a copy: 0 %: 0.52 ms, 1 %:
+// 0.71, 5 %: 0.77, 10 %: 1.15, 50 %: 1.28, 90 %: 1.44 -- the search alone: 1.10 at every share.  So the pass should run below
+// ~10 % and not above; "any of 8 samples" (round 4) ran it up to 100 %.  15 of 16: taken with probability 0.99 / 0.81 / 0.51 /
+// 0.06 / 0.0003 at 1 / 5 / 10 / 25 / 50 % -- a wrong guess costs time only, whatever the pass leaves open the search finds.
+constexpr int HJ_SAMPLES = 16, HJ_SAMPLE_MIN = 15;
+__device__ __forceinline__ bool hash_frame_takes_pass(const HashArgs& a, int f) { return __popc(a.sample_mask[f]) >= a.sample_min; }
 __device__ __forceinline__ bool row_safe(const Row10& r) {       // every |x| in [2^-40, inf): an unsigned range test on the bits
   unsigned worst = 0;
 #pragma unroll
@@ -1690,12 +1699,12 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(HashArgs a) {
   // hash_probe_kernel) -- 1.41 -> 1.2 ms for the matcher stage of 200 x 50k such frames, 1.10 without the pass.  A wrong guess
   // costs time only: whatever the pass leaves open, the search finds.
   if (nq > 0) {
-    const int step = nq >> 3;
+    const int step = nq / HJ_SAMPLES;
     unsigned hit = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) hit |= (__float_as_uint(qry[10 * (size_t)(k * step)]) == __float_as_uint(r.v[0]) ? 1u : 0u) << k;
+    for (int k = 0; k < HJ_SAMPLES; ++k) hit |= (__float_as_uint(qry[10 * (size_t)(k * step)]) == __float_as_uint(r.v[0]) ? 1u : 0u) << k;
     if (i < nt && hit) {
-      for (int k = 0; k < 8; ++k)
+      for (int k = 0; k < HJ_SAMPLES; ++k)
         if ((hit >> k) & 1u) {
           const Row10 sq = load_row_now(qry + 10 * (size_t)(k * step));
           if (rows_equal(sq, r)) atomicOr(&a.sample_mask[f], 1u << k);
@@ -1729,7 +1738,7 @@ __global__ __launch_bounds__(HJ_THREADS) void hash_table_kernel(HashArgs a) {
   constexpr unsigned S = 1u << LOG2S;
   int f, part;
   if (!xcd_frame_block(1 << a.log2p, a.n_frames, f, part)) return;
-  if (a.sample_mask[f] == 0) return;                       // no copies in this frame's data (hash_rows_kernel): no table, no lookup
+  if (!hash_frame_takes_pass(a, f)) return;                // too few copies in this frame's data (hash_rows_kernel): no table, no lookup
   const float* tree; const float* qry; int nt, nq;
   cell_sets(a, f, tree, qry, nt, nq);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1798,7 +1807,7 @@ __global__ __launch_bounds__(256) void hash_probe_kernel(HashArgs a) {
   const float* tree; const float* qry; int nt, nq;
   cell_sets(a, f, tree, qry, nt, nq);
   if (blk * (256 * HJ_Q) >= nq) return;                   // (uniform)
-  if (a.sample_mask[f] == 0) {                            // (uniform) a frame without copies: every query stays open
+  if (!hash_frame_takes_pass(a, f)) {                     // (uniform) a frame without (enough) copies: every query stays open
     unsigned long long* best = a.best + f * a.best_stride;
     int* seg = reinterpret_cast<int*>(a.queues + f * a.queue_stride);
     const int base = blk * (256 * HJ_Q), live = nq - base < 256 * HJ_Q ? nq - base : 256 * HJ_Q;
@@ -2249,7 +2258,7 @@ size_t match_hash_workspace_bytes(int nt, int n_frames) { return hash_ws_bytes(n
 static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, const float* qry, int nq, float r2,
                                     unsigned long long* d_best, void* ws, int n_frames, size_t tree_stride, size_t qry_stride,
                                     size_t best_stride, const int* d_n1, const int* d_n2, int** d_unres_out, int32_t* d_out_pairs,
-                                    size_t out_stride, int tree_is_1) {
+                                    size_t out_stride, int tree_is_1, bool automatic) {
   HashPlan p;
   const int nt_plan = d_n1 ? (nt > nq ? nt : nq) : nt;
   if (!hash_plan(nt_plan, p)) return hipErrorInvalidValue;
@@ -2265,6 +2274,7 @@ static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, c
   a.tables_stride = hash_table_bytes(p) / sizeof(unsigned);
   a.queues = reinterpret_cast<uint2*>(a.tables + a.tables_stride * (size_t)n_frames);
   a.qcap = p.qcap;
+  a.sample_min = automatic ? HJ_SAMPLE_MIN : 1;
   a.hblocks = (nt_plan + 255) / 256;
   hipError_t e0 = hipMemsetAsync(ws, 0, sizeof(int) * (size_t)n_frames * (3 + HJ_MAXP), st);
   if (e0 != hipSuccess) return e0;
@@ -2275,7 +2285,7 @@ static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, c
   a.qblocks = (q_cap + 256 * HJ_Q - 1) / (256 * HJ_Q);
   a.queue_stride = (size_t)p.qcap << p.log2p;
   a.seg_counts = a.qblocks * 256 * HJ_Q;                  // (4 (seg_counts + qblocks) <= 8 queue_stride: a queue holds 1.5 x the tree)
-  if (4 * ((size_t)a.seg_counts + (size_t)a.qblocks) > 8 * a.queue_stride) return hipErrorInvalidValue;
+  if (4 * ((size_t)a.seg_counts + (size_t)a.qblocks) > 8 * a.queue_stride) { *d_unres_out = nullptr; return hipErrorNotSupported; }   // (unreachable while nq <= nt; the caller then runs the plain search)
   const dim3 gb(xcd_grid(1 << p.log2p, n_frames)), gp(xcd_grid(a.qblocks, n_frames)), tb(HJ_THREADS);
   hipLaunchKernelGGL(hash_rows_kernel, dim3(xcd_grid(a.hblocks, n_frames)), dim3(256), 0, st, a);
   switch (p.log2s) {
@@ -2293,6 +2303,9 @@ static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, c
   return hipGetLastError();
 }
 
+// compute units of the device the running call targets (launch_match_batch sets it from its n_cu argument; the radius search,
+// which has none, keeps the last value or MI355X's 256)
+static thread_local int t_n_cu = 256;
 static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tree, int nt, const float* qry, int nq,
                                     float radius, float r2, unsigned long long* d_best, void* ws, int n_frames,
                                     size_t tree_stride, size_t qry_stride, size_t best_stride, const int* d_n1 = nullptr,
@@ -2316,7 +2329,7 @@ static hipError_t launch_cells_sort(hipStream_t st, CellArgs& a, const float* tr
     const int big = d_n1 ? (nt > nq ? nt : nq) : nt;
     // ~4 workgroups per CU over the call, so that the staging round trip at a workgroup's start is a small part of it
     const int runs = (big + 63) / 64;
-    int tblocks = (4 * 256 + n_frames - 1) / n_frames;
+    int tblocks = (4 * t_n_cu + n_frames - 1) / n_frames;
     const int tb_max = (runs + OPEN_SCAN_WAVES - 1) / OPEN_SCAN_WAVES;
     tblocks = tblocks > tb_max ? tb_max : tblocks;
     const int runs_per_wave = (runs + tblocks * OPEN_SCAN_WAVES - 1) / (tblocks * OPEN_SCAN_WAVES);
@@ -2366,6 +2379,9 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
                               int variant_in, const int* d_n1, const int* d_n2) {
   // variants 4 / 5: the exact-duplicate pass first, then variant 2 / 3 for the queries it left open (its workspace comes
   // first in d_prune_ws)
+  if (n_cu > 0) t_n_cu = n_cu;
+  const bool automatic = (variant_in & MATCH_VARIANT_AUTO) != 0;       // picked by the automatic rule, not forced (vo_match_set_mode)
+  variant_in &= ~MATCH_VARIANT_AUTO;
   const bool hash_first = variant_in >= 4 && d_prune_ws != nullptr;
   const int variant = variant_in >= 4 ? variant_in - 2 : variant_in;
   int* d_unres = nullptr;
@@ -2378,8 +2394,9 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
       void* ws = d_prune_ws;
       if (hash_first) {
         hipError_t eh = launch_hash_first(st, d_a1, n1, d_a2, n2, r2, d_best, d_prune_ws, n_frames, a1_stride, a2_stride, (size_t)q,
-                                          d_n1, d_n2, &d_unres, q > SMALL_COMPACT ? d_out_pairs : nullptr, out_stride, 1);
-        if (eh != hipSuccess) return eh;
+                                          d_n1, d_n2, &d_unres, q > SMALL_COMPACT ? d_out_pairs : nullptr, out_stride, 1, automatic);
+        if (eh == hipErrorNotSupported) d_unres = nullptr;        // sizes the pass does not take: the plain search answers every query
+        else if (eh != hipSuccess) return eh;
         ws = static_cast<char*>(d_prune_ws) + hash_ws_bytes(n1 > n2 ? n1 : n2, n_frames);
       }
       // the cell-hash search with per-frame sizes and roles (workspace laid out for max(n1, n2) in both roles)
@@ -2416,8 +2433,9 @@ hipError_t launch_match_batch(hipStream_t st, const float* d_a1, int n1, size_t 
   if (hash_first && nq > 0 && nt > 0 && (variant == 2 || variant == 3)) {
     hipError_t eh = launch_hash_first(st, tree, nt, qry, nq, r2, d_best, d_prune_ws, n_frames, n_frames > 1 ? ts : 0,
                                       n_frames > 1 ? qs : 0, best_stride, nullptr, nullptr, &d_unres,
-                                      nq > SMALL_COMPACT ? d_out_pairs : nullptr, n_frames > 1 ? out_stride : 0, tree_is_1);
-    if (eh != hipSuccess) return eh;
+                                      nq > SMALL_COMPACT ? d_out_pairs : nullptr, n_frames > 1 ? out_stride : 0, tree_is_1, automatic);
+    if (eh == hipErrorNotSupported) d_unres = nullptr;            // sizes the pass does not take: the plain search answers every query
+    else if (eh != hipSuccess) return eh;
     ws = static_cast<char*>(d_prune_ws) + hash_ws_bytes(nt, n_frames);
   }
   if (nq > 0 && nt > 0 && d_prune_ws && variant == 3) {

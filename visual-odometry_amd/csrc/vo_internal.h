@@ -219,6 +219,8 @@ hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const in
 // matcher variants: 1 = full scan (no workspace), 2 = bucket-pruned scan, 3 = cell-hash search, 4 / 5 = the
 // exact-duplicate pass first ("hash-first", match.hip), then variant 2 / 3 for the queries it left open; the
 // workspace of variant v holds match_workspace_bytes(v, nt, nq, n_frames) bytes
+constexpr int MATCH_VARIANT_AUTO = 0x100;     // or-ed into a variant that the automatic rule picked (launch_match[_batch]): the
+                                              //   exact-duplicate pass then asks for most of a frame's sample queries to have a copy
 size_t match_pruned_workspace_bytes(int nt, int nq, int n_frames);
 size_t match_cells_workspace_bytes(int nt, int nq, int n_frames);
 size_t match_hash_workspace_bytes(int nt, int n_frames);
