@@ -867,7 +867,7 @@ def batched_leg(torch, vo, ctx, stream, args):
     out = _batched_run(torch, vo, ctx, stream, args, args.batch_pairs)
     if args.batch_pairs == 200:
         out["chip_full"] = []
-        for P in (256, 512, 2048):
+        for P in (256, 512, 4096):
             r = _batched_run(torch, vo, ctx, stream, args, P)
             ws = r["working_set_MB"] * 1e6
             tb = r["frac_traffic"] * HBM_PEAK_GBS / 1e3
@@ -877,16 +877,20 @@ def batched_leg(torch, vo, ctx, stream, args):
                                      "traffic_TBs": tb, "frac_traffic_of_sustained_6.3TBs": tb * 1e3 / HBM_SUSTAINED_GBS,
                                      "working_set_MB": r["working_set_MB"],
                                      "working_set_fits_infinity_cache": r["working_set_fits_infinity_cache"],
+                                     "infinity_cache_share_upper_bound": min(1.0, 256 * 2 ** 20 / ws),
+                                     "traffic_TBs_from_hbm_lower_bound": tb * (1.0 - min(1.0, 256 * 2 ** 20 / ws)),
                                      "served_by": ("Infinity Cache" if ws < 256 * 2 ** 20 else
                                                    "Infinity-Cache-assisted (working set < 8 x the 256 MiB cache)" if ws < 8 * 256 * 2 ** 20
                                                    else "HBM")})
         past = [c for c in out["chip_full"] if c["served_by"] == "HBM"]
         if past:      # the one point to read as an HBM fraction: 2 GiB of packed correspondences swept 50 times, 8 x the Infinity Cache
-            out["hbm_point"] = dict(past[-1], note="working set 8 x the 256 MiB Infinity Cache, swept in order once per round: the cache "
-                                                    "cannot hold a line until its next use, so frac_traffic (bytes that leave the LDS, over "
-                                                    "time) is HBM traffic -- quoted against the 8.0 TB/s specification (frac_traffic) and "
-                                                    "against the 6.3 TB/s the guide measures as sustained (frac_traffic_of_sustained_6.3TBs). "
-                                                    "The 256- and 512-problem points are Infinity-Cache-assisted and are not HBM figures.")
+            out["hbm_point"] = dict(past[-1], note="working set 16 x the 256 MiB Infinity Cache, swept in order once per round: whatever the "
+                                                    "cache's replacement policy, at most cache / working set = 6 % of the bytes can come from it "
+                                                    "(infinity_cache_share_upper_bound), so at least traffic_TBs_from_hbm_lower_bound comes from "
+                                                    "HBM; frac_traffic (bytes that leave the LDS, over time) is quoted against the 8.0 TB/s "
+                                                    "specification and against the 6.3 TB/s the guide measures as sustained "
+                                                    "(frac_traffic_of_sustained_6.3TBs).  The 256- and 512-problem points are "
+                                                    "Infinity-Cache-assisted and are not HBM figures.")
         # a few problems per call: the launch-per-round form (problem = grid dimension) against one workgroup per problem
         out["few_problems"] = []
         for P in (4, 16):

@@ -525,13 +525,15 @@ def test_single_pass_compaction_equals_the_default(vo, ctx):
 
 
 @pytest.mark.parametrize("general_k", [False, True])
-def test_batched_forms_agree_on_nan_and_inf_world_points(vo, ctx, general_k):
+def test_batched_forms_agree_on_nan_and_inf_world_points(vo, ctx, o32, general_k):
     """the one-workgroup-per-problem kernel multiplies its Jacobian terms with v_mul_legacy_f32 (0 * anything = 0,
-    vo_math.h: vo_mul0), the launch-per-round form with plain products.  A world point that really is NaN (not the DROPPED
-    marker) passes every gate of the reference (all comparisons false, camera.h:28-35) and poisons H, b and the pose -- in
-    both forms; an infinite one fails the depth gate (pc.z > z_far) and must leave no trace -- in both forms, although
-    0 * inf is NaN in a plain product: a rejected term contributes exact zeros."""
+    vo_math.h: vo_mul0), the launch-per-round form with plain products and selects.  A world point that really is NaN (not
+    the DROPPED marker) passes every gate of the reference (all comparisons false, camera.h:28-35) and poisons H, b and the
+    pose -- in both forms, as in the oracle; so does x = -inf (R p at the identity holds 0 * inf = NaN in pc.y and pc.z).  A
+    point at z = +-inf fails the depth gate (pc.z beyond z_far / z_near: a true comparison) and must leave no trace -- in
+    both forms, although its pc.x is NaN: a rejected term contributes exact zeros."""
     import ctypes as C
+    from oracle.oracle import Camera as OCam
     fp = vo.synth.frame_pair(3000, seed=61)
     K = fp["K"].copy()
     if general_k:
@@ -539,11 +541,13 @@ def test_batched_forms_agree_on_nan_and_inf_world_points(vo, ctx, general_k):
     n = len(fp["model"])
     gt = fp["gt_matches"]
     pairs = np.stack([gt[:, 1], gt[:, 0]], 1).astype(np.int32)              # (cur idx, model idx): model i <-> ref i here
-    worlds = np.stack([fp["model"]] * 4).astype(np.float32)
-    worlds[1, 100] = np.nan                                                 # problem 1: a NaN world point
-    worlds[2, 200, 2] = np.inf                                              # problem 2: a point at infinite depth (rejected)
-    worlds[3, 300, 0] = -np.inf                                             # problem 3: infinite x at finite depth: u = -inf, rejected by the image gate
-    P = 4
+    P = 5
+    worlds = np.stack([fp["model"]] * P).astype(np.float32)
+    worlds[1, 100] = np.nan                                                 # poison
+    worlds[2, 200, 2] = np.inf                                              # rejected by the depth gate
+    worlds[3, 300, 2] = -np.inf                                             # rejected by the depth gate
+    worlds[4, 400, 0] = -np.inf                                             # poison (0 * inf in pc.y, pc.z)
+    poisoned = (1, 4)
     d_w, d_m = ctx.to_device(worlds), ctx.to_device(np.stack([fp["cur_pts"]] * P))
     d_p, d_n = ctx.to_device(np.stack([pairs] * P)), ctx.to_device(np.full(P, n, np.int32))
     d_T, d_s = ctx.alloc(P * 64), ctx.alloc(P * 16)
@@ -563,11 +567,14 @@ def test_batched_forms_agree_on_nan_and_inf_world_points(vo, ctx, general_k):
         ctx.lib.vo_picp_batch_set_form(ctx.h, 0)
         for d in (d_w, d_m, d_p, d_n, d_T, d_s):
             ctx.free(d)
-    for form in (1, 2):
-        T, st = out[form]
-        assert np.isfinite(T[0]).all() and st[0, 2] == n
-        assert np.isnan(T[1]).any()                                         # poisoned, like the reference
-        for p in (2, 3):                                                    # rejected: the other n - 1 correspondences decide
-            assert np.isfinite(T[p]).all() and st[p, 2] == n - 1 and np.abs(T[p] - T[0]).max() < 1e-3
+    for p in range(P):
+        r = o32.picp_solve(OCam(480, 640, 0, 10, K, np.eye(4)), worlds[p], fp["cur_pts"], pairs, 8, 10000.0, False, trace=False)
+        assert np.isfinite(r["T"]).all() == (p not in poisoned)             # the reference's own behaviour, as restated
+        for form in (1, 2):
+            T, st = out[form]
+            if p in poisoned:
+                assert np.isnan(T[p]).any()
+            else:
+                assert np.abs(T[p].reshape(4, 4).T - r["T"]).max() < 1e-4 and int(st[p, 2]) == r["num_inliers"] == (n if p == 0 else n - 1)
     for p in (0, 2, 3):                                                     # the two forms differ by the order of their sums only
         assert np.abs(out[1][0][p] - out[2][0][p]).max() < 1e-5 and np.array_equal(out[1][1][p, 1:], out[2][1][p, 1:])

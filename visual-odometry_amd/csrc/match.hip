@@ -1580,10 +1580,13 @@ struct HashArgs {
 
 // Sample queries per frame and how many of them must have a bitwise copy in the tree for the frame to take the pass in the
 // automatic mode.  Matcher stage per 200 x 50k frames by share of queries WITHOUT a copy: 0 %: 0.52 ms, 1 %:
-// 0.71, 5 %: 0.77, 10 %: 1.15, 50 %: 1.28, 90 %: 1.44 -- the search alone: 1.10 at every share.  So the pass should run below
-// ~10 % and not above; "any of 8 samples" (round 4) ran it up to 100 %.  15 of 16: taken with probability 0.99 / 0.81 / 0.51 /
-// 0.06 / 0.0003 at 1 / 5 / 10 / 25 / 50 % -- a wrong guess costs time only, whatever the pass leaves open the search finds.
-constexpr int HJ_SAMPLES = 16, HJ_SAMPLE_MIN = 15;
+// 0.72, 5 %: 0.77, 25 %: 1.26, 100 %: 1.21 with "any of 8 samples" (round 4) -- the search alone: 1.10 at every share, so the
+// pass loses 0.1-0.2 ms from ~10 % on.  Round 5 tried the obvious repair: 16 samples, at least 15 found -- taken
+// with probability 0.99 / 0.81 / 0.06 / 0 at 1 / 5 / 25 / 100 % -- and measured it WORSE at every share: 0.77 / 1.10 / 1.32 /
+// 1.29 ms (frames of one call split over two routes keep both chains of kernels busy, and sixteen scalar sample loads per
+// wave lengthen the row-hash kernel by 0.08 ms).  So the rule stays "any of 8"; vo_match_set_mode(3) is the choice for data
+// known to carry recomputed descriptors.  The plumbing for a threshold stays (HashArgs::sample_min).
+constexpr int HJ_SAMPLES = 8, HJ_SAMPLE_MIN = 1;
 __device__ __forceinline__ bool hash_frame_takes_pass(const HashArgs& a, int f) { return __popc(a.sample_mask[f]) >= a.sample_min; }
 __device__ __forceinline__ bool row_safe(const Row10& r) {       // every |x| in [2^-40, inf): an unsigned range test on the bits
   unsigned worst = 0;
