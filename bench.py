@@ -479,6 +479,35 @@ def _timed_batches(torch, ctx, bp, poses_t, dist, vdist, reps):
     return dt / reps, all_poses
 
 
+def _per_rank_rows(torch, ctx, bp, poses_t, dist, vdist, units, reps=5):
+    """Outside the timed region, for reading a scaling run: every rank's own compute time per pass (its calls alone,
+    synchronised on its own stream, no collective) and the time of the pose gather alone -- so that the first run on a
+    real node shows whether a lost rank, a slow GPU or the collective is what the whole-job figure pays for."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        bp.run()
+    ctx.synchronize()
+    compute = (time.perf_counter() - t0) / reps
+    gather = 0.0
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            vdist.gather_poses(poses_t)
+        torch.cuda.synchronize()
+        gather = (time.perf_counter() - t0) / reps
+        rows = vdist.gather_values([compute, gather, float(units)], poses_t.device)
+    else:
+        rows = [[compute, gather, float(units)]]
+    return {"ranks_seen": len(rows), "units_per_rank": [int(r[2]) for r in rows],
+            "compute_ms_per_rank": [r[0] * 1e3 for r in rows], "frames_per_sec_per_rank": [r[2] / r[0] for r in rows],
+            "gather_ms_per_rank": [r[1] * 1e3 for r in rows],
+            "note": "per rank, outside the timed region: its own calls per pass without any collective, and the all-gather of the "
+                    "poses alone (after a barrier)"}
+
+
 def _check_batches(bp, points):
     P = bp.poses()
     err = float(np.abs(P - bp.X_gt).max())
@@ -505,6 +534,7 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
         assert all_poses.shape == (world * frames, 16)
         assert torch.equal(all_poses[rank * frames:(rank + 1) * frames], poses_t)
     ms = sec * 1e3
+    per_rank = _per_rank_rows(torch, ctx, bp, poses_t, dist, vdist, frames)
     err = _check_batches(bp, args.points)
     # the matcher chain of the same frames alone (vo_match_appearances_batch_dev: bounds, level 1, offsets, level 2, search, compaction)
     bp.match_only(); ctx.synchronize()
@@ -575,6 +605,7 @@ def frame_throughput(vo, torch, ctx, stream, args, dist=None, vdist=None, rank=0
     return {"frames_per_gpu": frames, "n_gpus": world, "frames_total": frames * world, "ms_per_batch": ms, "scaling": "weak",
             "frames_per_sec": frames * world / (ms * 1e-3), "us_per_frame_per_gpu": ms * 1e3 / frames, "pose_err_vs_gt": err,
             "seeds": f"4000+p, p = {frames * rank}..{frames * rank + frames - 1} on this rank",
+            "per_rank": per_rank,
             "matcher_ms_per_batch": match_ms,
             "matcher_ms_by_open_share": by_share,
             "frames_per_sec_without_copies": without["frames_per_sec"] if without else None,
@@ -614,13 +645,14 @@ def frame_throughput_strong(vo, torch, ctx, stream, args, dist=None, vdist=None,
         r0, r1 = plan.own_rows()
         assert torch.equal(all_poses[r0:r1], poses_t[:n_local])
         assert plan.global_order(all_poses).shape == (P, 16)
+    per_rank = _per_rank_rows(torch, ctx, bp, poses_t, dist, vdist, n_local, reps=2)
     err = _check_batches(bp, args.points)
     bp.close()
     alg = _frame_alg_bytes(args.points, args.iters) * P
     return {"pairs_total": P, "n_gpus": world, "pairs_this_rank": n_local, "frames_per_call": args.strong_per_call,
             "calls_per_pass": len(bp.calls), "scaling": "strong", "seconds_per_pass": sec, "frames_per_sec": P / sec,
             "us_per_frame": sec * 1e6 / P, "pose_err_vs_gt": err, "seeds": f"4000+p, p = {lo}..{hi - 1} on this rank",
-            "setup_s": t_setup, "generator_workers": _PairGen.workers,
+            "setup_s": t_setup, "generator_workers": _PairGen.workers, "per_rank": per_rank,
             "roofline": {"bound": "hbm", "scope": "whole frame, all GPUs", "achieved": alg / sec / 1e9,
                          "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": alg / sec / 1e9 / (HBM_PEAK_GBS * world),
                          "algorithmic_bytes_per_pass": alg},

@@ -64,6 +64,9 @@ WORKER = textwrap.dedent("""
         pass
     t = vdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
     assert t == float(world)
+    # bench.py's per-rank rows (compute time, gather time, units): every rank's values on every rank, rank-major
+    rows = vdist.gather_values([0.5 + rank, 2.0 * rank, 200.0], torch.device("cpu"))
+    assert rows == [[0.5, 0.0, 200.0], [1.5, 2.0, 200.0]]
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")

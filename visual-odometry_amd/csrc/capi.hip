@@ -108,6 +108,15 @@ struct vo_ctx {
   const PicpParams* batch_params_dev = nullptr;
   DevBuf prune_ws;    // sorted copies / tables of the matcher's sorted variants
   DevBuf epi_ws;      // maxima, A^T A and vote counts of vo_estimate_transform
+  // Steering of the automatic matcher by what the previous batched call found: after a call that ran the
+  // exact-duplicate pass, "did any frame take it?" travels to pinned host memory behind the call (no wait); a later call
+  // that finds the answer "none" there leaves the pass out for the next HINT_SKIP calls, then probes again.  Data whose
+  // descriptors are recomputed per frame (no bitwise copies, ever) then pays the sampling pass once in seventeen calls.
+  int* hint_host = nullptr;        // pinned
+  int* hint_dev = nullptr;
+  hipEvent_t hint_ev = nullptr;
+  bool hint_pending = false;
+  int hint_skip_left = 0;
   int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan, 3 cell-hash search, 4 / 5 exact-duplicate pass first, then 2 / 3
   int batch_form = 0; // batched solver: 0 auto, 1 one launch per round, 2 one workgroup per problem
   bool capturing = false;
@@ -235,7 +244,10 @@ int vo_ctx_destroy(vo_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   c->scratch.release(); c->best.release(); c->table.release(); c->counts.release();
-  c->batch_pack.release(); c->batch_bad.release(); c->prune_ws.release(); c->epi_ws.release(); c->batch_states.release(); c->batch_partials.release();
+  c->batch_pack.release(); c->batch_bad.release(); c->prune_ws.release(); c->epi_ws.release();
+  if (c->hint_ev) (void)hipEventDestroy(c->hint_ev);
+  if (c->hint_host) (void)hipHostFree(c->hint_host);
+  if (c->hint_dev) (void)hipFree(c->hint_dev); c->batch_states.release(); c->batch_partials.release();
   for (auto& b : c->in) b.release();
   for (auto& b : c->out) b.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1058,6 +1070,38 @@ static int with_hash(int v, int nt, int n_frames) {
   return (on && (v == 2 || v == 3) && match_hash_supported(nt, n_frames)) ? v + 2 : v;
 }
 static int match_auto_flag(const vo_ctx* c) { return c->match_mode == 0 ? MATCH_VARIANT_AUTO : 0; }
+
+// the two halves of the steering described at vo_ctx::hint_host, around a batched matcher call in automatic mode
+constexpr int HINT_SKIP = 16;
+static int match_hint_before(vo_ctx* c, int variant) {
+  static const bool off = [] { const char* e = getenv("VO_MATCH_HINT"); return e && e[0] == '0'; }();
+  if (off || c->match_mode != 0 || variant < 4 || c->capturing) return variant;
+  if (c->hint_pending && hipEventQuery(c->hint_ev) == hipSuccess) {
+    c->hint_pending = false;
+    if (*c->hint_host == 0) c->hint_skip_left = HINT_SKIP;
+  }
+  (void)hipGetLastError();                        // (hipErrorNotReady of the query is not an error of this call)
+  if (c->hint_skip_left > 0) { --c->hint_skip_left; return variant - 2; }      // the plain search: same pairs
+  return variant;
+}
+static void match_hint_after(vo_ctx* c, int variant, const void* ws, int n_frames) {
+  if (c->match_mode != 0 || variant < 4 || c->capturing || !ws) return;
+  if (!c->hint_host) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->hint_host), 64, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->hint_dev), 64) != hipSuccess ||
+        hipEventCreateWithFlags(&c->hint_ev, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      if (c->hint_host) { (void)hipHostFree(c->hint_host); c->hint_host = nullptr; }      // no steering, nothing else changes
+      return;
+    }
+    *c->hint_host = 1;
+  }
+  if (c->hint_pending) return;                     // an answer is still on its way
+  if (launch_match_hint(c->stream, ws, n_frames, c->hint_dev) != hipSuccess ||
+      hipMemcpyAsync(c->hint_host, c->hint_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipEventRecord(c->hint_ev, c->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+  c->hint_pending = true;
+}
 static int match_variant(const vo_ctx* c, int nt, int nq, int n_frames) {
   const bool cells_ok = match_cells_supported(nt, nq);      // the cell-hash search serves sets of up to 1.8 M points
   if (c->match_mode != 0) {
@@ -1159,12 +1203,13 @@ int vo_match_appearances_batch_dev(vo_ctx* c, int n_frames, const float* d_a1, i
   VO_HIP_CHECK(c->scratch.ensure(sizeof(int) * compaction_scratch_ints(q) * (size_t)n_frames, c->stream));
   VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)(q ? q : 1) * (size_t)n_frames, c->stream));
   const int nt = cap1 > cap2 ? cap1 : cap2;
-  const int variant = d_n1 ? ragged_variant(c, nt, q, n_frames) : match_variant(c, nt, q, n_frames);
+  const int variant = match_hint_before(c, d_n1 ? ragged_variant(c, nt, q, n_frames) : match_variant(c, nt, q, n_frames));
   void* ws = nullptr;
   if (q > 0) if (int r = match_workspace(c, variant, nt, d_n1 ? nt : q, n_frames, &ws)) return r;
   VO_HIP_CHECK(launch_match_batch(c->stream, d_a1, cap1, 10 * (size_t)cap1, d_a2, cap2, 10 * (size_t)cap2, radius, d_out_pairs,
                                   (size_t)q, d_n_out, c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, n_frames,
                                   variant | match_auto_flag(c), d_n1, d_n2));
+  match_hint_after(c, variant, ws, n_frames);
   return VO_OK;
 }
 
@@ -1201,7 +1246,7 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
   VO_HIP_CHECK(c->table.ensure(sizeof(unsigned long long) * (size_t)(b->n_ref ? b->n_ref : 1) * (size_t)F, c->stream));
   // ragged frames (sz): the counts of the struct are capacities (= strides), frame f holds sz->n_ref[f] / n_cur[f] points and
   // n_model_pairs[f] model pairs; the matcher (full scan or cell-hash search) picks every frame's roles itself (vo_complete.cpp:15-20)
-  const int variant = sz ? ragged_variant(c, nt, q, F) : match_variant(c, nt, q, F);
+  const int variant = match_hint_before(c, sz ? ragged_variant(c, nt, q, F) : match_variant(c, nt, q, F));
   void* ws = nullptr;
   if (int r = match_workspace(c, variant, nt, sz ? nt : q, F, &ws)) return r;
   int* n_match = b->counts;
@@ -1212,6 +1257,7 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
                                   10 * (size_t)b->n_cur, b->radius, b->matches, (size_t)q, n_match,
                                   c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, F, variant | match_auto_flag(c),
                                   sz ? sz->n_ref : nullptr, sz ? sz->n_cur : nullptr));
+  match_hint_after(c, variant, ws, F);
   // X_curr * triangulated_pc                                                    vo_complete.cpp:159
   // The moved cloud as an output is optional: without it the solver's gather applies X_prev to the points it fetches (the
   // same arithmetic, PointCloud.h:80) and the pass that writes n_model points per frame only to re-read the joined ones

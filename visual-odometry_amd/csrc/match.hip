@@ -2306,6 +2306,20 @@ static hipError_t launch_hash_first(hipStream_t st, const float* tree, int nt, c
   return hipGetLastError();
 }
 
+// "did any frame of the call that just ran take the exact-duplicate pass?" (sample masks at the head of its workspace) into
+// *d_out: what the host reads -- without waiting, capi.hip -- to decide whether the next calls run the pass at all
+__global__ void hash_hint_kernel(const unsigned* masks, int n_frames, int sample_min, int* out) {
+  int any = 0;
+  for (int f = threadIdx.x; f < n_frames; f += blockDim.x) any |= __popc(masks[f]) >= sample_min ? 1 : 0;
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) *out = any;
+}
+hipError_t launch_match_hint(hipStream_t st, const void* d_prune_ws, int n_frames, int* d_out) {
+  const unsigned* masks = reinterpret_cast<const unsigned*>(static_cast<const int*>(d_prune_ws) + 2 * (size_t)n_frames);
+  hipLaunchKernelGGL(hash_hint_kernel, dim3(1), dim3(256), 0, st, masks, n_frames, HJ_SAMPLE_MIN, d_out);
+  return hipGetLastError();
+}
+
 // compute units of the device the running call targets (launch_match_batch sets it from its n_cu argument; the radius search,
 // which has none, keeps the last value or MI355X's 256)
 static thread_local int t_n_cu = 256;

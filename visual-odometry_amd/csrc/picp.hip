@@ -495,7 +495,10 @@ __global__ __launch_bounds__(PICP_BLOCK) void picp_round_batch_kernel(const Picp
 }
 
 int picp_grid_for(int n_corr, int n_cu) {
-  int g = (n_corr + PICP_BLOCK - 1) / PICP_BLOCK;
+  // correspondences per thread (VO_PICP_PER_THREAD in the environment, default 1): fewer workgroups mean fewer partial rows
+  // for every workgroup of the next round to wait for, against a longer linearisation in each
+  static const int per_thread = [] { const char* e = getenv("VO_PICP_PER_THREAD"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 16 ? v : 1; }();
+  int g = (n_corr + PICP_BLOCK * per_thread - 1) / (PICP_BLOCK * per_thread);
   if (g < 1) g = 1;
   // beyond one workgroup per CU let each thread take several correspondences
   // before adding workgroups: the per-iteration partial reduction reads

@@ -221,6 +221,8 @@ hipError_t launch_join(hipStream_t st, const int32_t* d_img, int n_img, const in
 // workspace of variant v holds match_workspace_bytes(v, nt, nq, n_frames) bytes
 constexpr int MATCH_VARIANT_AUTO = 0x100;     // or-ed into a variant that the automatic rule picked (launch_match[_batch]): the
                                               //   exact-duplicate pass then asks for most of a frame's sample queries to have a copy
+// after a call that ran variant 4 / 5 on d_prune_ws: *d_out = 1 when at least one frame took the exact-duplicate pass
+hipError_t launch_match_hint(hipStream_t st, const void* d_prune_ws, int n_frames, int* d_out);
 size_t match_pruned_workspace_bytes(int nt, int nq, int n_frames);
 size_t match_cells_workspace_bytes(int nt, int nq, int n_frames);
 size_t match_hash_workspace_bytes(int nt, int n_frames);

@@ -92,6 +92,19 @@ def max_over_ranks(value: float, device) -> float:
     return float(t.item())
 
 
+def gather_values(values, device):
+    """every rank's list of floats on every rank: (world, len(values)) nested list, rank-major (bench.py's per-rank rows)"""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return [[float(x) for x in p.tolist()] for p in parts]
+
+
 def gather_ragged(items, device=None):
     """All-gather of variable-length int32 pair lists: `items` is this rank's list of (n_i, 2) int32
     tensors (its contiguous block under shard_range); returns the list over ALL ranks in global item
