@@ -233,9 +233,12 @@ int vo_picp_solve_batch_dev(vo_ctx *ctx, int n_problems, int rows, int cols, int
  * at the sizes where it sorts (sets of up to 204 800 points; beyond, 2 / 3 alone).  In mode 5 a frame that is left with
  * FEW open queries (at most 1/16 of its queries, and 2560: the new landmarks of a tracking frame) does not sort its tree at
  * all: the open queries are ordered by cell and the tree is streamed once past them.  Matcher stage of 200 x 50k frames:
- * 0.52 ms when every query has a copy, 0.71 at 1 % open, 0.77 at 5 %, 1.15 beyond the limit; mode 3 alone 1.10;
- * data WITHOUT any copies is noticed from eight sampled queries per frame and skips the tables and the lookup (1.21 ms);
- * partly copied data (10 - 90 % of the queries without a copy) pays 0.05 - 0.35 ms for the pass -- ask for mode 3 there. */
+ * 0.52 ms when every query has a copy, 0.73 at 1 % open, 0.80 at 5 %, 1.27 at 25 % (profiles/r05_bench_line.json); mode 3
+ * alone 1.10; data WITHOUT any copies is noticed from eight sampled queries per frame and skips the tables and the lookup
+ * (1.29 ms) -- and, in mode 0, the NEXT calls leave the pass out altogether (1.10 ms): what the previous call found travels to
+ * the host behind the stream, "no frame took the pass" switches it off for 16 calls, a sample query that the search finds at
+ * distance 0 switches it on again at once, vo_match_set_mode() forgets what was learnt.  Partly copied data (10 - 90 % of
+ * the queries without a copy) pays 0.05 - 0.2 ms for the pass -- ask for mode 3 there. */
 int vo_match_set_mode(vo_ctx *ctx, int mode);
 int vo_match_appearances(vo_ctx *ctx, const float *a1, int n1, const float *a2, int n2,
                          float radius, int32_t *out_pairs, int *n_out);

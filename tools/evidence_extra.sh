@@ -25,3 +25,5 @@ O=gpurun_out/${TAG}_headline_per_thread.txt
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('%.0f iter/s  %.3f us/round' % (d['value'], d['roofline']['launch_us']))"; done; done; } > $O
 cat $O
+rm -rf gpurun_out/prof_${TAG}nocopy gpurun_out/prof_${TAG}onepass gpurun_out/prof_${TAG}twopass
+du -sh gpurun_out

@@ -112,11 +112,15 @@ struct vo_ctx {
   // exact-duplicate pass, "did any frame take it?" travels to pinned host memory behind the call (no wait); a later call
   // that finds the answer "none" there leaves the pass out for the next HINT_SKIP calls, then probes again.  Data whose
   // descriptors are recomputed per frame (no bitwise copies, ever) then pays the sampling pass once in seventeen calls.
+  // A call that ran WITHOUT the pass asks the same question of the keys the search left (a sample query at distance 0 from
+  // its match): the answer "yes" ends the skipping at once, so data that regains its copies loses one or two calls, not sixteen.
+  // vo_match_set_mode() forgets what was learnt.
   int* hint_host = nullptr;        // pinned
   int* hint_dev = nullptr;
   hipEvent_t hint_ev = nullptr;
   bool hint_pending = false;
   int hint_skip_left = 0;
+  bool hint_of_skipped_call = false;   // what the pending answer was asked of
   int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan, 3 cell-hash search, 4 / 5 exact-duplicate pass first, then 2 / 3
   int batch_form = 0; // batched solver: 0 auto, 1 one launch per round, 2 one workgroup per problem
   bool capturing = false;
@@ -1073,19 +1077,23 @@ static int match_auto_flag(const vo_ctx* c) { return c->match_mode == 0 ? MATCH_
 
 // the two halves of the steering described at vo_ctx::hint_host, around a batched matcher call in automatic mode
 constexpr int HINT_SKIP = 16;
-static int match_hint_before(vo_ctx* c, int variant) {
+static int match_hint_before(vo_ctx* c, int variant, bool* skipped) {
   static const bool off = [] { const char* e = getenv("VO_MATCH_HINT"); return e && e[0] == '0'; }();
+  *skipped = false;
   if (off || c->match_mode != 0 || variant < 4 || c->capturing) return variant;
   if (c->hint_pending && hipEventQuery(c->hint_ev) == hipSuccess) {
     c->hint_pending = false;
-    if (*c->hint_host == 0) c->hint_skip_left = HINT_SKIP;
+    if (c->hint_of_skipped_call) { if (*c->hint_host != 0) c->hint_skip_left = 0; }      // copies are back: the pass again
+    else if (*c->hint_host == 0) c->hint_skip_left = HINT_SKIP;                           // no frame took the pass: leave it out
   }
   (void)hipGetLastError();                        // (hipErrorNotReady of the query is not an error of this call)
-  if (c->hint_skip_left > 0) { --c->hint_skip_left; return variant - 2; }      // the plain search: same pairs
+  if (c->hint_skip_left > 0) { --c->hint_skip_left; *skipped = true; return variant - 2; }      // the plain search: same pairs
   return variant;
 }
-static void match_hint_after(vo_ctx* c, int variant, const void* ws, int n_frames) {
-  if (c->match_mode != 0 || variant < 4 || c->capturing || !ws) return;
+// skipped: the call ran without the pass (match_hint_before took it out); best / nq_cap / sizes: its keys
+static void match_hint_after(vo_ctx* c, int variant, bool skipped, const void* ws, int n_frames, const unsigned long long* d_best,
+                             size_t best_stride, int nq_cap, const int* d_n1, const int* d_n2) {
+  if (c->match_mode != 0 || (variant < 4 && !skipped) || c->capturing || !ws || nq_cap <= 0) return;
   if (!c->hint_host) {
     if (hipHostMalloc(reinterpret_cast<void**>(&c->hint_host), 64, hipHostMallocDefault) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->hint_dev), 64) != hipSuccess ||
@@ -1097,7 +1105,10 @@ static void match_hint_after(vo_ctx* c, int variant, const void* ws, int n_frame
     *c->hint_host = 1;
   }
   if (c->hint_pending) return;                     // an answer is still on its way
-  if (launch_match_hint(c->stream, ws, n_frames, c->hint_dev) != hipSuccess ||
+  const hipError_t el = skipped ? launch_match_hint_from_best(c->stream, d_best, best_stride, nq_cap, d_n1, d_n2, n_frames, c->hint_dev)
+                                : launch_match_hint(c->stream, ws, n_frames, c->hint_dev);
+  c->hint_of_skipped_call = skipped;
+  if (el != hipSuccess ||
       hipMemcpyAsync(c->hint_host, c->hint_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipEventRecord(c->hint_ev, c->stream) != hipSuccess) { (void)hipGetLastError(); return; }
   c->hint_pending = true;
@@ -1139,6 +1150,8 @@ int vo_match_set_mode(vo_ctx* c, int mode) {
   VO_REQUIRE(mode >= 0 && mode <= 5, "mode must be 0 (auto), 1 (full scan), 2 (bucket-pruned scan), 3 (cell-hash search), "
                                      "4 / 5 (exact-duplicate pass, then 2 / 3)");
   c->match_mode = mode;
+  c->hint_skip_left = 0;              // what the automatic mode learnt from earlier calls is forgotten
+  c->hint_pending = false;
   return VO_OK;
 }
 
@@ -1203,13 +1216,14 @@ int vo_match_appearances_batch_dev(vo_ctx* c, int n_frames, const float* d_a1, i
   VO_HIP_CHECK(c->scratch.ensure(sizeof(int) * compaction_scratch_ints(q) * (size_t)n_frames, c->stream));
   VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)(q ? q : 1) * (size_t)n_frames, c->stream));
   const int nt = cap1 > cap2 ? cap1 : cap2;
-  const int variant = match_hint_before(c, d_n1 ? ragged_variant(c, nt, q, n_frames) : match_variant(c, nt, q, n_frames));
+  bool skipped = false;
+  const int variant = match_hint_before(c, d_n1 ? ragged_variant(c, nt, q, n_frames) : match_variant(c, nt, q, n_frames), &skipped);
   void* ws = nullptr;
   if (q > 0) if (int r = match_workspace(c, variant, nt, d_n1 ? nt : q, n_frames, &ws)) return r;
   VO_HIP_CHECK(launch_match_batch(c->stream, d_a1, cap1, 10 * (size_t)cap1, d_a2, cap2, 10 * (size_t)cap2, radius, d_out_pairs,
                                   (size_t)q, d_n_out, c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, n_frames,
                                   variant | match_auto_flag(c), d_n1, d_n2));
-  match_hint_after(c, variant, ws, n_frames);
+  match_hint_after(c, variant, skipped, ws, n_frames, c->best.as<unsigned long long>(), (size_t)q, q, d_n1, d_n2);
   return VO_OK;
 }
 
@@ -1246,7 +1260,8 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
   VO_HIP_CHECK(c->table.ensure(sizeof(unsigned long long) * (size_t)(b->n_ref ? b->n_ref : 1) * (size_t)F, c->stream));
   // ragged frames (sz): the counts of the struct are capacities (= strides), frame f holds sz->n_ref[f] / n_cur[f] points and
   // n_model_pairs[f] model pairs; the matcher (full scan or cell-hash search) picks every frame's roles itself (vo_complete.cpp:15-20)
-  const int variant = match_hint_before(c, sz ? ragged_variant(c, nt, q, F) : match_variant(c, nt, q, F));
+  bool skipped = false;
+  const int variant = match_hint_before(c, sz ? ragged_variant(c, nt, q, F) : match_variant(c, nt, q, F), &skipped);
   void* ws = nullptr;
   if (int r = match_workspace(c, variant, nt, sz ? nt : q, F, &ws)) return r;
   int* n_match = b->counts;
@@ -1257,7 +1272,7 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
                                   10 * (size_t)b->n_cur, b->radius, b->matches, (size_t)q, n_match,
                                   c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, F, variant | match_auto_flag(c),
                                   sz ? sz->n_ref : nullptr, sz ? sz->n_cur : nullptr));
-  match_hint_after(c, variant, ws, F);
+  match_hint_after(c, variant, skipped, ws, F, c->best.as<unsigned long long>(), (size_t)q, q, sz ? sz->n_ref : nullptr, sz ? sz->n_cur : nullptr);
   // X_curr * triangulated_pc                                                    vo_complete.cpp:159
   // The moved cloud as an output is optional: without it the solver's gather applies X_prev to the points it fetches (the
   // same arithmetic, PointCloud.h:80) and the pass that writes n_model points per frame only to re-read the joined ones

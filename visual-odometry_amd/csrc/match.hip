@@ -2314,6 +2314,27 @@ __global__ void hash_hint_kernel(const unsigned* masks, int n_frames, int sample
   any = __syncthreads_or(any);
   if (threadIdx.x == 0) *out = any;
 }
+// the same question asked of a call that ran WITHOUT the pass: eight evenly spread queries per frame -- does any of them sit at
+// distance exactly 0 from its match (a bitwise copy, for rows the pass would take)?  Reads the keys the search left.
+__global__ void best_hint_kernel(const unsigned long long* best, size_t best_stride, int nq_cap, const int* d_n1, const int* d_n2,
+                                 int n_frames, int* out) {
+  int any = 0;
+  for (int i = threadIdx.x; i < n_frames * 8; i += blockDim.x) {
+    const int f = i >> 3, k = i & 7;
+    int nq = nq_cap;
+    if (d_n1 && d_n2) { const int a = d_n1[f], b = d_n2[f]; nq = a < b ? a : b; nq = nq < 0 ? 0 : (nq > nq_cap ? nq_cap : nq); }
+    if (nq <= 0) continue;
+    const unsigned long long key = best[(size_t)f * best_stride + (size_t)(k * (nq >> 3))];
+    any |= ((unsigned)(key >> 32) == 0u && (unsigned)key != 0xffffffffu) ? 1 : 0;
+  }
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) *out = any;
+}
+hipError_t launch_match_hint_from_best(hipStream_t st, const unsigned long long* d_best, size_t best_stride, int nq_cap,
+                                       const int* d_n1, const int* d_n2, int n_frames, int* d_out) {
+  hipLaunchKernelGGL(best_hint_kernel, dim3(1), dim3(256), 0, st, d_best, best_stride, nq_cap, d_n1, d_n2, n_frames, d_out);
+  return hipGetLastError();
+}
 hipError_t launch_match_hint(hipStream_t st, const void* d_prune_ws, int n_frames, int* d_out) {
   const unsigned* masks = reinterpret_cast<const unsigned*>(static_cast<const int*>(d_prune_ws) + 2 * (size_t)n_frames);
   hipLaunchKernelGGL(hash_hint_kernel, dim3(1), dim3(256), 0, st, masks, n_frames, HJ_SAMPLE_MIN, d_out);

@@ -223,6 +223,9 @@ constexpr int MATCH_VARIANT_AUTO = 0x100;     // or-ed into a variant that the a
                                               //   exact-duplicate pass then asks for most of a frame's sample queries to have a copy
 // after a call that ran variant 4 / 5 on d_prune_ws: *d_out = 1 when at least one frame took the exact-duplicate pass
 hipError_t launch_match_hint(hipStream_t st, const void* d_prune_ws, int n_frames, int* d_out);
+// after a call that ran WITHOUT the pass: *d_out = 1 when one of eight sample queries of some frame found its match at distance 0
+hipError_t launch_match_hint_from_best(hipStream_t st, const unsigned long long* d_best, size_t best_stride, int nq_cap,
+                                       const int* d_n1, const int* d_n2, int n_frames, int* d_out);
 size_t match_pruned_workspace_bytes(int nt, int nq, int n_frames);
 size_t match_cells_workspace_bytes(int nt, int nq, int n_frames);
 size_t match_hash_workspace_bytes(int nt, int n_frames);
