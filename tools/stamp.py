@@ -98,6 +98,15 @@ def status(path, sha=None):
     """'current' / 'stale' / 'unstamped' for an evidence file against the running tree's kernel sources"""
     st = read_stamp(path)
     if not st or not st.get("csrc_sha"):
+        # a file that cannot carry a stamp (csv): the round's list speaks for it (profiles/rNN_stamp.json)
+        side = os.path.join(os.path.dirname(path), os.path.basename(path)[:3] + "_stamp.json")
+        try:
+            d = json.load(open(side))
+            if os.path.basename(path) in d.get("files", []):
+                st = d["stamp"]
+        except (OSError, ValueError, KeyError):
+            pass
+    if not st or not st.get("csrc_sha"):
         return "unstamped", st
     return ("current" if st["csrc_sha"] == (sha or csrc_sha()) else "stale"), st
 
