@@ -149,7 +149,14 @@ int vo_picp_get_kernel_threshold(vo_picp *s, float *thr);       /* picp_solver.h
  * place between two rounds is seen.  When the array has the length of the
  * packed one the round is enqueued first and the comparison runs while the GPU
  * works; a difference then repeats that round on the new pairs (it had written
- * nothing a repeat does not overwrite).  As in the reference it cannot fail on
+ * nothing a repeat does not overwrite).  Once two calls in a row have matched --
+ * the reference's loop -- a call enqueues its round and up to six more as ONE
+ * graph launch, and the calls that follow only compare and claim theirs; rounds
+ * that ran ahead and are not claimed (the loop ended, the pairs / points /
+ * parameters changed) are ignored or repeated, never seen: every result is the
+ * one a closed solve of the counted rounds gives.  VO_PICP_RUN_AHEAD=0..6 in the
+ * environment (read by vo_picp_create) bounds the look-ahead; at most that many
+ * rounds of GPU time are spent for nothing per loop.  As in the reference it cannot fail on
  * "too few inliers" (min_num_inliers is 0 with no setter). */
 int vo_picp_one_round(vo_picp *s, const int32_t *pairs, int n_pairs, int keep_outliers);
 /* Bookkeeping of the above (any pointer may be NULL): rounds enqueued whose finishing launch is still to come, calls

@@ -172,3 +172,50 @@ def test_small_and_empty_problems_keep_their_one_launch_forms(vo, ctx, o32):
     t.solve(e, False, 3)
     assert _state(s) == _state(t)
     s.close(); t.close()
+
+
+def test_rounds_enqueued_ahead_of_the_caller_are_claimed_repeated_or_ignored(vo, ctx, o32):
+    """Once two calls in a row have matched, a call enqueues its round and up to six more as one graph launch (capi.hip:
+    run_ahead); the following calls claim theirs after comparing.  Whatever interrupts the loop at whatever position of that
+    window -- a getter, an in-place edit, other points, another threshold, a closed solve -- must leave the bits of closed solves
+    on the same arrays: rounds that ran ahead unclaimed are repeated on the new data or ignored."""
+    fp, j = _problem(vo, o32, n=5000, seed=36)
+    model2 = (fp["model"] + np.float32(0.02)).astype(np.float32)
+    C = vo.api.C
+    for k in range(2, 13):                          # the interruption after k calls: every position of the window at least once
+        for what in ("getter", "edit", "points", "threshold", "solve"):
+            s, t = _solver(vo, ctx, fp, 200.0), _solver(vo, ctx, fp, 200.0)
+            jj = j.copy()
+            for _ in range(k):
+                s.oneRound(jj, False)
+            t.solve(j, False, k)
+            if what == "getter":
+                assert s.numInliers() == t.numInliers()
+            elif what == "edit":
+                idx = np.arange(700, 720)
+                jj[idx, 1] = jj[idx + 900, 1]
+            elif what == "points":
+                for x in (s, t):
+                    assert x.lib.vo_picp_set_points(x.h, model2.ctypes.data_as(C.c_void_p), len(model2),
+                                                    fp["cur_pts"].ctypes.data_as(C.c_void_p), len(fp["cur_pts"])) == 0
+            elif what == "threshold":
+                s.setKernelThreshold(20.0); t.setKernelThreshold(20.0)
+            else:
+                s.solve(jj, False, 3); t.solve(jj, False, 3)
+            for _ in range(5):
+                s.oneRound(jj, False)
+            t.solve(jj, False, 5)
+            assert _state(s) == _state(t), (k, what)
+            s.close(); t.close()
+    # VO_PICP_RUN_AHEAD=0 in the environment is read when a handle is made: one round per call, same bits
+    import os
+    os.environ["VO_PICP_RUN_AHEAD"] = "0"
+    try:
+        u = _solver(vo, ctx, fp, 200.0)
+    finally:
+        os.environ.pop("VO_PICP_RUN_AHEAD", None)
+    w = _solver(vo, ctx, fp, 200.0)
+    for _ in range(11):
+        u.oneRound(j, False); w.oneRound(j, False)
+    assert _state(u) == _state(w)
+    u.close(); w.close()

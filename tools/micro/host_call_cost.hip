@@ -82,7 +82,28 @@ int main(int argc, char** argv) {
       launch_cmp += us(t0, t1);
     }
   }
-  std::printf("\"launch_us\": %.3f, \"launch_plus_compare_us\": %.3f}\n", launch / 5000, launch_cmp / 5000);
+  std::printf("\"launch_us\": %.3f, \"launch_plus_compare_us\": %.3f", launch / 5000, launch_cmp / 5000);
+  // one hipGraphLaunch of a captured run of k such kernels (what enqueueing k rounds ahead of the caller would cost per call)
+  for (int k : {1, 2, 4, 8}) {
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) break;
+    for (int i = 0; i < k; ++i) hipLaunchKernelGGL(probe_kernel, dim3(196), dim3(256), 0, st, (const void*)d, (void*)d, d, (size_t)50000, d, i, 196);
+    if (hipStreamEndCapture(st, &g) != hipSuccess || hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) break;
+    double t = 0;
+    for (int w = 0; w < 3; ++w) {
+      t = 0;
+      for (int burst = 0; burst < 100; ++burst) {
+        auto t0 = clk::now();
+        for (int i = 0; i < 50 / k + 1; ++i) (void)hipGraphLaunch(ge, st);
+        auto t1 = clk::now();
+        (void)hipStreamSynchronize(st);
+        t += us(t0, t1) / (50 / k + 1);
+      }
+    }
+    std::printf(", \"graph_of_%d_launch_us\": %.3f", k, t / 100);
+    (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
+  }
+  std::printf("}\n");
   (void)hipFree(d);
   return sink < 0;
 }

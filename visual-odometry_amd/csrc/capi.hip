@@ -180,6 +180,19 @@ struct vo_picp {
   // launch per call and leaves the finishing launch to whoever needs the state next (a getter, a setter, a multi-round
   // solve): picp_flush.  0 = the state is complete.
   int chain_len = 0;
+  // Rounds enqueued BEYOND chain_len: once a caller has shown the reference's pattern -- oneRound after oneRound on one
+  // unchanged vector -- a call enqueues its own round and up to run_ahead more as ONE graph launch (a hipGraphLaunch of 1..8
+  // kernels costs the host 5.5-5.9 us whatever their number, a plain launch 3.0: tools/micro/host_call_cost.hip), and the next
+  // calls find their round already in the stream: they only compare.  Round a writes slot a % PICP_SLOTS of the partial rows
+  // and of the pose.  The call that enqueues rounds k .. k + run_ahead may still find its OWN comparison differing and must then
+  // repeat round k from slot (k - 1) % PICP_SLOTS: so 1 + run_ahead <= PICP_SLOTS - 1 -- the rounds it enqueued never write the
+  // slot of the last counted round; later calls, a getter's finishing launch, or a repeat on other pairs / points / parameters
+  // read the slot of a round that was claimed, which nothing enqueued after it has written.  Whatever ran ahead and is not
+  // claimed by a matching call is overwritten or ignored.  At most run_ahead rounds of GPU time are spent for nothing when
+  // the loop ends.
+  int ahead = 0;
+  int streak = 0;                // consecutive one_round calls that matched their speculation
+  int run_ahead = PICP_SLOTS - 2;   // VO_PICP_RUN_AHEAD (0: every call enqueues exactly its own round; at most PICP_SLOTS - 2)
   unsigned long long spec_rounds = 0, spec_redone = 0;   // one_round calls enqueued before their comparison / found different
   int use_graph = 1;
   int graph_failures = 0;     // captures that failed (the handle then stays on plain launches): vo_picp_graph_info
@@ -191,15 +204,21 @@ static int set_device(vo_ctx* ctx) {
   return VO_OK;
 }
 
+// the `it` argument of round a >= 1 of an open chain (and of the finishing launch after a rounds): only its residue modulo
+// PICP_SLOTS matters to the kernels (which slot they read and write), so a chain of any length cycles through 1 .. PICP_SLOTS
+static int chain_it(int a) { return a <= 0 ? 0 : ((a - 1) % PICP_SLOTS) + 1; }
+
 // the finishing launch of the rounds vo_picp_one_round has enqueued so far (vo_picp::chain_len), if any
 static int picp_flush(vo_picp* s) {
-  if (s->chain_len == 0) return VO_OK;
+  if (s->chain_len == 0) { s->ahead = 0; return VO_OK; }
   vo_ctx* c = s->ctx;
   if (c->capturing)
     return fail(VO_ERR_NOT_READY, "vo_picp: rounds of vo_picp_one_round are still open (read the pose or the statistics once before the capture)");
   PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
-  VO_HIP_CHECK(launch_picp_finish(c->stream, s->d_params, s->d_state, pk, s->partials.as<float>(), s->grid, s->chain_len));
+  // (rounds that ran ahead of the caller sit in front of this launch in the stream; they wrote other slots than the one it reads)
+  VO_HIP_CHECK(launch_picp_finish(c->stream, s->d_params, s->d_state, pk, s->partials.as<float>(), s->grid, chain_it(s->chain_len)));
   s->chain_len = 0;
+  s->ahead = 0;
   return VO_OK;
 }
 
@@ -493,6 +512,7 @@ int vo_picp_create(vo_ctx* c, vo_picp** out) {
   s->hp.n_corr = 0;
   const char* g = getenv("VO_PICP_GRAPH");
   if (g) s->use_graph = atoi(g);
+  if (const char* ra = getenv("VO_PICP_RUN_AHEAD")) { const int v = atoi(ra); s->run_ahead = v < 0 ? 0 : (v > PICP_SLOTS - 2 ? PICP_SLOTS - 2 : v); }
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_params), sizeof(PicpParams));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_state), sizeof(PicpState));
   if (e == hipSuccess) e = hipMemsetAsync(s->d_state, 0, sizeof(PicpState), c->stream);
@@ -627,7 +647,7 @@ static int picp_prepare(vo_picp* s, const int32_t* d_pairs, int n_pairs, const i
     {
       // two buffers of round_up(grid,256) rows; rows >= grid are never written and must read as zero
       const size_t rows = ((size_t)s->grid + 255) & ~(size_t)255;
-      const size_t bytes = sizeof(float) * 2 * rows * PICP_PSTRIDE * PICP_REPLICAS;
+      const size_t bytes = sizeof(float) * PICP_SLOTS * rows * PICP_PSTRIDE * PICP_REPLICAS;
       if (bytes > s->partials.cap || s->grid != s->zeroed_for_grid) {
         VO_HIP_CHECK(s->partials.ensure(bytes, c->stream));
         VO_HIP_CHECK(hipMemsetAsync(s->partials.p, 0, s->partials.cap, c->stream));
@@ -650,20 +670,65 @@ static int picp_prepare(vo_picp* s, const int32_t* d_pairs, int n_pairs, const i
 
 static bool picp_chainable(const vo_picp* s) { return !s->exact && !s->ctx->capturing && picp_rounds_chain(s->grid); }
 
-// one round of the open chain; `count` = false: a speculative launch the caller may have to repeat (vo_picp_solve)
-static int picp_enqueue_chain_round(vo_picp* s, bool count) {
+// rounds chain_len .. chain_len + n - 1 of the open chain; `count` = false: speculative launches the caller may have to
+// repeat or will claim one by one (vo_picp_solve).  n > 1: one graph launch (captured once per starting slot and n).
+static int picp_enqueue_chain_rounds(vo_picp* s, int n, bool count) {
   vo_ctx* c = s->ctx;
   PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
-  VO_HIP_CHECK(launch_picp_chain_round(c->stream, s->d_params, s->d_state, pk, s->partials.as<float>(), s->grid, s->chain_len,
-                                       is_pinhole(s->hp.cam.K), s->hp.keep_outliers != 0));
-  if (count) ++s->chain_len;
-  return VO_OK;
+  float* partials = s->partials.as<float>();
+  const bool pinhole = is_pinhole(s->hp.cam.K), keep = s->hp.keep_outliers != 0;
+  const int first = s->chain_len;
+  bool done = false;
+  if (n > 1 && s->use_graph && first > 0) {
+    auto key = std::make_tuple(-(8 * n + chain_it(first)), s->grid, (const void*)pk.base, pk.cap, (const void*)partials,
+                               (pinhole ? 1 : 0) | (keep ? 2 : 0));
+    auto it = s->graphs.find(key);
+    if (it == s->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        hipError_t el = hipSuccess;
+        for (int k = 0; k < n && el == hipSuccess; ++k)
+          el = launch_picp_chain_round(c->stream, s->d_params, s->d_state, pk, partials, s->grid, chain_it(first + k), pinhole, keep);
+        e = hipStreamEndCapture(c->stream, &graph);
+        if (e == hipSuccess && el != hipSuccess) e = el;
+      }
+      if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (graph) (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        s->run_ahead = 0;                        // plain launches, one per call, from here on
+        ++s->graph_failures;
+        (void)fail(VO_OK, "vo_picp: graph capture of %d rounds ahead failed (%s); this solver enqueues one round per call", n, hipGetErrorString(e));
+        n = 1;
+      } else {
+        if (s->graphs.size() > 32) {
+          for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+          s->graphs.clear();
+        }
+        it = s->graphs.emplace(key, exec).first;
+      }
+    }
+    if (n > 1 && it != s->graphs.end()) {
+      VO_HIP_CHECK(hipGraphLaunch(it->second, c->stream));
+      done = true;
+    }
+  }
+  if (!done) {
+    if (!(s->use_graph && first > 0)) n = 1;     // (the first round of a chain is the kernel without the look at its predecessor)
+    for (int k = 0; k < n; ++k)
+      VO_HIP_CHECK(launch_picp_chain_round(c->stream, s->d_params, s->d_state, pk, partials, s->grid, chain_it(first + k), pinhole, keep));
+  }
+  if (count) s->chain_len += n;
+  return n;                                      // rounds enqueued (>= 1); errors return through VO_HIP_CHECK as negative codes
 }
 
 // lazy: a single round may stay open (no finishing launch) -- host entry points only, whose getters close it
 static int picp_enqueue(vo_picp* s, int n_iters, bool lazy = false) {
   vo_ctx* c = s->ctx;
-  if (lazy && n_iters == 1 && picp_chainable(s)) return picp_enqueue_chain_round(s, true);
+  s->ahead = 0;                                  // whatever ran ahead of the caller is not claimed by this call
+  if (lazy && n_iters == 1 && picp_chainable(s)) { const int r = picp_enqueue_chain_rounds(s, 1, true); return r < 0 ? r : VO_OK; }
   if (n_iters > 0) { if (int r = picp_flush(s)) return r; }
   PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
   float* partials = s->partials.as<float>();
@@ -764,13 +829,26 @@ int vo_picp_solve(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_outlie
   if (n_iters == 1 && s->packed_valid && s->shadow_valid && s->shadow.size() == words && s->have_points &&
       s->hp.keep_outliers == (keep_outliers ? 1 : 0) && !s->params_dirty && picp_chainable(s)) {
     if (int r = picp_prepare(s, s->pairs_own.as<int32_t>(), n_pairs, nullptr, keep_outliers)) return r;   // (a pending pose only)
-    if (int r = picp_enqueue_chain_round(s, false)) return r;
+    int enq = 0;                                 // rounds this call put into the stream (0: its round ran ahead of it)
+    if (s->ahead == 0) {
+      // the caller has shown the loop (two calls in a row matched): this round and run_ahead more, one graph launch
+      enq = picp_enqueue_chain_rounds(s, s->streak >= 2 ? 1 + s->run_ahead : 1, false);
+      if (enq < 0) return enq;
+    }
     ++s->spec_rounds;
     // (glibc's memcmp runs this pass at the L2 bandwidth of the host core -- 3.5 us for 2 x 400 KB on the EPYC 9575F of the
     // GPU box, faster than a hand-unrolled AVX2 pass: tools/micro/host_call_cost.hip)
-    if (words == 0 || memcmp(s->shadow.data(), pairs, sizeof(int32_t) * words) == 0) { ++s->chain_len; s->set_n = n_pairs; return VO_OK; }
+    if (words == 0 || memcmp(s->shadow.data(), pairs, sizeof(int32_t) * words) == 0) {
+      ++s->chain_len;
+      if (enq > 0) s->ahead = enq - 1; else --s->ahead;
+      ++s->streak;
+      s->set_n = n_pairs;
+      return VO_OK;
+    }
     ++s->spec_redone;
   }
+  s->ahead = 0;                                  // rounds that ran ahead (if any) are not this call's: round chain_len is enqueued again below
+  s->streak = 0;
   if (int r = picp_take_pairs(s, pairs, n_pairs)) return r;
   // pairs_own / shadow now hold THIS array: a later vo_picp_rounds continues on it (not on a stale count from an earlier
   // vo_picp_set_correspondences, which would re-pack a mix of both arrays once set_points invalidated the packing)
@@ -1022,7 +1100,7 @@ static int picp_batch_prepare(vo_ctx* c, int n_problems, int rows, int cols, int
     // problem as a grid dimension) instead of one workgroup per problem
     a.grid = picp_grid_for((int)a.cap, c->n_cu);
     const size_t rows = ((size_t)a.grid + 255) & ~(size_t)255;
-    const size_t part_bytes = sizeof(float) * 2 * rows * PICP_PSTRIDE * PICP_REPLICAS * (size_t)n_problems;
+    const size_t part_bytes = sizeof(float) * PICP_SLOTS * rows * PICP_PSTRIDE * PICP_REPLICAS * (size_t)n_problems;
     const size_t states_cap = c->batch_states.cap;
     VO_HIP_CHECK(c->batch_states.ensure(sizeof(PicpState) * (size_t)n_problems + sizeof(PicpParams), c->stream));
     if (c->batch_states.cap != states_cap) c->batch_params_dev = nullptr;               // reallocated: nothing uploaded yet

@@ -335,12 +335,12 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
   if (PRE) {
     const int l = tid & 63;
     const int c3 = l < 3 ? 0 : (l < 6 ? 3 : (l < 9 ? 6 : 9));
-    const float* pp = S->pose[(it - 1) & 1] + c3;
+    const float* pp = S->pose[(it - 1) & (PICP_SLOTS - 1)] + c3;
     pb0 = pp[0]; pb1 = pp[1]; pb2 = pp[2];
   }
   if (PRE) {
     const int nb_pad = (nb + 255) & ~255;
-    const float* prev = partials + (size_t)(blockIdx.x % PICP_REPLICAS) * 2 * nb_pad * PICP_PSTRIDE + (size_t)((it - 1) & 1) * nb_pad * PICP_PSTRIDE;
+    const float* prev = partials + (size_t)(blockIdx.x % PICP_REPLICAS) * PICP_SLOTS * nb_pad * PICP_PSTRIDE + (size_t)((it - 1) & (PICP_SLOTS - 1)) * nb_pad * PICP_PSTRIDE;
     const float4* src = reinterpret_cast<const float4*>(prev + (size_t)(tid >> 3) * PICP_PSTRIDE) + (tid & 7);
     constexpr int NJ = 256 / PICP_GROUPS;              // loads per thread and pass of 256 rows
     for (int b0 = 0; b0 < nb; b0 += 256) {
@@ -424,7 +424,7 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     {
       const Pose Tn = picp_tail_direct(val, pb0, pb1, pb2);
       if (tid == 0 && blockIdx.x == 0) {
-        store_pose12(S->pose[FINISH ? 0 : (it & 1)], Tn);
+        store_pose12(S->pose[FINISH ? 0 : (it & (PICP_SLOTS - 1))], Tn);
         if (FINISH) {
           float T16[16];
           pose_to_T16(Tn, T16);
@@ -471,7 +471,7 @@ __device__ __forceinline__ void picp_round_body(const PicpParams* __restrict__ P
     if (tid >= NACC) o = 0.f;
 #pragma unroll
     for (int r = 0; r < PICP_REPLICAS; ++r)
-      partials[(size_t)r * 2 * ((nb + 255) & ~255) * PICP_PSTRIDE + ((size_t)(it & 1) * ((nb + 255) & ~255) + blockIdx.x) * PICP_PSTRIDE + tid] = o;
+      partials[(size_t)r * PICP_SLOTS * ((nb + 255) & ~255) * PICP_PSTRIDE + ((size_t)(it & (PICP_SLOTS - 1)) * ((nb + 255) & ~255) + blockIdx.x) * PICP_PSTRIDE + tid] = o;
   }
   VO_STAMP(6);
 }
@@ -1052,7 +1052,7 @@ static hipError_t launch_picp_exact_batch(hipStream_t st, const BatchArgs& b) {
 template <bool PINHOLE, bool KEEP>
 static void launch_rounds_batch_t(hipStream_t st, const BatchArgs& a) {
   const size_t rows = ((size_t)a.grid + 255) & ~(size_t)255;
-  const RoundBatch rb{a.n_pairs, a.cap, 2 * rows * PICP_PSTRIDE * PICP_REPLICAS, a.T_out, a.stats_out};
+  const RoundBatch rb{a.n_pairs, a.cap, PICP_SLOTS * rows * PICP_PSTRIDE * PICP_REPLICAS, a.T_out, a.stats_out};
   const PackedCorr pk{a.packed, a.cap};
   const dim3 g(a.grid, a.n_problems), b(PICP_BLOCK);
   if (a.n_iters <= 0) {       // no round: the starting poses are the result

@@ -30,6 +30,13 @@ constexpr int PICP_MAX_BLOCKS = 2048; // grid cap (grid-stride beyond it)
 // copies (a writer stores its row twice, a reader takes copy blockIdx.x % 2) the round of the 50k headline takes 4.48-4.50
 // instead of 4.57-4.58 us; four copies 4.50, eight 4.55 (the stores), three 4.63 (the modulo).
 constexpr int PICP_REPLICAS = VO_PICP_REPLICAS;
+// Slots of the round-to-round hand-off (workgroup partial rows, pose): round `it` reads slot (it - 1) % PICP_SLOTS and writes
+// slot it % PICP_SLOTS.  Two would do for rounds enqueued one at a time; more let vo_picp_one_round enqueue up to PICP_SLOTS - 2
+// rounds AHEAD of its caller (capi.hip) without touching the slot of the last counted round.
+#ifndef VO_PICP_SLOTS
+#define VO_PICP_SLOTS 8
+#endif
+constexpr int PICP_SLOTS = VO_PICP_SLOTS;     // a power of two
 constexpr int PICP_BATCH_BLOCK = 768;   // 12 waves: 3 per SIMD, 168 VGPRs each (room for load double-buffering)
 constexpr int PICP_BATCH_LDS_TRIPS = 2;   // trips of the batched solver held in LDS across rounds (2 x 60 KiB)
 
@@ -45,7 +52,7 @@ struct PicpParams {
 
 // Solver state in device memory.
 struct PicpState {
-  float pose[2][12];   // double buffer: R (col-major 3x3) then t
+  float pose[PICP_SLOTS][12];   // ring (slot = round % PICP_SLOTS; slot 0 also holds the finished pose): R (col-major 3x3) then t
   float H[36];         // last round, damping included (col-major)
   float b[6];
   float chi_in, chi_out;
@@ -73,7 +80,7 @@ hipError_t launch_picp_pack(hipStream_t st, const int32_t* d_pairs, const int* d
                             PackedCorr pk, PicpParams* d_params, PicpState* d_state, const float* d_T0);
 
 // Enqueue n_iters Gauss-Newton rounds (n_iters+1 launches).  d_partials holds
-// 2 * round_up(grid,256) * PICP_PSTRIDE floats, zero-initialised.
+// PICP_REPLICAS * PICP_SLOTS * round_up(grid,256) * PICP_PSTRIDE floats, zero-initialised.
 hipError_t launch_picp_rounds(hipStream_t st, const PicpParams* d_params, PicpState* d_state,
                               PackedCorr pk, float* d_partials, int grid, int n_iters, bool pinhole,
                               bool keep_outliers);
