@@ -1295,9 +1295,12 @@ int vo_match_appearances_batch_dev(vo_ctx* c, int n_frames, const float* d_a1, i
   VO_HIP_CHECK(c->best.ensure(sizeof(unsigned long long) * (size_t)(q ? q : 1) * (size_t)n_frames, c->stream));
   const int nt = cap1 > cap2 ? cap1 : cap2;
   bool skipped = false;
-  const int variant = match_hint_before(c, d_n1 ? ragged_variant(c, nt, q, n_frames) : match_variant(c, nt, q, n_frames), &skipped);
+  const int variant_rule = d_n1 ? ragged_variant(c, nt, q, n_frames) : match_variant(c, nt, q, n_frames);
+  const int variant = match_hint_before(c, variant_rule, &skipped);
+  // (sized for what the rule picks, also while the steering leaves the pass out: the call that brings it back must not have to
+  // grow the workspace -- a device allocation of gigabytes and a synchronisation in the middle of a run)
   void* ws = nullptr;
-  if (q > 0) if (int r = match_workspace(c, variant, nt, d_n1 ? nt : q, n_frames, &ws)) return r;
+  if (q > 0) if (int r = match_workspace(c, variant_rule, nt, d_n1 ? nt : q, n_frames, &ws)) return r;
   VO_HIP_CHECK(launch_match_batch(c->stream, d_a1, cap1, 10 * (size_t)cap1, d_a2, cap2, 10 * (size_t)cap2, radius, d_out_pairs,
                                   (size_t)q, d_n_out, c->best.as<unsigned long long>(), c->scratch.as<int>(), c->n_cu, ws, n_frames,
                                   variant | match_auto_flag(c), d_n1, d_n2));
@@ -1339,9 +1342,10 @@ static int frames_batch(vo_ctx* c, const vo_frame_batch* b, const vo_frame_sizes
   // ragged frames (sz): the counts of the struct are capacities (= strides), frame f holds sz->n_ref[f] / n_cur[f] points and
   // n_model_pairs[f] model pairs; the matcher (full scan or cell-hash search) picks every frame's roles itself (vo_complete.cpp:15-20)
   bool skipped = false;
-  const int variant = match_hint_before(c, sz ? ragged_variant(c, nt, q, F) : match_variant(c, nt, q, F), &skipped);
-  void* ws = nullptr;
-  if (int r = match_workspace(c, variant, nt, sz ? nt : q, F, &ws)) return r;
+  const int variant_rule = sz ? ragged_variant(c, nt, q, F) : match_variant(c, nt, q, F);
+  const int variant = match_hint_before(c, variant_rule, &skipped);
+  void* ws = nullptr;                                     // (sized for the rule's pick: see vo_match_appearances_batch_dev)
+  if (int r = match_workspace(c, variant_rule, nt, sz ? nt : q, F, &ws)) return r;
   int* n_match = b->counts;
   int* n_join = b->counts + F;
   int* n_tri = b->counts + 2 * (size_t)F;
