@@ -78,7 +78,7 @@ class DeviceSequence {
     if (ran_) throw Error(VO_ERR_INVALID_ARG, "DeviceSequence: setKeepMap after run()");
     if (on && !map_) {
       const size_t cap = capacity ? capacity : std::min(off_.back(), 8 * cap_);
-      check(vo_map_create(ctx_, (int)std::min<size_t>(cap, 0x3fffffff), &map_), "vo_map_create");
+      check(vo_map_create(ctx_, (int)std::min<size_t>(cap, (size_t)1 << 29), &map_), "vo_map_create");
     }
     keep_map_ = on;
   }

@@ -229,3 +229,71 @@ def test_handles_that_outlive_their_context(vo, o32):
     s2.solve(j, False, 5)
     assert np.array_equal(s2.camera().worldInCameraPose(), T)
     s2.close(); c2.close()
+
+
+def test_map_and_device_initialisation_refuse_bad_arguments(vo, o32):
+    """round 5's entry points: nulls, negative counts, misaligned device rows, a map that outlives its context, a map
+    asked to grow inside a graph capture, fewer than eight pairs / wild pair indices for vo_estimate_transform_dev"""
+    c = vo.Context(0)
+    lib = c.lib
+    I, NUL = C.c_int, C.c_void_p(0)
+    h = C.c_void_p()
+    assert lib.vo_map_create(NUL, I(0), C.byref(h)) < 0 and lib.vo_map_create(c.h, I(-1), C.byref(h)) < 0
+    assert lib.vo_map_create(c.h, I((1 << 29) + 1), C.byref(h)) < 0 and lib.vo_map_create(c.h, I(0), NUL) < 0
+    m = vo.Map(c, capacity=1024)
+    rng = np.random.default_rng(3)
+    pts = rng.normal(0, 1, (600, 3)).astype(np.float32); app = rng.uniform(-1, 1, (600, 10)).astype(np.float32)
+    d_p, d_a = c.to_device(pts), c.to_device(app)
+    assert lib.vo_map_update_dev(NUL, C.c_void_p(d_p), C.c_void_p(d_a), I(600), NUL, NUL) < 0
+    assert lib.vo_map_update_dev(m.h, NUL, C.c_void_p(d_a), I(600), NUL, NUL) < 0
+    assert lib.vo_map_update_dev(m.h, C.c_void_p(d_p), NUL, I(600), NUL, NUL) < 0
+    assert lib.vo_map_update_dev(m.h, C.c_void_p(d_p), C.c_void_p(d_a), I(-5), NUL, NUL) < 0
+    assert lib.vo_map_update_dev(m.h, C.c_void_p(d_p), C.c_void_p(d_a + 4), I(599), NUL, NUL) < 0        # rows off the 8-byte boundary
+    assert lib.vo_map_update(m.h, NUL, _p(app), I(600), NUL) < 0 and lib.vo_map_update(m.h, _p(pts), _p(app), I(-1), NUL) < 0
+    assert lib.vo_map_history_reset_dev(m.h, NUL) < 0 and lib.vo_map_history_step_dev(m.h, NUL) < 0 and lib.vo_map_size(m.h, NUL) < 0
+    assert lib.vo_map_update_dev(m.h, C.c_void_p(d_p), C.c_void_p(d_a), I(0), NUL, NUL) == 0 and len(m) == 0   # an empty cloud is fine
+    m.update(pts, app)
+    assert len(m) == 600
+    # inside a graph capture the map may be updated while it has room, and refuses to grow
+    assert lib.vo_ctx_begin_capture(c.h) == 0
+    try:
+        assert lib.vo_map_update_dev(m.h, C.c_void_p(d_p), C.c_void_p(d_a), I(400), NUL, NUL) == 0      # 600 + 400 <= 1024 by the host's bound
+        assert lib.vo_map_update_dev(m.h, C.c_void_p(d_p), C.c_void_p(d_a), I(600), NUL, NUL) < 0       # would have to ask the device and grow
+        assert lib.vo_map_size(m.h, C.byref(I())) < 0                                                   # waits: not inside a capture
+    finally:
+        g = C.c_void_p()
+        assert lib.vo_ctx_end_capture(c.h, C.byref(g)) == 0
+    assert len(m) == 600                                     # a capture records, it does not run
+    assert lib.vo_graph_launch(g) == 0 and len(m) == 600     # the recorded update brought the first 400 rows again: all known
+    lib.vo_graph_destroy(g)
+    # vo_estimate_transform_dev
+    seq = vo.synth.sequence(seed=5, n_frames=2, n_visible=200)
+    f0, f1 = seq["frames"]
+    corr = o32.match(f0["app"], f1["app"])
+    K = np.ascontiguousarray(np.asarray(seq["K"], np.float32).T); X = np.zeros(16, np.float32)
+    d_c, d_0, d_1 = c.to_device(corr), c.to_device(f0["pts"]), c.to_device(f1["pts"])
+    ok = [c.h, _p(K), C.c_void_p(d_c), I(len(corr)), NUL, C.c_void_p(d_0), I(len(f0["pts"])), C.c_void_p(d_1), I(len(f1["pts"])), _p(X)]
+    assert lib.vo_estimate_transform_dev(*ok) == 0 and np.isfinite(X).all()
+    for k in (0, 1, 2, 5, 7, 9):
+        a = list(ok); a[k] = NUL
+        assert lib.vo_estimate_transform_dev(*a) < 0, k
+    for k, v in ((3, 7), (3, -1), (6, 0), (8, -3)):
+        a = list(ok); a[k] = I(v)
+        assert lib.vo_estimate_transform_dev(*a) == -1, (k, v)
+    d_few = c.to_device(np.array([5], np.int32))            # the device-side count says five pairs: refused after the read-back
+    a = list(ok); a[4] = C.c_void_p(d_few)
+    assert lib.vo_estimate_transform_dev(*a) == -1
+    bad = corr.copy(); bad[3, 1] = 10 ** 6
+    c.h2d(d_c, bad)
+    assert lib.vo_estimate_transform_dev(*ok) == -5 and b"outside" in lib.vo_last_error()
+    # a map that outlives its context fails cleanly and can still be destroyed
+    h_ctx = c.h
+    for d in (d_p, d_a, d_c, d_0, d_1, d_few):
+        c.free(d)
+    assert lib.vo_ctx_destroy(h_ctx) == 0
+    c.h = None
+    with pytest.raises(vo.VoError):
+        m.update(pts, app)
+    with pytest.raises(vo.VoError):
+        len(m)
+    m.close()

@@ -1630,9 +1630,10 @@ struct vo_map {
   DevBuf up_xyz, up_app;        // staging of vo_map_update
 };
 
+constexpr int MAP_MAX_ENTRIES = 1 << 29;      // 2.5 x that many table slots still fit 32 bits
 static unsigned map_tcap_for(int cap) {
   unsigned t = 1024;
-  while (t < 2u * (unsigned)cap + 2u * ((unsigned)cap >> 2)) t <<= 1;      // at most 40 % full
+  while (t < 2u * (unsigned)cap + 2u * ((unsigned)cap >> 2)) t <<= 1;      // at most 40 % full (cap <= MAP_MAX_ENTRIES: t <= 2^31)
   return t;
 }
 
@@ -1666,7 +1667,8 @@ static int map_reserve(vo_map* m, int n) {
   if ((long long)size + n <= m->d.cap) return VO_OK;
   long long want = 2ll * m->d.cap;
   if (want < (long long)size + n) want = (long long)size + n + ((long long)size + n) / 2;
-  if (want > 0x3fffffffll) return fail(VO_ERR_INVALID_ARG, "vo_map: more than 2^30 entries");
+  if ((long long)size + n > MAP_MAX_ENTRIES) return fail(VO_ERR_INVALID_ARG, "vo_map: more than 2^29 entries");
+  if (want > MAP_MAX_ENTRIES) want = MAP_MAX_ENTRIES;
   MapDev old = m->d;
   MapDev nd = old;
   nd.pts = nd.app = nullptr; nd.table = nullptr; nd.last = nullptr;
@@ -1688,7 +1690,7 @@ static int map_reserve(vo_map* m, int n) {
 int vo_map_create(vo_ctx* c, int capacity, vo_map** out) {
   VO_REQUIRE(c && out, "null argument");
   VO_NOT_CAPTURING(c);
-  VO_REQUIRE(capacity >= 0 && capacity <= 0x3fffffff, "bad capacity");
+  VO_REQUIRE(capacity >= 0 && capacity <= MAP_MAX_ENTRIES, "bad capacity (at most 2^29 entries)");
   *out = nullptr;
   if (int r = set_device(c)) return r;
   vo_map* m = new vo_map();
@@ -1735,7 +1737,7 @@ int vo_map_clear(vo_map* m) {
 
 int vo_map_update_dev(vo_map* m, const float* d_xyz, const float* d_app, int n_max, const int* d_n, const float* d_T16) {
   VO_MAP_LIVE(m);
-  VO_REQUIRE(n_max >= 0 && (n_max == 0 || (d_xyz && d_app)), "bad cloud");
+  VO_REQUIRE(n_max >= 0 && n_max <= MAP_MAX_ENTRIES && (n_max == 0 || (d_xyz && d_app)), "bad cloud");
   VO_REQUIRE(aligned8(d_app), "device appearance rows must be 8-byte aligned");
   if (n_max == 0) return VO_OK;
   vo_ctx* c = m->ctx;
