@@ -5,8 +5,9 @@
 // on vo::PICPSolver (include/vo/picp_solver.hpp -> vo_picp_one_round), at the size of BASELINE configs[1].
 //   usage: one_round_rate [points=50000] [rounds=50] [steps=200] [warmup=20] [seed=2000]
 // Prints one JSON object: iterations/s of the loop with the pose reset per step (`loop`) and with a full init() per
-// step as the reference's frame loop does (`with_init`), the host time per oneRound call (the calls alone, before
-// anything waits), and what the closed entry point (solve: one call, all rounds) does on the same pair.
+// step as the reference's frame loop does (`with_init`; `with_init_varying_sizes`: the vector's length changes from frame to
+// frame), the host time per oneRound call (the calls alone, before anything waits), and what the closed entry point
+// (solve: one call, all rounds) does on the same pair.
 // exit code 0 iff every step's pose is the generator's motion (1e-3) with all correspondences inliers.
 #include <chrono>
 #include <cmath>
@@ -130,16 +131,41 @@ int main(int argc, char** argv) {
     const double rounds_us = us(t0, t1);
     verify("rounds_call");
 
+    // (5) the reference's frame loop on frames of DIFFERENT sizes: init(), the rounds on a vector whose length changes from
+    // frame to frame (n - 0..10 %), camera() -- what the launch bookkeeping costs when no two frames share a launch geometry
+    std::vector<IntPairVector> sized;
+    for (int k = 0; k < 37; ++k) sized.emplace_back(corr.begin(), corr.begin() + (n - (int)((long long)n * k / 370)));
+    int fk = 0;
+    auto varied_step = [&] {
+      const IntPairVector& c = sized[(size_t)(fk++ % 37)];
+      solver.init(cam, model, meas);
+      for (int i = 0; i < rounds; ++i) solver.oneRound(c, false);
+      (void)solver.camera();
+    };
+    for (int s = 0; s < warmup; ++s) varied_step();
+    t0 = clk::now();
+    for (int s = 0; s < steps; ++s) varied_step();
+    t1 = clk::now();
+    const double varied_us = us(t0, t1);
+    {
+      const Isometry3f& X = solver.camera().worldInCameraPose();
+      float err = 0.f;
+      for (int i = 0; i < 16; ++i) err = std::fmax(err, std::fabs(X.m[i] - X_gt.m[i]));
+      if (!(err < 1e-3f)) { std::fprintf(stderr, "varied: pose error %g\n", err); ok = false; }
+    }
+
     const double iters = (double)steps * rounds;
     std::printf("{\"points\": %d, \"rounds_per_step\": %d, \"steps\": %d, \"warmup\": %d, "
                 "\"loop\": {\"iters_per_sec\": %.1f, \"us_per_round\": %.3f, \"host_us_per_call\": %.3f, \"ms_per_step\": %.4f}, "
                 "\"with_init\": {\"iters_per_sec\": %.1f, \"us_per_round\": %.3f, \"ms_per_step\": %.4f}, "
                 "\"solve_call\": {\"iters_per_sec\": %.1f, \"us_per_round\": %.3f, \"ms_per_step\": %.4f}, "
                 "\"rounds_call\": {\"iters_per_sec\": %.1f, \"us_per_round\": %.3f, \"host_us_per_call\": %.3f}, "
+                "\"with_init_varying_sizes\": {\"iters_per_sec\": %.1f, \"us_per_round\": %.3f, \"ms_per_step\": %.4f}, "
                 "\"speculative_calls\": %llu, \"repeated_calls\": %llu, \"ok\": %s}\n",
                 n, rounds, steps, warmup, iters / loop_us * 1e6, loop_us / iters, calls_us / iters, loop_us / steps * 1e-3,
                 iters / init_us * 1e6, init_us / iters, init_us / steps * 1e-3, iters / solve_us * 1e6, solve_us / iters,
-                solve_us / steps * 1e-3, iters / rounds_us * 1e6, rounds_us / iters, rcalls_us / iters, spec, redone, ok ? "true" : "false");
+                solve_us / steps * 1e-3, iters / rounds_us * 1e6, rounds_us / iters, rcalls_us / iters,
+                iters / varied_us * 1e6, varied_us / iters, varied_us / steps * 1e-3, spec, redone, ok ? "true" : "false");
     return ok ? 0 : 1;
   } catch (const vo::Error& e) {
     std::fprintf(stderr, "one_round_rate: %s\n", e.what());

@@ -150,11 +150,13 @@ int vo_picp_get_kernel_threshold(vo_picp *s, float *thr);       /* picp_solver.h
  * packed one the round is enqueued first and the comparison runs while the GPU
  * works; a difference then repeats that round on the new pairs (it had written
  * nothing a repeat does not overwrite).  Once two calls in a row have matched --
- * the reference's loop -- a call enqueues its round and up to six more as ONE
- * graph launch, and the calls that follow only compare and claim theirs; rounds
+ * the reference's loop -- a call enqueues its round and up to seven more as ONE
+ * graph launch (captured the third time a launch geometry asks for it; the last
+ * window of a run is cut to the remembered length of the previous run), and the
+ * calls that follow only compare and claim theirs; rounds
  * that ran ahead and are not claimed (the loop ended, the pairs / points /
  * parameters changed) are ignored or repeated, never seen: every result is the
- * one a closed solve of the counted rounds gives.  VO_PICP_RUN_AHEAD=0..6 in the
+ * one a closed solve of the counted rounds gives.  VO_PICP_RUN_AHEAD=0..14 in the
  * environment (read by vo_picp_create) bounds the look-ahead; at most that many
  * rounds of GPU time are spent for nothing per loop.  As in the reference it cannot fail on
  * "too few inliers" (min_num_inliers is 0 with no setter). */

@@ -175,16 +175,25 @@ def test_small_and_empty_problems_keep_their_one_launch_forms(vo, ctx, o32):
 
 
 def test_rounds_enqueued_ahead_of_the_caller_are_claimed_repeated_or_ignored(vo, ctx, o32):
-    """Once two calls in a row have matched, a call enqueues its round and up to six more as one graph launch (capi.hip:
-    run_ahead); the following calls claim theirs after comparing.  Whatever interrupts the loop at whatever position of that
-    window -- a getter, an in-place edit, other points, another threshold, a closed solve -- must leave the bits of closed solves
-    on the same arrays: rounds that ran ahead unclaimed are repeated on the new data or ignored."""
+    """Once two calls in a row have matched, a call enqueues its round and up to seven more as one graph launch (capi.hip:
+    run_ahead; the graph is captured the third time its launch geometry asks for it); the following calls claim theirs after
+    comparing.  Whatever interrupts the loop at whatever position of that window -- a getter, an in-place edit, other points,
+    another threshold, a closed solve -- must leave the bits of closed solves on the same arrays: rounds that ran ahead
+    unclaimed are repeated on the new data or ignored.  ONE pair of handles goes through all of it (the graphs, the remembered
+    loop length and the streak are the handle's), the twin only ever through closed solves."""
     fp, j = _problem(vo, o32, n=5000, seed=36)
-    model2 = (fp["model"] + np.float32(0.02)).astype(np.float32)
+    model = [fp["model"], (fp["model"] + np.float32(0.02)).astype(np.float32)]
     C = vo.api.C
-    for k in range(2, 13):                          # the interruption after k calls: every position of the window at least once
+    s, t = _solver(vo, ctx, fp, 200.0), _solver(vo, ctx, fp, 200.0)
+    for _ in range(5):                              # the loop shows itself, its windows get their graphs
+        for _ in range(20):
+            s.oneRound(j, False)
+        t.solve(j, False, 20)
+        assert _state(s) == _state(t)
+    assert s.graphInfo()[1] >= 2 and s.graphInfo()[2] == 0          # windows are graph launches now (vo_picp_graph_info)
+    which, thr = 0, 200.0
+    for k in range(2, 21):                          # the interruption after k calls: every position of a window, twice over
         for what in ("getter", "edit", "points", "threshold", "solve"):
-            s, t = _solver(vo, ctx, fp, 200.0), _solver(vo, ctx, fp, 200.0)
             jj = j.copy()
             for _ in range(k):
                 s.oneRound(jj, False)
@@ -195,18 +204,21 @@ def test_rounds_enqueued_ahead_of_the_caller_are_claimed_repeated_or_ignored(vo,
                 idx = np.arange(700, 720)
                 jj[idx, 1] = jj[idx + 900, 1]
             elif what == "points":
+                which ^= 1
                 for x in (s, t):
-                    assert x.lib.vo_picp_set_points(x.h, model2.ctypes.data_as(C.c_void_p), len(model2),
+                    assert x.lib.vo_picp_set_points(x.h, model[which].ctypes.data_as(C.c_void_p), len(model[which]),
                                                     fp["cur_pts"].ctypes.data_as(C.c_void_p), len(fp["cur_pts"])) == 0
             elif what == "threshold":
-                s.setKernelThreshold(20.0); t.setKernelThreshold(20.0)
+                thr = 20.0 if thr == 200.0 else 200.0
+                s.setKernelThreshold(thr); t.setKernelThreshold(thr)
             else:
                 s.solve(jj, False, 3); t.solve(jj, False, 3)
-            for _ in range(5):
+            for _ in range(9):
                 s.oneRound(jj, False)
-            t.solve(jj, False, 5)
+            t.solve(jj, False, 9)
             assert _state(s) == _state(t), (k, what)
-            s.close(); t.close()
+    assert s.chainInfo()[2] >= 19                   # the edits were found by the comparison and their rounds repeated
+    s.close(); t.close()
     # VO_PICP_RUN_AHEAD=0 in the environment is read when a handle is made: one round per call, same bits
     import os
     os.environ["VO_PICP_RUN_AHEAD"] = "0"
@@ -215,7 +227,9 @@ def test_rounds_enqueued_ahead_of_the_caller_are_claimed_repeated_or_ignored(vo,
     finally:
         os.environ.pop("VO_PICP_RUN_AHEAD", None)
     w = _solver(vo, ctx, fp, 200.0)
-    for _ in range(11):
-        u.oneRound(j, False); w.oneRound(j, False)
-    assert _state(u) == _state(w)
+    for _ in range(4):
+        for _ in range(19):
+            u.oneRound(j, False); w.oneRound(j, False)
+        assert _state(u) == _state(w)
+    assert u.graphInfo()[1] == 0 and w.graphInfo()[1] >= 1
     u.close(); w.close()

@@ -82,8 +82,17 @@ def fuzz_chain():
     cur = j.copy()
     keep = False
     ok = True
-    for _ in range(int(rng.integers(3, 25))):
-        op = int(rng.integers(0, 10))
+    if rng.integers(0, 2):                            # the loop shows itself first: windows of rounds ahead of the caller get their
+        for _ in range(4):                            # graphs (captured the third time a geometry asks), the loop length is remembered
+            k = int(rng.integers(9, 20))
+            for _ in range(k):
+                s.oneRound(cur, keep)
+            t.solve(cur, keep, k)
+            ok = ok and state(s) == state(t)
+    for _ in range(int(rng.integers(3, 40))):
+        op = int(rng.integers(0, 14))
+        if op >= 10:
+            op = 0                                    # (half of the steps are the loop's own call)
         if op <= 3:                                   # the loop's call, on whatever the array holds now
             s.oneRound(cur, keep)
             t.solve(cur, keep, 1); t.numInliers()      # the twin closes every round

@@ -192,7 +192,16 @@ struct vo_picp {
   // the loop ends.
   int ahead = 0;
   int streak = 0;                // consecutive one_round calls that matched their speculation
-  int run_ahead = PICP_SLOTS - 2;   // VO_PICP_RUN_AHEAD (0: every call enqueues exactly its own round; at most PICP_SLOTS - 2)
+  int loop_hint = 0;             // rounds the previous run of calls had when a getter closed it: the reference's loop has a fixed
+                                 // count (vo_complete.cpp:163: 100), so the last window of a run is cut to what is left of it and
+                                 // nothing runs ahead for nothing; a longer run than last time simply goes on in full windows
+  int run_ahead = PICP_SLOTS / 2 - 1;   // VO_PICP_RUN_AHEAD (0: every call enqueues exactly its own round; at most PICP_SLOTS - 2).
+                                        // Windows of PICP_SLOTS / 2 rounds start at two alternating slots: two graphs per geometry.
+  // A window's graph is captured only the third time it is wanted (key -> times wanted): a caller whose correspondence count --
+  // and with it the launch geometry -- changes from frame to frame never pays a capture (~0.15 ms each), it gets one plain
+  // launch per call as before (apps/one_round_rate, with_init_varying_sizes: 54 k iterations/s with eager captures, 115-120 k
+  // without); and nothing is ever destroyed to make room: a full cache means plain launches for new keys.
+  std::map<std::tuple<int, int, const void*, size_t, const void*, int>, int> chain_wanted;
   unsigned long long spec_rounds = 0, spec_redone = 0;   // one_round calls enqueued before their comparison / found different
   int use_graph = 1;
   int graph_failures = 0;     // captures that failed (the handle then stays on plain launches): vo_picp_graph_info
@@ -217,6 +226,7 @@ static int picp_flush(vo_picp* s) {
   PackedCorr pk{s->packed.as<float>(), s->packed.cap / (5 * sizeof(float)) & ~(size_t)3};
   // (rounds that ran ahead of the caller sit in front of this launch in the stream; they wrote other slots than the one it reads)
   VO_HIP_CHECK(launch_picp_finish(c->stream, s->d_params, s->d_state, pk, s->partials.as<float>(), s->grid, chain_it(s->chain_len)));
+  s->loop_hint = s->chain_len;
   s->chain_len = 0;
   s->ahead = 0;
   return VO_OK;
@@ -680,10 +690,13 @@ static int picp_enqueue_chain_rounds(vo_picp* s, int n, bool count) {
   const int first = s->chain_len;
   bool done = false;
   if (n > 1 && s->use_graph && first > 0) {
-    auto key = std::make_tuple(-(8 * n + chain_it(first)), s->grid, (const void*)pk.base, pk.cap, (const void*)partials,
+    static_assert(PICP_SLOTS < 64, "key of a window's graph: 64 * rounds + starting slot");
+    auto key = std::make_tuple(-(64 * n + chain_it(first)), s->grid, (const void*)pk.base, pk.cap, (const void*)partials,
                                (pinhole ? 1 : 0) | (keep ? 2 : 0));
     auto it = s->graphs.find(key);
-    if (it == s->graphs.end()) {
+    if (it == s->graphs.end() && (s->graphs.size() >= 64 || (s->chain_wanted.size() < 4096 ? ++s->chain_wanted[key] : 3) < 3)) {
+      n = 1;                                     // not (yet) worth a capture: this call's own round, plainly
+    } else if (it == s->graphs.end()) {
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
       hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
@@ -703,10 +716,6 @@ static int picp_enqueue_chain_rounds(vo_picp* s, int n, bool count) {
         (void)fail(VO_OK, "vo_picp: graph capture of %d rounds ahead failed (%s); this solver enqueues one round per call", n, hipGetErrorString(e));
         n = 1;
       } else {
-        if (s->graphs.size() > 32) {
-          for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
-          s->graphs.clear();
-        }
         it = s->graphs.emplace(key, exec).first;
       }
     }
@@ -762,9 +771,11 @@ static int picp_enqueue(vo_picp* s, int n_iters, bool lazy = false) {
         (void)fail(VO_OK, "vo_picp: graph capture of %d rounds failed (%s); this solver now uses plain launches", n_iters,
                    hipGetErrorString(e));
       } else {
-        if (s->graphs.size() > 32) {
+        if (s->graphs.size() >= 64) {            // (a handle used at ever new sizes: start over -- once nothing of it is in flight)
+          (void)hipStreamSynchronize(c->stream);
           for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
           s->graphs.clear();
+          s->chain_wanted.clear();
         }
         it = s->graphs.emplace(key, exec).first;
       }
@@ -832,7 +843,9 @@ int vo_picp_solve(vo_picp* s, const int32_t* pairs, int n_pairs, int keep_outlie
     int enq = 0;                                 // rounds this call put into the stream (0: its round ran ahead of it)
     if (s->ahead == 0) {
       // the caller has shown the loop (two calls in a row matched): this round and run_ahead more, one graph launch
-      enq = picp_enqueue_chain_rounds(s, s->streak >= 2 ? 1 + s->run_ahead : 1, false);
+      int want = s->streak >= 2 ? 1 + s->run_ahead : 1;
+      if (s->loop_hint > s->chain_len && want > s->loop_hint - s->chain_len) want = s->loop_hint - s->chain_len;
+      enq = picp_enqueue_chain_rounds(s, want, false);
       if (enq < 0) return enq;
     }
     ++s->spec_rounds;

@@ -32,9 +32,10 @@ constexpr int PICP_MAX_BLOCKS = 2048; // grid cap (grid-stride beyond it)
 constexpr int PICP_REPLICAS = VO_PICP_REPLICAS;
 // Slots of the round-to-round hand-off (workgroup partial rows, pose): round `it` reads slot (it - 1) % PICP_SLOTS and writes
 // slot it % PICP_SLOTS.  Two would do for rounds enqueued one at a time; more let vo_picp_one_round enqueue up to PICP_SLOTS - 2
-// rounds AHEAD of its caller (capi.hip) without touching the slot of the last counted round.
+// rounds AHEAD of its caller (capi.hip) without touching the slot of the last counted round.  Sixteen, with windows of eight
+// rounds: consecutive windows of a loop then start at two alternating slots only, i.e. TWO launch graphs serve a loop.
 #ifndef VO_PICP_SLOTS
-#define VO_PICP_SLOTS 8
+#define VO_PICP_SLOTS 16
 #endif
 constexpr int PICP_SLOTS = VO_PICP_SLOTS;     // a power of two
 constexpr int PICP_BATCH_BLOCK = 768;   // 12 waves: 3 per SIMD, 168 VGPRs each (room for load double-buffering)
