@@ -309,3 +309,17 @@ def test_device_map_inside_the_chain_equals_the_reference_loop(vo, ctx, o32, seq
     p3, a3 = sp.map.read()
     sp.close()
     assert a3.tobytes() == app.tobytes() and np.abs(p3 - pts).max() < 5e-2
+
+
+def test_device_map_with_the_matcher_up_front_or_on_a_second_stream(vo, ctx, seq_run):
+    """keep_map together with the other ways the chain can get its matches (all pairs by one batched call first; the
+    matcher one frame ahead on a second stream): the same chain, hence the same map, entry for entry."""
+    seq, d, res0, P = seq_run
+    maps = []
+    for kw in ({}, {"prematch": True}, {"overlap_match": True}):
+        sp = vo.SequencePipeline(ctx, seq, n_iters=ROUNDS, keep_map=True, **kw)
+        sp.run()
+        p, a = sp.map.read()
+        maps.append((sp.trajectory().tobytes(), p.tobytes(), a.tobytes(), sp.map.history().tobytes()))
+        sp.close()
+    assert maps[0] == maps[1] == maps[2] and len(maps[0][1]) > 12 * 2 * N_VISIBLE
