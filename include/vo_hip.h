@@ -245,7 +245,7 @@ int vo_picp_solve_batch_dev(vo_ctx *ctx, int n_problems, int rows, int cols, int
  * 0.52 ms when every query has a copy, 0.73 at 1 % open, 0.80 at 5 %, 1.27 at 25 % (profiles/r05_bench_line.json); mode 3
  * alone 1.10; data WITHOUT any copies is noticed from eight sampled queries per frame and skips the tables and the lookup
  * (1.29 ms) -- and, in mode 0, the NEXT calls leave the pass out altogether (1.10 ms): what the previous call found travels to
- * the host behind the stream, "no frame took the pass" switches it off for 16 calls, a sample query that the search finds at
+ * the host behind the stream, "no frame took the pass" twice in a row switches it off for 16 calls, a sample query that the search finds at
  * distance 0 switches it on again at once, vo_match_set_mode() forgets what was learnt.  Partly copied data (10 - 90 % of
  * the queries without a copy) pays 0.05 - 0.2 ms for the pass -- ask for mode 3 there. */
 int vo_match_set_mode(vo_ctx *ctx, int mode);

@@ -121,6 +121,8 @@ struct vo_ctx {
   bool hint_pending = false;
   int hint_skip_left = 0;
   bool hint_of_skipped_call = false;   // what the pending answer was asked of
+  int hint_none_streak = 0;            // consecutive answers "no frame took the pass": two in a row start the skipping (a context
+                                       // that alternates between data with and without copies is then never steered wrong)
   int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan, 3 cell-hash search, 4 / 5 exact-duplicate pass first, then 2 / 3
   int batch_form = 0; // batched solver: 0 auto, 1 one launch per round, 2 one workgroup per problem
   bool capturing = false;
@@ -1174,8 +1176,13 @@ static int match_hint_before(vo_ctx* c, int variant, bool* skipped) {
   if (off || c->match_mode != 0 || variant < 4 || c->capturing) return variant;
   if (c->hint_pending && hipEventQuery(c->hint_ev) == hipSuccess) {
     c->hint_pending = false;
-    if (c->hint_of_skipped_call) { if (*c->hint_host != 0) c->hint_skip_left = 0; }      // copies are back: the pass again
-    else if (*c->hint_host == 0) c->hint_skip_left = HINT_SKIP;                           // no frame took the pass: leave it out
+    if (c->hint_of_skipped_call) {
+      if (*c->hint_host != 0) { c->hint_skip_left = 0; c->hint_none_streak = 0; }          // copies are back: the pass again
+    } else if (*c->hint_host == 0) {
+      if (++c->hint_none_streak >= 2) c->hint_skip_left = HINT_SKIP;                       // twice in a row no frame took the pass: leave it out
+    } else {
+      c->hint_none_streak = 0;
+    }
   }
   (void)hipGetLastError();                        // (hipErrorNotReady of the query is not an error of this call)
   if (c->hint_skip_left > 0) { --c->hint_skip_left; *skipped = true; return variant - 2; }      // the plain search: same pairs
@@ -1242,6 +1249,7 @@ int vo_match_set_mode(vo_ctx* c, int mode) {
                                      "4 / 5 (exact-duplicate pass, then 2 / 3)");
   c->match_mode = mode;
   c->hint_skip_left = 0;              // what the automatic mode learnt from earlier calls is forgotten
+  c->hint_none_streak = 0;
   c->hint_pending = false;
   return VO_OK;
 }
