@@ -172,17 +172,23 @@ class Map:
         self.pts, self.app, self.idx = [], [], {}
 
     def update(self, pts, app):
-        for p, a in zip(pts, app):
-            a = np.asarray(a, np.float32)
-            if np.isnan(a).any():
-                self.pts.append(p); self.app.append(a)
+        if len(pts) == 0:
+            return
+        A = np.ascontiguousarray(np.asarray(app, np.float32).reshape(-1, 10))
+        nan = np.isnan(A).any(axis=1)
+        canon = np.ascontiguousarray(A + np.float32(0.0))        # -0 -> +0: rows equal under == share their bytes
+        keys = canon.view("V40").ravel()                          # one 40-byte record per row
+        for i, p in enumerate(pts):
+            if nan[i]:
+                self.pts.append(p); self.app.append(A[i])
                 continue
-            k = (a + np.float32(0.0)).tobytes()
-            if k in self.idx:
-                self.pts[self.idx[k]] = p
+            k = keys[i].tobytes()
+            j = self.idx.get(k)
+            if j is not None:
+                self.pts[j] = p
             else:
                 self.idx[k] = len(self.pts)
-                self.pts.append(p); self.app.append(a)
+                self.pts.append(p); self.app.append(A[i])
 
 
 def literal_update(map_pts, map_app, pts, app):

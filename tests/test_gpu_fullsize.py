@@ -125,15 +125,22 @@ def test_sequence_200x50k_is_bit_identical_to_ref32(vo, ctx, o32, n_frames):
     seq = vo.synth.sequence(seed=3000, n_frames=n_frames, n_visible=N)
     n = [len(f["pts"]) for f in seq["frames"]]
     assert min(n) > 45000
-    sp = vo.SequencePipeline(ctx, seq, n_iters=100)
+    sp = vo.SequencePipeline(ctx, seq, n_iters=100, keep_map=True)      # the loop body's map upkeep inside the chain, on the device
     assert sp.lib.vo_picp_set_exact(sp.solver, 1) == 0
     sp.run()
     traj, counts = sp.trajectory(), sp.counts()
     n_in = sp.stats()[2]
+    map_pts, map_app = sp.map.read()
     sp.close()
     frames = [(f["pts"], f["app"]) for f in seq["frames"]]
     res = P.run_sequence(frames, seq["K"], seq["rows"], seq["cols"], seq["z_near"], seq["z_far"], rounds=100, o=o32,
-                         X0=traj[1], kdtree=True, keep_map=False)
+                         X0=traj[1], kdtree=True, keep_map=True)
+    # the map at the path's scale (vo_complete.cpp:145-147,175-176; PointCloud.h:52-66): ~0.8 M entries after 200 frames of ~50k
+    # points, every entry in the reference's order, points and appearance bits
+    want = res["map"]
+    assert len(map_pts) == len(want.pts) > 10 * N
+    assert map_pts.tobytes() == np.array(want.pts, np.float32).reshape(-1, 3).tobytes()
+    assert map_app.tobytes() == np.array(want.app, np.float32).reshape(-1, 10).tobytes()
     exp = np.array(res["stats"], dtype=int)
     assert np.array_equal(counts[2:, 0], exp[:, 0]) and np.array_equal(counts[2:, 1], exp[:, 1])    # matches, joins
     assert np.array_equal(counts[1:, 2], np.array(res["tri_counts"]))                              # triangulated points
