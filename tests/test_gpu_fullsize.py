@@ -135,6 +135,12 @@ def test_sequence_200x50k_is_bit_identical_to_ref32(vo, ctx, o32, n_frames):
     frames = [(f["pts"], f["app"]) for f in seq["frames"]]
     res = P.run_sequence(frames, seq["K"], seq["rows"], seq["cols"], seq["z_near"], seq["z_far"], rounds=100, o=o32,
                          X0=traj[1], kdtree=True, keep_map=True)
+    # the first relative pose at the path's scale: vo_estimate_transform_dev (sums over ~50k correspondences on the GPU, epi.hip)
+    # against the oracle's numpy restatement of epipolar_utils.cpp:103-213 on the same pair
+    f0, f1 = seq["frames"][0], seq["frames"][1]
+    corr01 = o32.match_kdtree(f0["app"], f1["app"])
+    X0_o = P.estimate_transform(o32, seq["K"], corr01, f0["pts"], f1["pts"])
+    assert len(corr01) > 40000 and np.abs(np.asarray(traj[1]) - X0_o).max() < 5e-5, np.abs(np.asarray(traj[1]) - X0_o).max()
     # the map at the path's scale (vo_complete.cpp:145-147,175-176; PointCloud.h:52-66): ~0.8 M entries after 200 frames of ~50k
     # points, every entry in the reference's order, points and appearance bits
     want = res["map"]
