@@ -214,10 +214,19 @@ int vo_picp_get_system(vo_picp *s, float H[36], float b[6]);
  * index lies outside its point arrays: they are dropped (the single-problem entry points report the same
  * condition as VO_ERR_BAD_INDEX from their getters). */
 /* Two forms, same results up to the summation order of H and b: one workgroup per problem with all rounds
- * inside one launch (many problems: HBM-bound streaming), or one launch per round with many workgroups per
- * problem (a few problems: the single-problem kernels with the problem as a grid dimension; 4x faster at 4
- * problems of 50k, equal at ~30).  form 0 (default) picks by a cost model, 1 / 2 force one. */
+ * inside one launch (many problems: streaming bound), or one launch per round with many workgroups per
+ * problem (a few problems: the single-problem kernels with the problem as a grid dimension; 2.5x faster at one
+ * problem of 50k, equal at ~10).  form 0 (default) picks by a cost model, 1 / 2 force one.
+ * With one workgroup per problem and at most 0.65 problems per CU (and >= 18 432 correspondences of capacity per problem)
+ * the launch has one workgroup per CU and the waves of those without a problem take work off the others' every round
+ * (csrc/picp.hip, picp_batch_shared_kernel: 1.9x at 32 problems of 50k, 1.1x at 128; beyond, the problems' own
+ * workgroups already draw what the memory side delivers).  The result does not depend on when, or whether, a helper
+ * wave runs; problems with the same data in one call get the same bits.  VO_PICP_SHARE=0 in the environment turns it off.
+ * vo_picp_batch_info: what the context's LAST batched call ran as -- 1 one launch per round, 2 one workgroup per problem,
+ * 3 reference-order arithmetic, 4 one workgroup per problem with helpers (0: no call yet) -- and its workgroups per
+ * launch.  Either pointer may be NULL. */
 int vo_picp_batch_set_form(vo_ctx *ctx, int form);
+int vo_picp_batch_info(vo_ctx *ctx, int *form, int *workgroups);
 int vo_picp_solve_batch_dev(vo_ctx *ctx, int n_problems, int rows, int cols, int z_near, int z_far,
                             const float K[9], float kernel_threshold, int keep_outliers,
                             const float *d_world_xyz, size_t world_stride, const float *d_meas_uv,

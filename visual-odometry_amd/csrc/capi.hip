@@ -104,6 +104,7 @@ struct vo_ctx {
   DevBuf batch_pack;  // packed correspondences of the batched solver
   DevBuf batch_bad;   // its per-problem bad-index counters
   DevBuf batch_states, batch_partials;   // launch-per-round form of the batched solver: per-problem state + partial rows
+  DevBuf batch_help;  // shared form (fewer problems than CUs): tagged words handed between workgroups
   PicpParams batch_params_host{};        //   its parameter block as last uploaded, and where
   const PicpParams* batch_params_dev = nullptr;
   DevBuf prune_ws;    // sorted copies / tables of the matcher's sorted variants
@@ -125,6 +126,7 @@ struct vo_ctx {
                                        // that alternates between data with and without copies is then never steered wrong)
   int match_mode = 0; // 0 auto, 1 full scan, 2 bucket-pruned scan, 3 cell-hash search, 4 / 5 exact-duplicate pass first, then 2 / 3
   int batch_form = 0; // batched solver: 0 auto, 1 one launch per round, 2 one workgroup per problem
+  int batch_last_form = 0, batch_last_wgs = 0;   // what the last batched call ran as (vo_picp_batch_info)
   bool capturing = false;
   unsigned long long id = 0;   // unique per context ever created: an address can be reused, an id cannot
 };
@@ -282,7 +284,7 @@ int vo_ctx_destroy(vo_ctx* c) {
   c->batch_pack.release(); c->batch_bad.release(); c->prune_ws.release(); c->epi_ws.release();
   if (c->hint_ev) (void)hipEventDestroy(c->hint_ev);
   if (c->hint_host) (void)hipHostFree(c->hint_host);
-  if (c->hint_dev) (void)hipFree(c->hint_dev); c->batch_states.release(); c->batch_partials.release();
+  if (c->hint_dev) (void)hipFree(c->hint_dev); c->batch_states.release(); c->batch_partials.release(); c->batch_help.release();
   for (auto& b : c->in) b.release();
   for (auto& b : c->out) b.release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1034,6 +1036,13 @@ int vo_picp_batch_set_form(vo_ctx* c, int form) {
   return VO_OK;
 }
 
+int vo_picp_batch_info(vo_ctx* c, int* form, int* workgroups) {
+  VO_REQUIRE(c, "ctx is null");
+  if (form) *form = c->batch_last_form;
+  if (workgroups) *workgroups = c->batch_last_wgs;
+  return VO_OK;
+}
+
 static int picp_solve_batch(vo_ctx* c, int n_problems, int rows, int cols, int z_near, int z_far,
                             const float K[9], float thr, int keep_outliers, const float* d_world,
                             size_t world_stride, const float* d_meas, size_t meas_stride,
@@ -1136,6 +1145,14 @@ static int picp_batch_prepare(vo_ctx* c, int n_problems, int rows, int cols, int
     a.partials = c->batch_partials.as<float>();
     a.params = d_params;
   }
+  picp_help_args(a, nullptr, 0);
+  if (!a.states && !a.exact && picp_batch_shares(n_problems, a.cap, n_iters, c->n_cu)) {
+    // one workgroup per problem would leave CUs without one: their waves take work off the others (picp_batch_shared_kernel)
+    VO_HIP_CHECK(c->batch_help.ensure(sizeof(unsigned long long) * picp_help_words(n_problems, c->n_cu), c->stream));
+    picp_help_args(a, c->batch_help.as<unsigned long long>(), c->n_cu);
+  }
+  c->batch_last_form = a.exact ? 3 : a.states ? 1 : a.help_words ? 4 : 2;
+  c->batch_last_wgs = a.states ? a.grid * n_problems : a.help_words ? a.help_grid : n_problems;
   return VO_OK;
 }
 

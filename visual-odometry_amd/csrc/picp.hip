@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "vo_internal.h"
+#include "chain_scan.h"
 
 namespace vo {
 
@@ -854,6 +855,374 @@ __global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_kernel(BatchArgs 
   }
 }
 
+// ---- batched solver, fewer problems than CUs: the waves of the idle CUs take work off the problems' own workgroups -----
+// picp_batch_kernel is bound by VALU issue on the CUs it holds, and a call of 200 problems holds 200 of 256.  Here the launch
+// has one workgroup per CU: workgroup p < n_problems is problem p's HOME (poses, tail, results: everything picp_batch_kernel
+// does), the waves of the others are HELPERS, each on its own.  A home keeps the first `keep` trips of its problem (a trip:
+// PICP_BATCH_BLOCK x 4 correspondences, one float4 group per thread); what lies beyond is cut into CHUNKS of `C` wave-trips
+// (a wave-trip: 64 x 4 correspondences), and chunk g of the launch, counted in problem order, belongs to helper wave g.
+// Per round a helper wave waits for the pose of its chunk's problem, linearises the chunk, reduces it over its lanes and
+// publishes the 30 sums; the home adds the sums of its chunks IN CHUNK ORDER to its own, solves, and publishes the next
+// pose.  A helper wave meets no barrier and no other wave: twelve chunks per CU are in flight independently, which is what
+// hides the hand-over (an earlier form with one SEGMENT per helper workgroup at a time -- pose, data, reduction, barriers in
+// series, 3.6 segments per round -- left the homes waiting: no gain at 200 problems).
+//
+// What travels between workgroups are 8-byte words (tag << 32 | float bits), tag = the round the value belongs to, read
+// and written with agent-scope relaxed atomics (the accesses that go past a CU's L1 and an XCD's L2; a round trip between
+// two workgroups is 1.0-1.3 us, tools/micro/hop_latency.hip): a value and its validity arrive together, no fence, single
+// buffered (a home cannot publish pose r + 1 before every helper has delivered round r, i.e. has read pose r; a helper
+// cannot deliver round r + 1 before it has read pose r + 1, i.e. before the home has taken round r).
+//
+// The result does not depend on which wave computed a chunk, and therefore not on timing: a chunk's sums are a function of
+// (problem, pose, range) computed by ONE wave in a fixed order, the chunks are canonical (keep and C are functions of the
+// launch: problem count and sizes), the order of the additions is fixed.  That is also what makes every wait BOUNDED: a
+// home that has polled HELP_POLLS_HOME times for a chunk has one of its own waves compute it -- the same instructions on
+// the same data, the same bits -- and never waits for that chunk again; a helper that finds a pose tagged beyond its round
+// (the home has gone on without it), or none within HELP_POLLS_HELPER polls, leaves.  Nothing assumes that the workgroups of
+// the launch are resident together (another stream's kernel may hold CUs): late helpers cost time, not correctness, and
+// every wave reaches its exit.  Two problems with the same data in one launch get the same bits (same keep, same C).
+constexpr int HELP_TRIP = PICP_BATCH_BLOCK * 4;
+constexpr int HELP_WAVES = PICP_BATCH_BLOCK / 64;
+constexpr int HELP_MAXP = 1024;                 // problems the partition tables hold (the form serves n_problems < CUs)
+constexpr int HELP_MAXCHUNK = 64;               // chunks per problem (a home's set of chunks it computes itself is one 64-bit word)
+constexpr int HELP_SLACK10 = 20;                // what a helper's round costs beyond its wave-trips, in tenths of a trip
+constexpr int HELP_ITER100 = 71;                // a wave-trip on a CU full of helper waves, in hundredths of a home's trip
+constexpr unsigned HELP_POLLS_HOME = 1u << 9;   // ~0.6 us each: a few hundred microseconds
+constexpr unsigned HELP_POLLS_HELPER = 1u << 13;
+
+// wave-trips per chunk for a home that keeps `keep` trips: what a helper wave finishes within the home's round
+__device__ __forceinline__ int help_chunk_len(int keep, int slack10) {
+  const int c = ((keep * 10 - slack10) * 10) / HELP_ITER100;
+  return c < 1 ? 1 : c;
+}
+
+// Positions are BYTE offsets into the five arrays, 32 bits wide: a load is then scalar base + vector offset, one VGPR for all
+// five arrays (64-bit addresses per array and thread -- ten VGPRs -- get hoisted out of the round loop and spilled: four
+// dependent scratch reloads at the head of every round).
+__device__ __forceinline__ float4 ld16(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+// float4 groups i, i + STEP, ... < end of one problem, register double buffered as in picp_batch_kernel; `between` runs
+// after the first group's loads have been issued
+template <bool PINHOLE, bool KEEP, bool STATS, unsigned STEP, class Between>
+__device__ __forceinline__ void batch_stream(const CamK& cam, const Pose& T, float thr, const float* X, const float* Y,
+                                             const float* Z, const float* U, const float* V, unsigned i, unsigned end,
+                                             float acc[NACC], Between between) {
+  bool have = i < end;
+  float4 x, y, z, u, v;
+  {
+    const unsigned ic = have ? i : 0u;
+    x = ld16(X, ic); y = ld16(Y, ic); z = ld16(Z, ic); u = ld16(U, ic); v = ld16(V, ic);
+  }
+  between();
+  float4 x2, y2, z2, u2, v2;
+  while (have) {
+    i += STEP;
+    const bool have2 = i < end;
+    {
+      const unsigned ic = have2 ? i : i - STEP;
+      x2 = ld16(X, ic); y2 = ld16(Y, ic); z2 = ld16(Z, ic); u2 = ld16(U, ic); v2 = ld16(V, ic);
+    }
+    picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, thr, x.x, y.x, z.x, u.x, v.x, acc);
+    picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, thr, x.y, y.y, z.y, u.y, v.y, acc);
+    picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, thr, x.z, y.z, z.z, u.z, v.z, acc);
+    picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, thr, x.w, y.w, z.w, u.w, v.w, acc);
+    if (!have2) break;
+    i += STEP;
+    have = i < end;
+    {
+      const unsigned ic = have ? i : i - STEP;
+      x = ld16(X, ic); y = ld16(Y, ic); z = ld16(Z, ic); u = ld16(U, ic); v = ld16(V, ic);
+    }
+    picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, thr, x2.x, y2.x, z2.x, u2.x, v2.x, acc);
+    picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, thr, x2.y, y2.y, z2.y, u2.y, v2.y, acc);
+    picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, thr, x2.z, y2.z, z2.z, u2.z, v2.z, acc);
+    picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, thr, x2.w, y2.w, z2.w, u2.w, v2.w, acc);
+  }
+}
+
+template <bool PINHOLE, bool KEEP>
+__global__ __launch_bounds__(PICP_BATCH_BLOCK) void picp_batch_shared_kernel(BatchArgs a) {
+  __shared__ float s_red[HELP_WAVES * 4 * 32];
+  __shared__ float s_tot[32];
+  __shared__ float s_pose[12];
+  __shared__ float s_wave[HELP_WAVES][32];        // a wave's own 30 sums on their way from registers to lanes
+  __shared__ float s_rows[HELP_MAXCHUNK][32];     // a home's chunks of the round
+  __shared__ unsigned s_late[2];                  // chunks that did not arrive
+  __shared__ int s_misc[8];
+  __shared__ int s_n4[HELP_MAXP];                 // correspondences per problem (whole float4 groups)
+  __shared__ int s_chunkpre[HELP_MAXP + 1];       // chunks before problem p
+  __shared__ float4 s_cache[PICP_BATCH_LDS_TRIPS][5][PICP_BATCH_BLOCK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = a.n_problems, H = (int)gridDim.x - P;
+  const CamK cam = a.cam;
+  chain_word* rows = chain_ptr(a.help_words);
+  chain_word* posew = rows + (size_t)a.help_rows * 32;
+  auto clamp_n = [&](int p) { int n = a.n_pairs[p]; if (n < 0) n = 0; if ((size_t)n > a.cap) n = (int)a.cap; return n; };
+  auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };      // (values every lane read from the same LDS word)
+
+  // ---- the partition: every workgroup derives the same one from the problem sizes ----
+  if (tid < 8) s_misc[tid] = tid == 1 ? 0x7fffffff : 0;
+  __syncthreads();
+  {
+    int nmax = 0;
+    for (int p = tid; p < P; p += PICP_BATCH_BLOCK) {
+      const int n4 = clamp_n(p) & ~3;
+      s_n4[p] = n4;
+      nmax = n4 > nmax ? n4 : nmax;
+    }
+    if (nmax > 0) atomicMax(&s_misc[0], nmax);
+  }
+  __syncthreads();
+  const int c0 = PICP_BATCH_LDS_TRIPS > 1 ? PICP_BATCH_LDS_TRIPS : 1;     // a home keeps at least what it caches in LDS
+  const int Kmax_raw = (sgpr(s_misc[0]) + HELP_TRIP - 1) / HELP_TRIP;
+  const int Kmax = Kmax_raw > c0 ? Kmax_raw : c0;
+  const int slack10 = a.help_slack10 > 0 ? a.help_slack10 : HELP_SLACK10;
+  const int budget = H * HELP_WAVES < a.help_rows ? H * HELP_WAVES : a.help_rows;      // helper waves = rows
+  // chunks of problem p when the homes keep c trips (and whether any problem has more than a home can track)
+  auto chunks_of = [&](int n4, int c, int C) { const int left = n4 - c * HELP_TRIP; return left > 0 ? ((left + 255) / 256 + C - 1) / C : 0; };
+  if (a.help_keep > 0) {
+    if (tid == 0) s_misc[1] = a.help_keep < c0 ? c0 : (a.help_keep > Kmax ? Kmax : a.help_keep);
+  } else {
+    // the smallest `keep` whose leftovers, cut into chunks a helper wave finishes within the home's round, are at most as
+    // many as there are helper waves.  keep = Kmax (nothing left over) always passes.  One candidate per wave at a time (at
+    // most 128 candidates, evenly spaced, when the problems are longer than that many trips).
+    const int step = (Kmax - c0) / 128 + 1;
+    for (int c = c0 + wave * step; c <= Kmax; c += HELP_WAVES * step) {
+      const int Cc = help_chunk_len(c, slack10);
+      int cnt = 0, most = 0;
+      for (int p = lane; p < P; p += 64) { const int k = chunks_of(s_n4[p], c, Cc); cnt += k; most = k > most ? k : most; }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { cnt += __shfl_xor(cnt, d); const int o = __shfl_xor(most, d); most = o > most ? o : most; }
+      if (lane == 0 && cnt <= budget && most <= HELP_MAXCHUNK) atomicMin(&s_misc[1], c);
+    }
+  }
+  __syncthreads();
+  int keep = sgpr(s_misc[1] < Kmax ? s_misc[1] : Kmax);
+  int C = a.help_g > 0 ? a.help_g : help_chunk_len(keep, slack10);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (tid < 64) {                               // exclusive prefix of the chunk counts, 64 problems per step
+      int carry = 0, most = 0;
+      for (int base = 0; base < P; base += 64) {
+        const int p = base + lane;
+        const int k = p < P ? chunks_of(s_n4[p], keep, C) : 0;
+        most = k > most ? k : most;
+        int ki = k;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl_up(ki, d);
+          if (lane >= d) ki += o;
+        }
+        if (p < P) s_chunkpre[p] = carry + ki - k;
+        carry += __shfl(ki, 63);
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(most, d); most = o > most ? o : most; }
+      if (lane == 0) { s_chunkpre[P] = carry; s_misc[5] = most; }
+    }
+    __syncthreads();
+    if (sgpr(s_chunkpre[P]) <= budget && sgpr(s_misc[5]) <= HELP_MAXCHUNK) break;
+    keep = Kmax; C = help_chunk_len(keep, slack10);        // (pinned values that do not fit: no helper work)
+    __syncthreads();
+  }
+  const int N = sgpr(s_chunkpre[P]);
+
+  // One chunk: float4 groups [first, first + 256 * count) bytes-wise of problem p under pose T, by the calling WAVE alone.
+  // Lanes < 32 return the chunk's sums (lane k: accumulator k, 0 beyond NACC).
+  auto chunk_sums = [&](int p, int c, const Pose& T, auto stats_tag) {
+    constexpr bool STATS = decltype(stats_tag)::value;
+    const float* X = a.packed + (size_t)p * 5 * a.cap;
+    const int n4 = clamp_n(p) & ~3;
+    const unsigned first = (unsigned)(keep * HELP_TRIP + c * C * 256) * 4u;
+    unsigned end = first + (unsigned)C * 1024u;
+    if (end > (unsigned)n4 * 4u) end = (unsigned)n4 * 4u;
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    batch_stream<PINHOLE, KEEP, STATS, 1024u>(cam, T, a.thr, X, X + a.cap, X + 2 * a.cap, X + 3 * a.cap, X + 4 * a.cap,
+                                              first + (unsigned)lane * 16u, end, acc, [] {});
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+      float v = row16_allsum(acc[k]);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane == 0) s_wave[wave][k] = v;
+    }
+    return lane < NACC ? s_wave[wave][lane] : 0.f;
+  };
+
+  if ((int)blockIdx.x >= P) {
+    // ---- a helper: twelve waves, each with its own chunk ----
+    const int g = ((int)blockIdx.x - P) * HELP_WAVES + wave;
+    if (g >= N || a.n_iters <= 0 || a.help_absent) return;
+    int lo = 0, hi = P;                                     // the problem whose chunks include g
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sgpr(s_chunkpre[mid]) <= g) lo = mid; else hi = mid; }
+    const int p = lo, c = g - sgpr(s_chunkpre[p]);
+    for (int r = 0; r < a.n_iters; ++r) {
+      float val = 0.f;
+      bool ok = true;
+      if (r == 0) {
+        if (lane < 12) {
+          if (a.T0) val = lane < 9 ? a.T0[16 * (size_t)p + (lane % 3) + 4 * (lane / 3)] : a.T0[16 * (size_t)p + 12 + (lane - 9)];
+          else val = (lane < 9 && (lane % 4) == 0) ? 1.f : 0.f;
+        }
+      } else {
+        ok = false;
+        for (unsigned polls = 0; polls < HELP_POLLS_HELPER; ++polls) {
+          unsigned long long w = (unsigned long long)(unsigned)r << 32;
+          if (lane < 12) w = __hip_atomic_load(posew + (size_t)p * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int tag = (int)(w >> 32);
+          if (__all(tag == r)) { ok = true; val = __int_as_float((int)(unsigned)w); break; }
+          if (__any(tag > r)) break;                        // the home has gone on without this wave
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      if (!ok) return;
+      Pose T;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) T.R[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val), i));
+#pragma unroll
+      for (int i = 0; i < 3; ++i) T.t[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val), 9 + i));
+      VO_BATCH_T_VGPR(T);
+      float tot;
+      if (r == a.n_iters - 1) tot = chunk_sums(p, c, T, std::true_type{});
+      else tot = chunk_sums(p, c, T, std::false_type{});
+      if (lane < 32)
+        __hip_atomic_store(rows + (size_t)g * 32 + lane, ((unsigned long long)(unsigned)(r + 1) << 32) | (unsigned)__float_as_int(tot),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+
+  // ---- a home ----
+  const int p = blockIdx.x;
+  const int n = clamp_n(p);
+  const float* X = a.packed + (size_t)p * 5 * a.cap;
+  const float* Y = X + a.cap;
+  const float* Z = Y + a.cap;
+  const float* U = Z + a.cap;
+  const float* V = U + a.cap;
+  Pose T;
+  if (a.T0) {
+    T = pose_from_T16(a.T0 + 16 * (size_t)p);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) T.R[k] = (k % 4 == 0) ? 1.f : 0.f;
+    T.t[0] = T.t[1] = T.t[2] = 0.f;
+  }
+  T = uniform_pose(T);
+  VO_BATCH_T_VGPR(T);
+  const int n4 = n & ~3;
+  const int own_end = keep * HELP_TRIP < n4 ? keep * HELP_TRIP : n4;
+  const int row0 = sgpr(s_chunkpre[p]);
+  const int nchunk = sgpr(s_chunkpre[p + 1]) - row0;
+  unsigned long long own = 0;                                // chunks this home computes itself from now on
+  auto round = [&](int it, auto stats_tag) {
+    constexpr bool STATS = decltype(stats_tag)::value;
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    unsigned t16 = (unsigned)tid * 16u;                      // (opaque: this thread's byte offset is re-derived every round, not
+    asm volatile("" : "+v"(t16));                            //  kept -- and spilled -- as ready-made addresses across the rounds)
+    batch_stream<PINHOLE, KEEP, STATS, HELP_TRIP * 4u>(cam, T, a.thr, X, Y, Z, U, V, t16 + PICP_BATCH_LDS_TRIPS * HELP_TRIP * 4u,
+                                                       (unsigned)own_end * 4u, acc, [&] {
+#pragma unroll
+      for (int c = 0; c < PICP_BATCH_LDS_TRIPS; ++c) {
+        const unsigned j = t16 + c * HELP_TRIP * 4u;
+        if (j < (unsigned)n4 * 4u) {
+          float4 cx, cy, cz, cu, cv;
+          if (it == 0) {
+            cx = ld16(X, j); cy = ld16(Y, j); cz = ld16(Z, j); cu = ld16(U, j); cv = ld16(V, j);
+            s_cache[c][0][tid] = cx; s_cache[c][1][tid] = cy; s_cache[c][2][tid] = cz;
+            s_cache[c][3][tid] = cu; s_cache[c][4][tid] = cv;
+          } else {
+            cx = s_cache[c][0][tid]; cy = s_cache[c][1][tid]; cz = s_cache[c][2][tid];
+            cu = s_cache[c][3][tid]; cv = s_cache[c][4][tid];
+          }
+          picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, cx.x, cy.x, cz.x, cu.x, cv.x, acc);
+          picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, cx.y, cy.y, cz.y, cu.y, cv.y, acc);
+          picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, cx.z, cy.z, cz.z, cu.z, cv.z, acc);
+          picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, cx.w, cy.w, cz.w, cu.w, cv.w, acc);
+        }
+      }
+    });
+    for (int i = n4 + tid; i < n; i += PICP_BATCH_BLOCK)
+      picp_accumulate_t<PINHOLE, KEEP, STATS, true>(cam, T, a.thr, X[i], Y[i], Z[i], U[i], V[i], acc);
+    if (tid < 2) s_late[tid] = 0;
+    float tot = block_reduce_acc<HELP_WAVES>(acc, s_red);    // (its barrier also publishes s_late = 0)
+    if (nchunk > 0) {
+      // the chunks of the round: every wave polls for two rows at a time (lanes 0-31 one, 32-63 the other)
+      for (int j = 2 * wave + (lane >> 5); j - (lane >> 5) < nchunk; j += 2 * HELP_WAVES) {
+        const bool live = j < nchunk && !((own >> j) & 1ull);
+        bool got = !live;
+        float val = 0.f;
+        for (unsigned polls = 0; polls < HELP_POLLS_HOME; ++polls) {
+          if (live && !got) {
+            const unsigned long long w = __hip_atomic_load(rows + (size_t)(row0 + j) * 32 + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (a row is complete when all its 32 words carry the round's tag: checked per half wave below)
+            const bool hit = (int)(w >> 32) == it + 1;
+            const unsigned long long hits = __ballot(hit);
+            const unsigned half = (lane >> 5) ? (unsigned)(hits >> 32) : (unsigned)hits;
+            if (half == 0xffffffffu) { got = true; val = __int_as_float((int)(unsigned)w); }
+          }
+          if (__all(got)) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (live) {
+          if (got) s_rows[j][lane & 31] = val;
+          else if ((lane & 31) == 0) atomicOr(&s_late[j >> 5], 1u << (j & 31));
+        }
+      }
+      __syncthreads();
+      own |= (unsigned long long)(unsigned)sgpr((int)s_late[0]) | ((unsigned long long)(unsigned)sgpr((int)s_late[1]) << 32);
+      if (own) {                                             // chunks without a helper: wave j % 12 of the home stands in
+        for (int j = wave; j < nchunk; j += HELP_WAVES)
+          if ((own >> j) & 1ull) {
+            const float v = chunk_sums(p, j, T, stats_tag);
+            if (lane < 32) s_rows[j][lane] = v;
+          }
+        __syncthreads();
+      }
+      if (tid < 32)
+        for (int j = 0; j < nchunk; ++j) tot += s_rows[j][tid];    // in chunk order
+    }
+    if (tid < 32) s_tot[tid] = tot;
+    __syncthreads();
+    if (tid < 64) {
+      float b0, b1, b2;
+      pose_lane_operands(T, b0, b1, b2);
+      const Pose Tn = picp_tail_direct(picp_lane_value(s_tot, a.damping, nullptr, nullptr), b0, b1, b2);
+      if (tid == 0) {
+        store_pose12(s_pose, Tn);
+        if (it == a.n_iters - 1 && a.stats_out) {
+          float* so = a.stats_out + 4 * (size_t)p;
+          so[0] = s_tot[27]; so[1] = s_tot[28]; so[2] = s_tot[29]; so[3] = 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    if (nchunk > 0 && tid < 12)                              // the pose of round it + 1 (after the last round: lets late helpers go)
+      __hip_atomic_store(posew + (size_t)p * 16 + tid, ((unsigned long long)(unsigned)(it + 1) << 32) | (unsigned)__float_as_int(s_pose[tid]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    T = uniform_pose(load_pose12(s_pose));
+    VO_BATCH_T_VGPR(T);
+  };
+  for (int it = 0; it < a.n_iters; ++it) {
+    if (it == a.n_iters - 1) round(it, std::true_type{});
+    else round(it, std::false_type{});
+  }
+  if (tid == 0) {
+    float T16[16];
+    pose_to_T16(T, T16);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a.T_out[16 * (size_t)p + k] = T16[k];
+    if (a.n_iters <= 0 && a.stats_out) {
+      float* so = a.stats_out + 4 * (size_t)p;
+      so[0] = so[1] = so[2] = so[3] = 0.f;
+    }
+  }
+}
+
 // ---- reference-order ("exact") solver ---------------------------------------------------
 // Bit-identical to the reference's scalar float32 arithmetic (picp_solver.cpp:55-112; checked against the
 // CPU restatement by tests/test_gpu_exact.py): the per-correspondence terms are computed in parallel with every
@@ -1069,20 +1438,47 @@ static void launch_rounds_batch_t(hipStream_t st, const BatchArgs& a) {
 }
 
 // One workgroup per problem (all rounds in one launch) costs ~36 us per round at 50k correspondences whatever the problem
-// count (up to one per CU); the launch-per-round form costs ~5.5 us per round while its workgroups fit the chip once and
-// grows with their number.
+// count (up to one per CU) -- with the other CUs' waves helping (picp_batch_shared_kernel, up to 0.65 problems per CU) 12.6 us
+// up to ~60 problems and 0.2 us per problem beyond; the launch-per-round form costs ~5.5 us per round while its workgroups
+// fit the chip once and grows with their number.
 bool picp_batch_prefers_rounds(int n_problems, size_t cap, int n_iters, int n_cu) {
   if (n_iters <= 0 || n_cu <= 0) return false;
-  // per-round cost model fitted on MI355X (tools/batch_forms.py, 50k correspondences: the forms cross at ~30 problems):
-  // launch per round 5.5 us + 1.3 us per further "wave" of workgroups over the CUs; one workgroup per problem 36 us per
-  // 50k correspondences and per ceil(problems / CUs)
+  // per-round cost model fitted on MI355X (tools/batch_forms.py, 50k correspondences: the forms cross at ~10 problems; at ~30
+  // before the shared form): launch per round 5.5 us + 1.3 us per further "wave" of workgroups over the CUs
   const double wg_waves = (double)n_problems * (double)picp_grid_for((int)cap, n_cu) / (double)n_cu;
   const double t_rounds = 5.5 + 1.3 * (wg_waves > 1.0 ? wg_waves - 1.0 : 0.0);
-  const double t_onewg = 36.0 * ((double)cap / 50000.0) * (double)((n_problems + n_cu - 1) / n_cu);
+  const double size = (double)cap / 50000.0;
+  double t_onewg = 36.0 * size * (double)((n_problems + n_cu - 1) / n_cu);
+  if (picp_batch_shares(n_problems, cap, n_iters, n_cu)) {
+    const double per_problem = 0.2 * (double)n_problems * 256.0 / (double)n_cu;
+    t_onewg = 4.0 + size * ((per_problem > 12.6 ? per_problem : 12.6) - 4.0);      // (~4 us of a round are the hand-over, whatever the size)
+  }
   return t_rounds < t_onewg;
 }
 
 static hipError_t launch_picp_batch_solve(hipStream_t st, const BatchArgs& a);
+
+// The shared form (picp_batch_shared_kernel) for calls that leave CUs without a problem: from 6 trips per problem on (below,
+// a home's round is too short for a hand-over to pay).  VO_PICP_SHARE=0 in the environment keeps every call on
+// picp_batch_kernel; VO_PICP_HELP_KEEP / _G / _SLACK (tenths of a trip) pin what the kernel otherwise derives.
+struct HelpEnv { int share, keep, g, slack10, absent; };
+static HelpEnv help_env() {      // read per call (a batched call is milliseconds; tests flip these in-process)
+  auto num = [](const char* name, int dflt) { const char* v = getenv(name); return v && v[0] ? atoi(v) : dflt; };
+  return HelpEnv{num("VO_PICP_SHARE", 1), num("VO_PICP_HELP_KEEP", 0), num("VO_PICP_HELP_G", 0), num("VO_PICP_HELP_SLACK", 0), num("VO_PICP_HELP_ABSENT", 0)};
+}
+bool picp_batch_shares(int n_problems, size_t cap, int n_iters, int n_cu) {
+  // up to 0.65 problems per CU: beyond, the homes alone already draw what the memory side delivers (200 x 50k: 5.9 TB/s out of
+  // the Infinity Cache), and workgroups that add requests without adding bandwidth only add the hand-over (tools/share_ab.py:
+  // 160 problems 1.47 against 1.56 ms, 176 problems 1.68 against 1.60)
+  return help_env().share != 0 && n_iters > 0 && n_problems >= 1 && n_problems * 100 <= n_cu * 65 && n_problems <= HELP_MAXP &&
+         cap >= (size_t)6 * HELP_TRIP && cap < ((size_t)1 << 29);      // (32-bit byte offsets)
+}
+int picp_help_rows(int n_problems, int n_cu) { return n_cu > n_problems ? (n_cu - n_problems) * HELP_WAVES : 0; }     // one per helper wave
+void picp_help_args(BatchArgs& a, unsigned long long* words, int n_cu) {
+  a.help_words = words; a.help_grid = words ? n_cu : 0; a.help_rows = words ? picp_help_rows(a.n_problems, n_cu) : 0;
+  const HelpEnv e = help_env();
+  a.help_keep = e.keep; a.help_g = e.g; a.help_slack10 = e.slack10; a.help_absent = e.absent;
+}
 
 hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a) {
   if (a.n_problems <= 0) return hipSuccess;
@@ -1108,6 +1504,16 @@ static hipError_t launch_picp_batch_solve(hipStream_t st, const BatchArgs& a) {
     else if (ph) launch_rounds_batch_t<true, true>(st, a);
     else if (!keep) launch_rounds_batch_t<false, false>(st, a);
     else launch_rounds_batch_t<false, true>(st, a);
+    return hipGetLastError();
+  }
+  if (a.help_words && a.help_grid > a.n_problems) {          // fewer problems than CUs: the others help
+    hipError_t e = hipMemsetAsync(a.help_words, 0, sizeof(unsigned long long) * ((size_t)a.help_rows * 32 + (size_t)a.n_problems * 16), st);
+    if (e != hipSuccess) return e;
+    const dim3 g(a.help_grid), b(PICP_BATCH_BLOCK);
+    if (ph && !keep) hipLaunchKernelGGL((picp_batch_shared_kernel<true, false>), g, b, 0, st, a);
+    else if (ph) hipLaunchKernelGGL((picp_batch_shared_kernel<true, true>), g, b, 0, st, a);
+    else if (!keep) hipLaunchKernelGGL((picp_batch_shared_kernel<false, false>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((picp_batch_shared_kernel<false, true>), g, b, 0, st, a);
     return hipGetLastError();
   }
   const dim3 g(a.n_problems), b(PICP_BATCH_BLOCK);

@@ -130,8 +130,20 @@ struct BatchArgs {
                          //   (X_curr * triangulated_pc of vo_complete.cpp:159 without the pass that writes the moved cloud)
   int prepacked;         // the packed arrays are already filled (the join's writing pass gathered through its own pairs:
                          //   launch_join_batch with a sink): no gather pass
+  // fewer problems than CUs (picp_batch_shared_kernel): the workgroups beyond n_problems take trips off the problems' own
+  unsigned long long* help_words;   // picp_help_words(n_problems, n_cu) tagged words, zeroed by launch_picp_batch; null: form off
+  int help_grid;         // workgroups of the launch (n_problems + helpers), 0: form off
+  int help_rows;         // partial rows in help_words
+  int help_absent;       // test hook (VO_PICP_HELP_ABSENT=1): the helper waves leave at once, the homes stand in for all of them
+  int help_keep, help_g, help_slack10;   // 0: the kernel's own choice (experiments: VO_PICP_HELP_KEEP / _G / _SLACK): trips a home keeps,
+                         //   wave-trips per chunk, a helper's overhead per round in tenths of a trip
 };
 hipError_t launch_picp_batch(hipStream_t st, const BatchArgs& a);
+// the shared form: whether it serves this call, and what it needs (rows of 32 words, then 16 words per problem)
+bool picp_batch_shares(int n_problems, size_t cap, int n_iters, int n_cu);
+int picp_help_rows(int n_problems, int n_cu);
+void picp_help_args(BatchArgs& a, unsigned long long* words, int n_cu);     // words null: form off
+inline size_t picp_help_words(int n_problems, int n_cu) { return (size_t)picp_help_rows(n_problems, n_cu) * 32 + (size_t)n_problems * 16; }
 #if defined(__HIPCC__)
 // What the gather does for correspondence i of problem p: (measurement m, world point w) -> packed x, y, z, u, v; an index
 // outside its array leaves the marker and is counted (picp_batch_pack_kernel and the join's writing pass share this).
