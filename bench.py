@@ -940,6 +940,23 @@ def batched_leg(torch, vo, ctx, stream, args):
             _chk(ctx.lib, ctx.lib.vo_picp_batch_set_form(ctx.h, 0))
             row["iters_per_sec"] = P * args.iters / (row["auto_ms"] * 1e-3)
             out["few_problems"].append(row)
+        # fewer problems than CUs: the waves of the CUs without a problem take chunks of the others' rounds (picp_batch_shared_kernel,
+        # up to 0.65 problems per CU; VO_PICP_SHARE is read per call) against one workgroup per problem alone
+        out["helper_waves"] = []
+        for P in (32, 64, 128, 160):
+            row = {"pairs": P}
+            for share, name in (("0", "alone"), ("1", "with_helpers")):
+                os.environ["VO_PICP_SHARE"] = share
+                try:
+                    _chk(ctx.lib, ctx.lib.vo_picp_batch_set_form(ctx.h, 2))
+                    r = _batched_run(torch, vo, ctx, stream, args, P)
+                finally:
+                    os.environ.pop("VO_PICP_SHARE", None)
+                    _chk(ctx.lib, ctx.lib.vo_picp_batch_set_form(ctx.h, 0))
+                row[name + "_ms"] = r["ms_per_call"]
+            row["speedup"] = row["alone_ms"] / row["with_helpers_ms"]
+            row["iters_per_sec"] = P * args.iters / (row["with_helpers_ms"] * 1e-3)
+            out["helper_waves"].append(row)
     return out
 
 

@@ -3,7 +3,9 @@
 #   the reference's own oneRound loop (apps/one_round_rate, tools/micro/host_call_cost);
 #   kernel trace of the matcher stage when no query has a bitwise copy (tools/prof_open.sh 1.0);
 #   single-pass against count/scan/scatter compaction on one box (VO_ONE_PASS, tools/ab_frames.sh + kernel trace);
-#   the headline with 1..3 correspondences per thread (VO_PICP_PER_THREAD).
+#   the headline with 1..3 correspondences per thread (VO_PICP_PER_THREAD);
+#   the batched solver with and without helper waves over the problem count (tools/share_ab.py), the hand-over's round trip
+#   (tools/micro/hop_latency).
 set -e
 TAG=${1:-r05}
 O=gpurun_out/${TAG}_one_round_api.txt
@@ -25,5 +27,11 @@ O=gpurun_out/${TAG}_headline_per_thread.txt
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('%.0f iter/s  %.3f us/round' % (d['value'], d['roofline']['launch_us']))"; done; done; } > $O
 cat $O
-rm -rf gpurun_out/prof_${TAG}nocopy gpurun_out/prof_${TAG}onepass gpurun_out/prof_${TAG}twopass
+O=gpurun_out/${TAG}_share_ab.txt
+{ echo "# $(python3 tools/stamp.py line)"; echo "# tools/micro/bin/hop_latency: round trip of 32 tagged words between workgroup 0 and workgroup <key> of one launch (us)";
+  tools/micro/bin/hop_latency 2000;
+  echo "# tools/share_ab.py: vo_picp_solve_batch_dev, one workgroup per problem, 50k correspondences x 50 rounds: alone (share=0) / with helper waves (share=1)";
+  RAGGED=0 python3 tools/share_ab.py 16,32,64,96,128,160,176,200 share=0 share=1; RAGGED=1 python3 tools/share_ab.py 64,128,200 share=0 share=1; } > $O 2>&1
+cat $O
+rm -rf gpurun_out/prof_${TAG}nocopy gpurun_out/prof_${TAG}onepass gpurun_out/prof_${TAG}twopass gpurun_out/share_ab_T.npy
 du -sh gpurun_out
