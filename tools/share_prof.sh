@@ -11,5 +11,8 @@ for st in ${2:-VO_PICP_SHARE=0 VO_PICP_SHARE=1}; do
   f=$(find /tmp/share_prof -name '*kernel_stats.csv' | head -1)
   echo "== $st (P=$P): $(grep '"ms"' /tmp/share_prof.log)"
   [ -n "$f" ] || { tail -20 /tmp/share_prof.log; find /tmp/share_prof | head; exit 1; }
-  grep -E "picp_batch|fillBuffer" "$f" | awk -F'","' '{gsub(/"/,"",$1); printf "   %-60.60s calls %s avg %.1f us min %.1f max %.1f\n", $1, $2, $4/1000, $6/1000, $7/1000}'
+  python3 -c 'import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if "picp_batch" in r["Name"] or "fillBuffer" in r["Name"]:
+        print("   %-58.58s calls %4s  avg %9.1f us  min %9.1f  max %9.1f" % (r["Name"], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))' "$f"
 done
