@@ -2,7 +2,7 @@
 """Batched solver with fewer problems than CUs: picp_batch_kernel (one workgroup per problem, the other CUs idle) against
 picp_batch_shared_kernel (the other CUs take trips off the problems' workgroups), which the environment switches
 (VO_PICP_SHARE, read once per process: every setting runs in a child process).
-  usage (GPU box): tools/share_ab.py [P,P,...] [setting setting ...]     setting: share=0 | keep=K | g=G | slack=S, joined by '+'
+  usage (GPU box): tools/share_ab.py [P,P,...] [setting setting ...]     setting: share=0 | keep=K (trips a home keeps) | g=G (wave-trips per chunk) | slack=S | absent=1, joined by '+'
 Per setting and problem count: ms per vo_picp_solve_batch_dev call (form 2, 50 rounds, 50k correspondences per problem, the
 gather pass included), whether problems with the same data got the same bits, and the largest difference of a pose entry
 against the first setting's."""
@@ -56,7 +56,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     Ps = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [200]
     settings = sys.argv[2:] or ["share=0", "share=1"]
-    names = {"share": "VO_PICP_SHARE", "keep": "VO_PICP_HELP_KEEP", "g": "VO_PICP_HELP_G", "slack": "VO_PICP_HELP_SLACK", "debug": "VO_PICP_HELP_DEBUG"}
+    names = {"share": "VO_PICP_SHARE", "keep": "VO_PICP_HELP_KEEP", "g": "VO_PICP_HELP_G", "slack": "VO_PICP_HELP_SLACK", "absent": "VO_PICP_HELP_ABSENT"}
     for ragged in ([int(os.environ['RAGGED'])] if 'RAGGED' in os.environ else (0, 1)):
         for P in Ps:
             base = None
