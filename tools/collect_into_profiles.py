@@ -8,7 +8,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 keep = ["bench_line.json", "bench_kernel_stats.csv", "headline_check.txt", "headline_kernel_stats.csv", "headline_stamps.json",
         "headline_stamps.txt", "pmc_dram.txt", "pmc_fetch_write.json", "pmc_match.txt", "pmc_valu.json", "sq_frames.txt",
-        "one_round_api.txt", "nocopy_matcher.txt", "one_pass_ab.txt", "headline_per_thread.txt", "share_ab.txt"]
+        "one_round_api.txt", "nocopy_matcher.txt", "one_pass_ab.txt", "headline_per_thread.txt", "share_ab.txt", "share_prof.txt"]
 for k in keep:
     src = os.path.join(G, f"{tag}_{k}")
     if os.path.exists(src):

@@ -33,5 +33,9 @@ O=gpurun_out/${TAG}_share_ab.txt
   echo "# tools/share_ab.py: vo_picp_solve_batch_dev, one workgroup per problem, 50k correspondences x 50 rounds: alone (share=0) / with helper waves (share=1)";
   RAGGED=0 python3 tools/share_ab.py 16,32,64,96,128,160,176,200 share=0 share=1; RAGGED=1 python3 tools/share_ab.py 64,128,200 share=0 share=1; } > $O 2>&1
 cat $O
+O=gpurun_out/${TAG}_share_prof.txt
+{ echo "# $(python3 tools/stamp.py line)"; echo "# tools/share_prof.sh: rocprofv3 --kernel-trace --stats of tools/share_ab.py child (7 calls of 50 rounds, 50k correspondences per problem), alone / with helper waves";
+  tools/share_prof.sh 64 "VO_PICP_SHARE=0 VO_PICP_SHARE=1"; tools/share_prof.sh 128 "VO_PICP_SHARE=0 VO_PICP_SHARE=1"; } > $O 2>&1
+cat $O
 rm -rf gpurun_out/prof_${TAG}nocopy gpurun_out/prof_${TAG}onepass gpurun_out/prof_${TAG}twopass gpurun_out/share_ab_T.npy
 du -sh gpurun_out
