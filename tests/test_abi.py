@@ -60,3 +60,18 @@ def test_fails_loudly_without_device(vo):
         vo.Context(0)
     with pytest.raises(vo.VoError):
         vo.compute_correspondences_images([[0.0] * 10], [[0.0] * 10])
+
+
+def test_every_environment_switch_is_documented():
+    """every VO_* variable the library, the facade or the apps read appears in DESIGN.md section 9's table"""
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    found = set()
+    for base in ("visual-odometry_amd", os.path.join("include", "vo"), "apps"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                    src = open(os.path.join(dirpath, f), errors="replace").read()
+                    found |= set(re.findall(r'(?:getenv|num|environ\.get)\(\s*"(VO_[A-Z0-9_]+)"', src))
+    assert len(found) >= 15
+    missing = sorted(k for k in found if "`%s`" % k not in design)
+    assert not missing, missing
